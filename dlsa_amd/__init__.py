@@ -1,0 +1,8 @@
+"""dlsa_amd -- MI355X-native engine for the DLSA hot path (feng-li/dlsa):
+per-partition logistic fit -> X'WX / X'W theta -> one-round sum -> WLS combine -> LARS shrinkage.
+
+The compute path is hand-written HIP for gfx950 behind the C ABI in include/dlsa_hip.h
+(libdlsa_hip.so); this package is the Python host side mirroring the reference's operator
+interface (dlsa/models.py, dlsa/dlsa.py, dlsa/lsa.py).  There is no CPU fallback.
+"""
+__version__ = "0.1.0"

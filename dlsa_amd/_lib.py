@@ -1,0 +1,78 @@
+"""ctypes binding of libdlsa_hip.so (the C ABI declared in include/dlsa_hip.h).
+
+There is no CPU fallback: importing the engine without the built library, or calling it
+without a GPU, raises.  Build with `make` (or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdlsa_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_dbl = ctypes.c_double
+c_vp = ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); every symbol include/dlsa_hip.h declares
+SIGNATURES = {
+    "dlsa_version": (c_int, []),
+    "dlsa_last_error": (c_int, [ctypes.c_char_p, c_int]),
+    "dlsa_synth_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dlsa_synth_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dlsa_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
+    "dlsa_gram_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_gram_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_logit_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dlsa_logit_pass_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_loglik_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_irls_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dlsa_irls_fit_f64": (c_int, [c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_int, c_int, c_dbl, c_int,
+                                  c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                  ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
+    "dlsa_sum_blocks_f64": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_int), c_vp, c_vp]),
+    "dlsa_solve_workspace_bytes": (c_sz, [c_int]),
+    "dlsa_spd_solve_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_lars_workspace_bytes": (c_sz, [c_int]),
+    "dlsa_lars_lsa_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_int,
+                                  c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp, c_sz, c_vp]),
+    "dlsa_gram_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+}
+
+_lib = None
+
+
+class DlsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libdlsa_hip status %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load the shared library (no GPU needed to load it or to resolve symbols)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: the HIP extension has not been built (run `make`). "
+                          "dlsa_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().dlsa_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(code):
+    if code != 0:
+        raise DlsaError(code, last_error())

@@ -1,0 +1,295 @@
+// Fused logit pass over the rows (HBM-bound; one read of X):
+//   eta_i = x_i . beta,  mu_i = sigmoid(eta_i),  w_i = mu_i (1 - mu_i),
+//   g = X'(y - mu),  loglik = sum_i y_i log mu_i + (1 - y_i) log(1 - mu_i).
+// Reference call sites: dlsa/models.py:113-114 (the inner products inside sklearn's newton-cg
+// fit and predict_proba), :130 (the p(1-p) weights), :217-222 (log-likelihood).
+//
+// Layout: a wave owns RB consecutive rows at a time.  Lane l holds columns 128c + 2l + {0,1}
+// (c < NC), i.e. one 16-byte load per lane per 128-column chunk = 1 KiB coalesced per wave
+// instruction.  The RB row dot products are reduced with ONE merged butterfly (the first
+// log2(RB) exchange steps halve the number of live rows), the transcendental part runs once
+// per RB rows instead of once per row, and the residuals are broadcast back through SGPRs for
+// the rank-1 update of g, which stays in registers for the whole kernel.
+#include "common.h"
+
+namespace dlsa {
+
+constexpr int LOGIT_THREADS = 256;
+constexpr int LOGIT_WAVES = LOGIT_THREADS / 64;
+constexpr int LOGIT_MAX_BLOCKS = 2048;
+
+template <int RB>
+__device__ __forceinline__ double merged_reduce(double (&v)[RB], int lane) {
+    // after this, every lane holds the wave-sum of row rsel(lane)
+    int m = 32;
+#pragma unroll
+    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) {
+        const int half = cnt / 2;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const double mine = up ? v[i + half] : v[i];
+            const double other = up ? v[i] : v[i + half];
+            v[i] = mine + __shfl_xor(other, m, 64);
+        }
+    }
+    double s = v[0];
+    for (; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    return s;
+}
+
+// row handled by `lane` after merged_reduce, and the representative lane of row i
+template <int RB>
+__device__ __forceinline__ int row_of_lane(int lane) {
+    int r = 0, m = 32;
+#pragma unroll
+    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) r += ((lane & m) ? 1 : 0) * (cnt / 2);
+    return r;
+}
+template <int RB>
+__host__ __device__ constexpr int lane_of_row(int i) {
+    int lane = 0, m = 32;
+    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) {
+        if (i >= cnt / 2) { lane |= m; i -= cnt / 2; }
+    }
+    return lane;
+}
+template <int RB>
+__host__ __device__ constexpr int rep_mask() {   // lane bits that must be zero for a representative lane
+    int used = 0, m = 32;
+    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) used |= m;
+    return 63 & ~used;
+}
+
+struct LogitArgs {
+    const double* X;
+    const double* y;
+    const double* beta;
+    double* w_out;     // nullable
+    double* gpart;     // [nblocks][NC*128]
+    double* llpart;    // [nblocks]
+    int64_t ldx;
+    int64_t n;
+    int p;
+};
+
+template <int NC, int RB, bool VEC>
+__global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
+    __shared__ double red[NC * 128 + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    double2 b[NC], g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = c * 128 + 2 * lane;
+        b[c].x = col < a.p ? a.beta[col] : 0.0;
+        b[c].y = col + 1 < a.p ? a.beta[col + 1] : 0.0;
+        g[c].x = 0.0; g[c].y = 0.0;
+    }
+    double ll = 0.0;
+    const int myrow = row_of_lane<RB>(lane);
+    const bool rep = (lane & rep_mask<RB>()) == 0;
+
+    const int64_t nbatch = (a.n + RB - 1) / RB;
+    const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
+    for (int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave; bt < nbatch; bt += stride) {
+        const int64_t row0 = bt * RB;
+        double2 x[RB][NC];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int64_t r = row0 + i;
+            const double* src = a.X + r * a.ldx + 2 * lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = c * 128 + 2 * lane;
+                double2 v; v.x = 0.0; v.y = 0.0;
+                if (r < a.n) {
+                    if (col + 1 < a.p) {
+                        if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
+                        else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
+                    } else if (col < a.p) {
+                        v.x = src[c * 128];
+                    }
+                }
+                x[i][c] = v;
+            }
+        }
+        double dot[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s = fma(x[i][c].x, b[c].x, fma(x[i][c].y, b[c].y, s));
+            dot[i] = s;
+        }
+        const double eta = merged_reduce<RB>(dot, lane);
+        const int64_t r = row0 + myrow;
+        const bool valid = r < a.n;
+        const double yv = valid ? a.y[r] : 0.0;
+        // e = exp(-|eta|);  mu = sigmoid(eta);  w = mu(1-mu) = e/(1+e)^2
+        const double e = exp(-fabs(eta));
+        const double inv = 1.0 / (1.0 + e);
+        const double mu = eta >= 0.0 ? inv : e * inv;
+        const double wgt = e * inv * inv;
+        const double resid = valid ? (yv - mu) : 0.0;
+        if (valid && rep) {
+            if (a.w_out) a.w_out[r] = wgt;
+            // y log mu + (1-y) log(1-mu) = y*eta - softplus(eta)
+            ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const double ri = __shfl(resid, lane_of_row<RB>(i), 64);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                g[c].x = fma(ri, x[i][c].x, g[c].x);
+                g[c].y = fma(ri, x[i][c].y, g[c].y);
+            }
+        }
+    }
+
+    // block reduction of g and loglik: waves add into LDS one after another (fixed order)
+    for (int m = 32; m >= 1; m >>= 1) ll += __shfl_xor(ll, m, 64);
+    for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double* dst = red + c * 128 + 2 * lane;
+                if (wv == 0) { dst[0] = g[c].x; dst[1] = g[c].y; }
+                else { dst[0] += g[c].x; dst[1] += g[c].y; }
+            }
+            if (lane == 0) { if (wv == 0) red[NC * 128] = ll; else red[NC * 128] += ll; }
+        }
+        __syncthreads();
+    }
+    double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 128);
+    for (int col = tid; col < NC * 128; col += LOGIT_THREADS) gp[col] = red[col];
+    if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
+}
+
+// g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b]   (fixed order -> deterministic)
+__global__ void logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart,
+                                    int nblocks, int pitch, int p, double* __restrict__ g,
+                                    double* __restrict__ loglik) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g && col < p) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += gpart[(int64_t)b * pitch + col];
+        g[col] = s;
+    }
+    if (loglik && blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += llpart[b];
+        *loglik = s;
+    }
+}
+
+static int logit_nc(int p) {
+    const int chunks = (p + 127) / 128;
+    int nc = 1;
+    while (nc < chunks) nc *= 2;
+    return nc;
+}
+
+static int logit_blocks(int64_t n, int rb) {
+    const int64_t nbatch = (n + rb - 1) / rb;
+    int64_t blocks = (nbatch + LOGIT_WAVES * 4 - 1) / (LOGIT_WAVES * 4);   // >= 4 batches per wave
+    if (blocks < 1) blocks = 1;
+    if (blocks > LOGIT_MAX_BLOCKS) blocks = LOGIT_MAX_BLOCKS;
+    return (int)blocks;
+}
+
+template <int NC, int RB>
+static void launch_logit(const LogitArgs& a, bool vec, int blocks, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((logit_kernel<NC, RB, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((logit_kernel<NC, RB, false>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+}
+
+size_t logit_workspace_bytes_impl(int64_t n, int p) {
+    (void)n;
+    const int nc = logit_nc(p);
+    return align_up((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double), 256) +
+           align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
+}
+
+int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
+                    double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream) {
+    DLSA_REQUIRE(X && y && beta, "logit_pass: null X, y or beta");
+    DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p, "logit_pass: bad shape n=%lld p=%d ldx=%lld", (long long)n, p, (long long)ldx);
+    DLSA_REQUIRE(p <= 2048, "logit_pass: p=%d > 2048 not supported", p);
+    const int nc = logit_nc(p);
+    if (!ws || ws_bytes < logit_workspace_bytes_impl(n, p) || ((uintptr_t)ws & 255)) {
+        set_error("logit_pass: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    Arena ar(ws, ws_bytes);
+    LogitArgs a;
+    a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p;
+    a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
+    a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    int blocks;
+    switch (nc) {
+        case 1: blocks = logit_blocks(n, 8); launch_logit<1, 8>(a, vec, blocks, stream); break;
+        case 2: blocks = logit_blocks(n, 8); launch_logit<2, 8>(a, vec, blocks, stream); break;
+        case 4: blocks = logit_blocks(n, 4); launch_logit<4, 4>(a, vec, blocks, stream); break;
+        case 8: blocks = logit_blocks(n, 2); launch_logit<8, 2>(a, vec, blocks, stream); break;
+        default: blocks = logit_blocks(n, 1); launch_logit<16, 1>(a, vec, blocks, stream); break;
+    }
+    DLSA_HIP_CHECK(hipGetLastError());
+    if (g || loglik) {
+        hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 127) / 128), dim3(128), 0, stream,
+                           (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, loglik);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
+    return DLSA_OK;
+}
+
+__global__ void gather_column_kernel(const double* __restrict__ par, int64_t ldpar, int col, int p,
+                                     double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) out[i] = par[(int64_t)i * ldpar + col];
+}
+
+}  // namespace dlsa
+
+extern "C" {
+
+// N1 (dlsa/models.py:217-222).  First cut: one fused logit pass per estimator column (c reads
+// of X); the single-read multi-column variant is a planned optimisation.
+int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
+                    int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(X && y && par && out, "loglik: null argument");
+    DLSA_REQUIRE(c > 0 && c <= 8 && ldpar >= c, "loglik: need 1 <= c <= 8 and ldpar >= c");
+    const size_t need = logit_workspace_bytes_impl(n, p) + 256 + align_up((size_t)p * sizeof(double), 256);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("loglik: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    double* bcol = (double*)ar.take((size_t)p * sizeof(double));
+    void* lws = ar.take(logit_workspace_bytes_impl(n, p));
+    for (int j = 0; j < c; ++j) {
+        hipLaunchKernelGGL(gather_column_kernel, dim3((p + 255) / 256), dim3(256), 0, s, par, ldpar, j, p, bcol);
+        int rc = logit_pass_impl(X, ldx, y, bcol, n, p, nullptr, nullptr, out + j, lws, logit_workspace_bytes_impl(n, p), s);
+        if (rc) return rc;
+    }
+    return DLSA_OK;
+}
+
+size_t dlsa_logit_workspace_bytes(int64_t n, int p) {
+    if (p <= 0 || p > 2048 || n < 0) return 0;
+    return dlsa::logit_workspace_bytes_impl(n, p);
+}
+
+int dlsa_logit_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n,
+                        int p, double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes,
+                        void* stream) {
+    return dlsa::logit_pass_impl(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// Counter-based synthetic rows (replaces simulate_logistic, dlsa/models.py:6-40, whose
+// per-row Python loop is O(n^2) and unseeded).  Row i is a pure function of (seed, i):
+// Philox-4x32-10 with counter (i_lo, i_hi, pair, stream) and key (seed, 0).  The integer
+// pipeline and the uint32 -> double conversion are bit-identical to oracle/dlsa_oracle.py, so
+// the uniform variant gives the CPU oracle and every GPU shard exactly the same rows.
+#include "common.h"
+
+namespace dlsa {
+
+struct u4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(u4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x;
+        const unsigned long long p1 = 0xCD9E8D57ull * c.z;
+        u4 n;
+        n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (unsigned)p1;
+        n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (unsigned)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ double u53(unsigned hi, unsigned lo) {
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// one thread per (row, column pair); also accumulates eta = x . beta_true per row when y != NULL
+template <typename T>
+__global__ void synth_features_kernel(unsigned long long seed, int64_t row0, int64_t n, int p, int kind,
+                                      int ones_col, T* __restrict__ X, int64_t ldx) {
+    const int npair = (p + 1) / 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * npair) return;
+    const int64_t r = idx / npair;
+    const int jp = (int)(idx % npair);
+    const unsigned long long gi = (unsigned long long)(row0 + r);
+    u4 c; c.x = (unsigned)gi; c.y = (unsigned)(gi >> 32); c.z = (unsigned)jp; c.w = 0u;
+    const u4 o = philox4x32_10(c, (unsigned)seed, 0u);
+    const double ua = u53(o.x, o.y), ub = u53(o.z, o.w);
+    double a, b;
+    if (kind == 0) { a = ua - 0.5; b = ub - 0.5; }
+    else {
+        const double rad = sqrt(-2.0 * log(1.0 - ua)) * 0.28867513459481287;   // sd = sqrt(1/12)
+        const double ang = 6.283185307179586 * ub;
+        a = rad * cos(ang); b = rad * sin(ang);
+    }
+    T* row = X + r * ldx + (ones_col ? 1 : 0);
+    row[2 * jp] = (T)a;
+    if (2 * jp + 1 < p) row[2 * jp + 1] = (T)b;
+    if (ones_col && jp == 0) X[r * ldx] = (T)1;
+}
+
+// y_i = 1{u_i < sigmoid(x_i . beta)} with u_i from counter (i_lo, i_hi, 0, 1), key (seed+1, 0).
+// One wave per row; X already holds the features.
+template <typename T>
+__global__ void synth_labels_kernel(unsigned long long seed, int64_t row0, int64_t n, int pcols,
+                                    const T* __restrict__ X, int64_t ldx, const T* __restrict__ beta,
+                                    int p_true_ones, int first_col, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    double s = 0.0;
+    const T* row = X + r * ldx;
+    if (beta) {
+        for (int k = lane; k < pcols; k += 64) s += (double)row[k] * (double)beta[k];
+    } else {
+        // default truth: ones on the first p_true_ones feature columns (models.py:12,18-19)
+        for (int k = lane; k < p_true_ones; k += 64) s += (double)row[first_col + k];
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) {
+        const unsigned long long gi = (unsigned long long)(row0 + r);
+        u4 c; c.x = (unsigned)gi; c.y = (unsigned)(gi >> 32); c.z = 0u; c.w = 1u;
+        const u4 o = philox4x32_10(c, (unsigned)(seed + 1ull), 0u);
+        const double u = u53(o.x, o.y);
+        const double prob = 1.0 / (1.0 + exp(-s));
+        y[r] = (u < prob) ? (T)1 : (T)0;
+    }
+}
+
+template <typename T>
+int synth_impl(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col, T* X, int64_t ldx,
+               T* y, const T* beta_true, hipStream_t s) {
+    DLSA_REQUIRE(X, "synth: null X");
+    DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p + (ones_col ? 1 : 0), "synth: bad shape n=%lld p=%d ldx=%lld",
+                 (long long)n, p, (long long)ldx);
+    DLSA_REQUIRE(kind == 0 || kind == 1, "synth: kind must be 0 (uniform) or 1 (gaussian)");
+    if (n == 0) return DLSA_OK;
+    const int npair = (p + 1) / 2;
+    const int64_t total = n * npair;
+    const int64_t blocks = (total + 255) / 256;
+    DLSA_REQUIRE(blocks < (1ll << 31), "synth: too many elements for one launch; generate in chunks");
+    hipLaunchKernelGGL((synth_features_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (unsigned long long)seed, row0, n, p, kind, ones_col, X, ldx);
+    DLSA_HIP_CHECK(hipGetLastError());
+    if (y) {
+        const int64_t lb = (n + 3) / 4;
+        DLSA_REQUIRE(lb < (1ll << 31), "synth: too many rows for one launch; generate in chunks");
+        hipLaunchKernelGGL((synth_labels_kernel<T>), dim3((unsigned)lb), dim3(256), 0, s,
+                           (unsigned long long)seed, row0, n, p + (ones_col ? 1 : 0), (const T*)X, ldx, beta_true,
+                           (int)(p * 0.4), ones_col ? 1 : 0, y);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
+    return DLSA_OK;
+}
+
+}  // namespace dlsa
+
+extern "C" {
+int dlsa_synth_f64(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col, double* X,
+                   int64_t ldx, double* y, const double* beta_true, void* stream) {
+    return dlsa::synth_impl<double>(seed, row0, n, p, kind, ones_col, X, ldx, y, beta_true, (hipStream_t)stream);
+}
+int dlsa_synth_f32(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col, float* X,
+                   int64_t ldx, float* y, const float* beta_true, void* stream) {
+    return dlsa::synth_impl<float>(seed, row0, n, p, kind, ones_col, X, ldx, y, beta_true, (hipStream_t)stream);
+}
+}

@@ -1,0 +1,205 @@
+"""Tensor-level front end of the HIP engine.
+
+PyTorch-ROCm is used for device memory and streams only: every function here hands raw
+device pointers to libdlsa_hip.so through the C ABI of include/dlsa_hip.h and returns torch
+tensors that own the results.  There is no CPU path -- a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+SYNTH_UNIFORM = 0
+SYNTH_GAUSSIAN = 1
+
+PART_STATUS = {0: "OK", 1: "NOT_CONVERGED", 2: "NOT_SPD", 3: "NAN", 4: "EMPTY"}
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dlsa_amd runs on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (256-byte aligned by the torch allocator)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws_cache.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspace():
+    _ws_cache.clear()
+
+
+def _rowmajor(X):
+    if X.dim() != 2 or X.stride(1) != 1:
+        raise ValueError("X must be a 2-D row-major tensor (stride(1) == 1)")
+    return X.stride(0) if X.shape[0] > 1 else max(X.stride(0), X.shape[1])
+
+
+def synth(seed, row0, n, p, kind=SYNTH_UNIFORM, ones_col=False, labels=True, dtype=torch.float64,
+          device="cuda", beta_true=None, out=None):
+    """Seeded synthetic logistic rows (replaces simulate_logistic, dlsa/models.py:6-40).
+    Returns (X [n, p + ones_col], y [n] or None)."""
+    lib = _lib.load()
+    cols = p + (1 if ones_col else 0)
+    X = out if out is not None else torch.empty((n, cols), dtype=dtype, device=device)
+    _require_gpu(X)
+    y = torch.empty((n,), dtype=dtype, device=X.device) if labels else None
+    fn = lib.dlsa_synth_f64 if dtype == torch.float64 else lib.dlsa_synth_f32
+    # one launch handles < 2^31 workgroups: chunk the rows
+    chunk = max(1, (1 << 28) // max(1, (p + 1) // 2))
+    ld = _rowmajor(X)
+    for r in range(0, n, chunk):
+        m = min(chunk, n - r)
+        check(fn(seed, row0 + r, m, p, kind, 1 if ones_col else 0,
+                 _ptr(X[r:]), ld, _ptr(y[r:]) if labels else ctypes.c_void_p(0),
+                 _ptr(beta_true), _stream()))
+    return X, y
+
+
+def gram(X, w=None, out=None, accumulate=False):
+    """H = X' diag(w) X (dlsa/models.py:130) on the MFMA Gram kernel.  X [n,p] fp64/fp32."""
+    lib = _lib.load()
+    _require_gpu(X, w, out)
+    n, p = X.shape
+    ldx = _rowmajor(X)
+    H = out if out is not None else torch.empty((p, p), dtype=X.dtype, device=X.device)
+    es = X.element_size()
+    nb = lib.dlsa_gram_workspace_bytes(n, p, es)
+    ws = _workspace(nb, X.device)
+    fn = lib.dlsa_gram_f64 if X.dtype == torch.float64 else lib.dlsa_gram_f32
+    if w is not None and (w.dtype != X.dtype or not w.is_contiguous() or w.numel() != n):
+        raise ValueError("w must be a contiguous vector of n elements with X's dtype")
+    check(fn(_ptr(X), ldx, _ptr(w), n, p, _ptr(H), H.stride(0), 1 if accumulate else 0,
+             _ptr(ws), ws.numel(), _stream()))
+    return H
+
+
+def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True):
+    """One fused pass: w = mu(1-mu), g = X'(y-mu), loglik.  Returns (w, g, loglik) tensors."""
+    lib = _lib.load()
+    _require_gpu(X, y, beta)
+    n, p = X.shape
+    ldx = _rowmajor(X)
+    w = torch.empty((n,), dtype=torch.float64, device=X.device) if want_w else None
+    g = torch.empty((p,), dtype=torch.float64, device=X.device) if want_g else None
+    ll = torch.empty((1,), dtype=torch.float64, device=X.device) if want_loglik else None
+    nb = lib.dlsa_logit_workspace_bytes(n, p)
+    ws = _workspace(nb, X.device)
+    check(lib.dlsa_logit_pass_f64(_ptr(X), ldx, _ptr(y), _ptr(beta), n, p, _ptr(w), _ptr(g), _ptr(ll),
+                                  _ptr(ws), ws.numel(), _stream()))
+    return w, g, ll
+
+
+def loglik(X, y, par):
+    """Log-likelihood of each column of par [p, c] (dlsa/models.py:217-222)."""
+    lib = _lib.load()
+    _require_gpu(X, y, par)
+    n, p = X.shape
+    par = par.contiguous()
+    c = par.shape[1]
+    out = torch.empty((c,), dtype=torch.float64, device=X.device)
+    nb = lib.dlsa_logit_workspace_bytes(n, p) + 8 * p + 1024
+    ws = _workspace(nb, X.device)
+    check(lib.dlsa_loglik_f64(_ptr(X), _rowmajor(X), _ptr(y), n, p, _ptr(par), par.stride(0), c, _ptr(out),
+                              _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def irls_fit(X, y, part_offsets, tol=1e-13, max_iter=100):
+    """Per-partition exact-MLE fit + local quadratic approximation (dlsa/models.py:110-131).
+    part_offsets: K+1 ints; partition k = rows [off[k], off[k+1]).  Returns a dict with
+    coef [K,p], Sig_invMcoef [K,p], Sig_inv [K,p,p] (device) and n_iter/status/loglik (host)."""
+    lib = _lib.load()
+    _require_gpu(X, y)
+    n, p = X.shape
+    offs = [int(v) for v in part_offsets]
+    K = len(offs) - 1
+    if offs[0] < 0 or offs[-1] > n:
+        raise ValueError("part_offsets out of range")
+    dev = X.device
+    coef = torch.empty((K, p), dtype=torch.float64, device=dev)
+    smc = torch.empty((K, p), dtype=torch.float64, device=dev)
+    sig = torch.empty((K, p, p), dtype=torch.float64, device=dev)
+    max_rows = max(offs[k + 1] - offs[k] for k in range(K))
+    nb = lib.dlsa_irls_workspace_bytes(max_rows, p)
+    ws = _workspace(nb, dev)
+    c_offs = (ctypes.c_int64 * (K + 1))(*offs)
+    n_iter = (ctypes.c_int * K)()
+    status = (ctypes.c_int * K)()
+    ll = (ctypes.c_double * K)()
+    rc = lib.dlsa_irls_fit_f64(_ptr(X), _rowmajor(X), _ptr(y), c_offs, K, p, tol, max_iter,
+                               _ptr(coef), _ptr(sig), _ptr(smc), n_iter, status, ll,
+                               _ptr(ws), ws.numel(), _stream())
+    if rc not in (0, 4, 5, 6):     # per-partition soft failures are reported through `status`
+        check(rc)
+    return {"coef": coef, "Sig_invMcoef": smc, "Sig_inv": sig, "n_iter": list(n_iter),
+            "status": list(status), "loglik": list(ll), "rc": rc}
+
+
+def sum_blocks(coef, smc, sig, mask=None):
+    """[sum Sig_inv | sum Sig_invMcoef | sum coef]: the rank's all-reduce message (dlsa.py:30-34)."""
+    lib = _lib.load()
+    _require_gpu(coef, smc, sig)
+    K, p = coef.shape
+    out = torch.empty((p * p + 2 * p,), dtype=torch.float64, device=coef.device)
+    cmask = (ctypes.c_int * K)(*[int(v) for v in mask]) if mask is not None else None
+    check(lib.dlsa_sum_blocks_f64(_ptr(coef.contiguous()), _ptr(sig.contiguous()), _ptr(smc.contiguous()),
+                                  K, p, cmask, _ptr(out), _stream()))
+    return out
+
+
+def spd_solve(S, v):
+    """theta = S^{-1} v by device Cholesky (the WLS combine, dlsa/dlsa.py:48-49)."""
+    lib = _lib.load()
+    _require_gpu(S, v)
+    p = S.shape[0]
+    theta = torch.empty((p,), dtype=torch.float64, device=S.device)
+    nb = lib.dlsa_solve_workspace_bytes(p)
+    ws = _workspace(nb, S.device)
+    check(lib.dlsa_spd_solve_f64(_ptr(S), S.stride(0), _ptr(v.contiguous()), p, _ptr(theta),
+                                 _ptr(ws), ws.numel(), _stream()))
+    return theta
+
+
+def lars_path(Sigma0, b0, intercept, n, type="lar", eps=2.220446049250313e-16, max_steps=None):
+    """LARS / lasso path of the LSA objective on the device (dlsa/lsa.py:90-212).
+    Returns dict of device tensors AIC, BIC [steps+1], beta [steps+1, m], beta0 [steps+1]."""
+    lib = _lib.load()
+    _require_gpu(Sigma0, b0)
+    p = Sigma0.shape[0]
+    m = p - (1 if intercept else 0)
+    ms = 8 * m if max_steps is None else int(max_steps)
+    dev = Sigma0.device
+    beta = torch.zeros((ms + 1, m), dtype=torch.float64, device=dev)
+    beta0 = torch.zeros((ms + 1,), dtype=torch.float64, device=dev)
+    aic = torch.zeros((ms + 1,), dtype=torch.float64, device=dev)
+    bic = torch.zeros((ms + 1,), dtype=torch.float64, device=dev)
+    nb = lib.dlsa_lars_workspace_bytes(p)
+    ws = _workspace(nb, dev)
+    steps = ctypes.c_int(0)
+    check(lib.dlsa_lars_lsa_f64(_ptr(Sigma0), Sigma0.stride(0), _ptr(b0.contiguous()), p, 1 if intercept else 0,
+                                float(n), {"lar": 0, "lasso": 1}[type], float(eps), ms,
+                                _ptr(beta), _ptr(beta0), _ptr(aic), _ptr(bic), ctypes.byref(steps),
+                                _ptr(ws), ws.numel(), _stream()))
+    k = steps.value
+    return {"AIC": aic[: k + 1], "BIC": bic[: k + 1], "beta": beta[: k + 1], "beta0": beta0[: k + 1]}

@@ -1,0 +1,137 @@
+/*
+ * dlsa_hip.h -- C ABI of libdlsa_hip.so: the MI355X (gfx950) engine for the DLSA hot path.
+ *
+ * The reference (feng-li/dlsa) is pure Python on Spark and has no FFI: the entry points
+ * below are what a binding for its per-partition map step, one-round reduce and LARS
+ * shrinkage would call.  Each entry cites the reference interface it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer named X, y, w, beta, H, ... is a DEVICE pointer unless marked host;
+ *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS;
+ *   - the caller owns all memory; the library never allocates what it returns.  Scratch
+ *     comes from a caller-provided device workspace (`ws`, `ws_bytes`), sized by the
+ *     matching *_workspace_bytes() query; the workspace must be 256-byte aligned;
+ *   - all device work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  Functions that return host scalars synchronise that stream;
+ *   - return value: 0 = DLSA_OK, otherwise a dlsa_status; dlsa_last_error() has the text.
+ */
+#ifndef DLSA_HIP_H
+#define DLSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DLSA_OK = 0,
+    DLSA_ERR_INVALID = 1,       /* bad argument (null pointer, p<=0, ld<p, ...)             */
+    DLSA_ERR_HIP = 2,           /* a HIP runtime call failed                                */
+    DLSA_ERR_WORKSPACE = 3,     /* workspace too small / misaligned                         */
+    DLSA_ERR_NOT_SPD = 4,       /* Cholesky met a non-positive pivot                        */
+    DLSA_ERR_NOT_CONVERGED = 5, /* IRLS hit max_iter (results are still written)            */
+    DLSA_ERR_NAN = 6,           /* NaN/Inf in a result (reference: warnings.warn, models.py:144) */
+    DLSA_ERR_NO_DEVICE = 7
+} dlsa_status;
+
+/* per-partition status written by dlsa_irls_fit_f64 (reference soft-fail conventions,
+ * models.py:84-91 zero block, :144-145 NaN warning) */
+typedef enum {
+    DLSA_PART_OK = 0,
+    DLSA_PART_NOT_CONVERGED = 1,
+    DLSA_PART_NOT_SPD = 2,
+    DLSA_PART_NAN = 3,
+    DLSA_PART_EMPTY = 4
+} dlsa_part_status;
+
+int dlsa_version(void);
+/* copies the last error message of the calling thread into buf (NUL-terminated) */
+int dlsa_last_error(char* buf, int len);
+
+/* ---- synthetic rows (replaces simulate_logistic, dlsa/models.py:6-40) -----------------
+ * Row i is a pure function of (seed, i) (Philox-4x32-10), so any sharding sees the same
+ * rows.  kind 0: x ~ U(-0.5,0.5) (models.py:22); kind 1: x ~ N(0,1/12).
+ * y (nullable) ~ Bernoulli(sigmoid(x . beta_true)); beta_true nullable = first int(0.4p)
+ * coefficients 1, rest 0 (models.py:12,18-19).  If ones_col != 0, column 0 of X is set to
+ * 1.0 (the intercept column of models.py:121-122) and features start at column 1. */
+int dlsa_synth_f64(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col,
+                   double* X, int64_t ldx, double* y, const double* beta_true, void* stream);
+int dlsa_synth_f32(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col,
+                   float* X, int64_t ldx, float* y, const float* beta_true, void* stream);
+
+/* ---- K3: weighted tall-skinny Gram  H = X' diag(w) X  (dlsa/models.py:130) ------------
+ * X: n x p, w: n (NULL = all ones, the linear-model X'X), H: p x p (ldh >= p), both
+ * triangles written (exactly symmetric).  accumulate != 0 adds into H.
+ * fp64 uses v_mfma_f64_16x16x4_f64; fp32 uses v_mfma_f32_16x16x4_f32. */
+size_t dlsa_gram_workspace_bytes(int64_t n, int p, int elem_bytes);
+int dlsa_gram_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p,
+                  double* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int dlsa_gram_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
+                  float* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K1/K2: fused logit pass over the rows (dlsa/models.py:113-114 inner products) ----
+ * eta = X beta, mu = sigmoid(eta); writes w_out[i] = mu(1-mu) (nullable), g = X'(y-mu)
+ * (p values, nullable) and loglik = sum y log mu + (1-y) log(1-mu) (1 value, nullable).
+ * One read of X. */
+size_t dlsa_logit_workspace_bytes(int64_t n, int p);
+int dlsa_logit_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta,
+                        int64_t n, int p, double* w_out, double* g, double* loglik,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- N1: log-likelihood of c estimator columns (dlsa/models.py:217-222) ---------------
+ * par: p x c row-major (ldpar >= c), c <= 8; out: c values. */
+int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p,
+                    const double* par, int64_t ldpar, int c, double* out,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a2-a6: per-partition exact-MLE fit + local quadratic approximation ---------------
+ * Replaces logistic_model's numeric core (dlsa/models.py:110-131) for K partitions stored
+ * contiguously: partition k = rows [part_offsets[k], part_offsets[k+1]) of X (host array of
+ * K+1 int64).  Newton/IRLS from beta=0 until |delta|_inf <= tol*max(1,|beta|_inf).
+ * Outputs (device): coef K x p, Sig_inv K x p x p (evaluated at coef, models.py:130),
+ * Sig_invMcoef K x p (models.py:131).  Host outputs (nullable): n_iter[K], status[K]
+ * (dlsa_part_status), loglik[K].  If X is to carry an intercept, the caller materialises the
+ * leading ones column (models.py:121-122) -- see dlsa_synth_f64(ones_col). */
+size_t dlsa_irls_workspace_bytes(int64_t max_rows_per_partition, int p);
+int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y,
+                      const int64_t* part_offsets_host, int K, int p,
+                      double tol, int max_iter,
+                      double* coef, double* Sig_inv, double* Sig_invMcoef,
+                      int* n_iter_host, int* status_host, double* loglik_host,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a9: local sum of partition blocks before the one-round all-reduce (dlsa.py:30-34) -
+ * out = [ sum_k Sig_inv (p*p) | sum_k Sig_invMcoef (p) | sum_k coef (p) ] contiguous,
+ * the message a rank contributes to the RCCL all-reduce.  Blocks whose status is not OK may
+ * be skipped via mask_host (nullable, K ints, 0 = include). */
+int dlsa_sum_blocks_f64(const double* coef, const double* Sig_inv, const double* Sig_invMcoef,
+                        int K, int p, const int* mask_host, double* out, void* stream);
+
+/* ---- a10: WLS combine  theta = Sig_inv^{-1} v  (dlsa/dlsa.py:48-49, lstsq on an SPD
+ * system) by Cholesky on the device.  S p x p (lds >= p) is not modified. */
+size_t dlsa_solve_workspace_bytes(int p);
+int dlsa_spd_solve_f64(const double* S, int64_t lds, const double* v, int p, double* theta,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a13/a14: LARS path for the least-squares approximation (dlsa/lsa.py:90-212) ------
+ * Sigma0 p x p, b0 p (device).  type 0 = 'lar', 1 = 'lasso'.  max_steps <= 0 -> 8*m.
+ * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
+ * aic, bic (max_steps+1 each); n_steps_host = number of steps taken (path has n_steps+1
+ * rows).  Runs as one persistent workgroup on the device. */
+size_t dlsa_lars_workspace_bytes(int p);
+int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p,
+                      int intercept, double n, int type, double eps, int max_steps,
+                      double* beta_path, double* beta0, double* aic, double* bic,
+                      int* n_steps_host, void* ws, size_t ws_bytes, void* stream);
+
+/* test hook: host-only validation of the Gram tile plan for p (0 = every upper-triangular
+ * 16x16 tile is assigned exactly once).  Not part of the drop-in surface. */
+int dlsa_gram_plan_check(int p, int* nitems, int* nt_max, int* ntiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLSA_HIP_H */

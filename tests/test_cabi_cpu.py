@@ -1,0 +1,63 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every symbol the
+header declares, validates arguments, and its Gram tile plan covers every tile exactly once."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from dlsa_amd import _lib
+    return _lib.load()
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    from dlsa_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dlsa_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dlsa_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_version_and_error_text(lib):
+    assert lib.dlsa_version() >= 100
+    # argument validation happens before any HIP call, so it works without a GPU
+    rc = lib.dlsa_gram_f64(None, 4, None, 10, 4, None, 4, 0, None, 0, None)
+    assert rc == 1
+    from dlsa_amd import _lib
+    assert "null" in _lib.last_error()
+    assert lib.dlsa_gram_workspace_bytes(1000, 0, 8) == 0
+    assert lib.dlsa_gram_workspace_bytes(25_000_000, 500, 8) > 0
+    assert lib.dlsa_irls_workspace_bytes(1000, 50) > lib.dlsa_gram_workspace_bytes(1000, 50, 8)
+
+
+@pytest.mark.parametrize("p", [1, 15, 16, 17, 50, 100, 127, 128, 129, 250, 256, 257, 300, 384, 385, 500,
+                               512, 513, 640, 1000, 1024, 2000, 2048])
+def test_gram_tile_plan_covers_upper_triangle_once(lib, p):
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_plan_check(p, a, b, c) == 0
+    nt = (p + 15) // 16
+    assert c.value == nt * (nt + 1) // 2
+    assert 1 <= b.value <= 11
+
+
+def test_metric_config_plan_is_perfectly_balanced(lib):
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_plan_check(500, a, b, c) == 0
+    assert (a.value, b.value, c.value) == (6, 11, 528)     # 6 panel pairs x 8 waves x 11 tiles
+
+
+def test_engine_refuses_cpu_tensors():
+    import torch
+    from dlsa_amd import engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.gram(torch.zeros(4, 2, dtype=torch.float64))

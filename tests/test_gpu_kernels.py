@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full per-GPU
+size -- through size-independent properties.  Run with `pytest -m gpu` on an MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL_KERNEL = 1e-12   # fp64 kernels vs numpy/BLAS on identical inputs (summation order only)
+TOL_MLE = 1e-10      # north star: theta-hat within 1e-10 relative l_inf of the exact MLE
+
+
+def rel_inf(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dlsa_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------------------------------
+def test_synth_rows_bit_identical_to_oracle(eng, orc):
+    for (n, p, row0, ones) in [(257, 9, 0, False), (1000, 50, 12345678901, False), (64, 7, 5, True)]:
+        X, y = eng.synth(20260101, row0, n, p, kind=eng.SYNTH_UNIFORM, ones_col=ones)
+        Xo, yo = orc.synth_logistic(20260101, row0, n, p, orc.SYNTH_UNIFORM)
+        Xg = X.cpu().numpy()
+        if ones:
+            assert np.all(Xg[:, 0] == 1.0)
+            Xg = Xg[:, 1:]
+        assert np.array_equal(Xg, Xo)                       # integer pipeline: bit exact
+        # labels go through exp(): allow a label flip only where u is within 1e-12 of prob
+        assert np.mean(y.cpu().numpy() != yo) < 1e-3
+    G, _ = eng.synth(7, 0, 200000, 6, kind=eng.SYNTH_GAUSSIAN, labels=False)
+    g = G.cpu().numpy()
+    assert abs(g.std() - (1 / 12) ** 0.5) < 2e-3 and abs(g.mean()) < 2e-3
+
+
+GRAM_CASES = [(1, 1), (15, 3), (1000, 5), (777, 17), (5000, 50), (4099, 100), (3000, 129),
+              (2048, 250), (3001, 500), (1500, 513), (40000, 64), (700, 1000)]
+
+
+@pytest.mark.parametrize("n,p", GRAM_CASES)
+@pytest.mark.parametrize("weighted", [True, False])
+def test_gram_matches_oracle(eng, orc, n, p, weighted):
+    rng = np.random.default_rng(n * 1000 + p)
+    X = rng.random((n, p)) - 0.5            # asymmetric operands: catches transposed C writes
+    w = rng.random(n) * 0.25 if weighted else None
+    H = eng.gram(dev(X), dev(w) if weighted else None).cpu().numpy()
+    Ho = orc.gram(X, w)
+    assert rel_inf(H, Ho) < TOL_KERNEL
+    assert np.array_equal(H, H.T)           # both triangles written, exactly symmetric
+
+
+def test_gram_strided_rows_and_accumulate(eng, orc):
+    rng = np.random.default_rng(3)
+    n, p, ld = 999, 37, 41                  # odd leading dimension -> unaligned (scalar-load) path
+    buf = rng.random((n, ld)) - 0.5
+    Xd = dev(buf)[:, :p]
+    w = rng.random(n)
+    H0 = rng.random((p, p))
+    H = dev(H0.copy())
+    eng.gram(Xd, dev(w), out=H, accumulate=True)
+    assert rel_inf(H.cpu().numpy(), H0 + orc.gram(buf[:, :p], w)) < 1e-11
+
+
+def test_gram_identity_operand_layout(eng):
+    """A = I check with asymmetric B (guide section 3): X = [I_p ; B] rows -> X'X = I + B'B."""
+    p = 48
+    B = np.arange(p * p, dtype=np.float64).reshape(p, p) / (p * p)
+    X = np.vstack([np.eye(p), B])
+    H = eng.gram(dev(X)).cpu().numpy()
+    assert rel_inf(H, np.eye(p) + B.T @ B) < 1e-13
+
+
+def test_gram_f32(eng):
+    rng = np.random.default_rng(9)
+    for (n, p) in [(3000, 100), (2000, 500), (500, 1030)]:
+        X = (rng.random((n, p)) - 0.5).astype(np.float32)
+        w = (rng.random(n) * 0.25).astype(np.float32)
+        H = eng.gram(dev(X), dev(w)).cpu().numpy()
+        Ho = X.astype(np.float64).T @ (w.astype(np.float64)[:, None] * X.astype(np.float64))
+        assert rel_inf(H, Ho) < 2e-5          # fp32 accumulate over n rows
+
+
+LOGIT_CASES = [(1, 1), (13, 3), (1000, 5), (4099, 100), (5000, 128), (3000, 129), (2048, 250),
+               (3001, 500), (1500, 513), (700, 1000), (300, 2000)]
+
+
+@pytest.mark.parametrize("n,p", LOGIT_CASES)
+def test_logit_pass_matches_oracle(eng, orc, n, p):
+    rng = np.random.default_rng(n + 7 * p)
+    X = rng.random((n, p)) - 0.5
+    beta = rng.standard_normal(p) * (3.0 / np.sqrt(p))
+    y = (rng.random(n) < 0.5).astype(np.float64)
+    w, g, ll = eng.logit_pass(dev(X), dev(y), dev(beta))
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    assert rel_inf(w.cpu().numpy(), wo) < TOL_KERNEL
+    assert rel_inf(g.cpu().numpy(), go) < 1e-11
+    assert abs(ll.item() - llo) < 1e-12 * abs(llo)
+
+
+def test_logit_pass_extreme_eta(eng, orc):
+    X = np.array([[800.0, 0.0], [-800.0, 0.0], [0.0, 0.0], [30.0, 1.0]])
+    y = np.array([1.0, 0.0, 1.0, 0.0])
+    beta = np.array([1.0, 1.0])
+    w, g, ll = eng.logit_pass(dev(X), dev(y), dev(beta))
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    assert np.all(np.isfinite(w.cpu().numpy())) and np.isfinite(ll.item())
+    assert np.allclose(w.cpu().numpy(), wo, rtol=1e-12, atol=1e-300)
+    assert abs(ll.item() - llo) < 1e-12 * abs(llo)
+
+
+def test_spd_solve(eng):
+    rng = np.random.default_rng(1)
+    for p in (1, 7, 64, 65, 200, 500):
+        A = rng.standard_normal((p + 5, p))
+        S = A.T @ A + 0.1 * np.eye(p)
+        v = rng.standard_normal(p)
+        th = eng.spd_solve(dev(S), dev(v)).cpu().numpy()
+        assert rel_inf(th, np.linalg.solve(S, v)) < 1e-9
+    from dlsa_amd._lib import DlsaError
+    with pytest.raises(DlsaError):
+        eng.spd_solve(dev(np.array([[1.0, 2.0], [2.0, 1.0]])), dev(np.array([1.0, 1.0])))
+
+
+# ---------------------------------------------------------------------------------------
+F1 = sorted(os.path.basename(f)[3:-8] for f in glob.glob(os.path.join(GOLDEN, "F1_*_mle.npz")))
+
+
+def _inputs(orc, z, name):
+    if name.startswith("synth"):
+        return orc.synth_logistic(int(z["seed"]), 0, int(z["n"]), int(z["p"]), orc.SYNTH_UNIFORM)
+    g = np.load(os.path.join(GOLDEN, "games_expand_input.npz"))
+    return g["X"].astype(np.float64), g["y"].astype(np.float64)
+
+
+@pytest.mark.parametrize("name", F1)
+def test_irls_fit_matches_reference_golden(eng, orc, name):
+    """HIP map step vs the reference's own logistic_model output (tol=1e-15 tier)."""
+    z = np.load(os.path.join(GOLDEN, "F1_%s_mle.npz" % name))
+    X, y = _inputs(orc, z, name)
+    K, icpt = int(z["K"]), bool(z["fit_intercept"])
+    parts = orc.partition_rows(X.shape[0], K)
+    order = np.concatenate(parts)
+    Xp = X[order]
+    if icpt:
+        Xp = np.column_stack([np.ones(Xp.shape[0]), Xp])
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in parts])])
+    r = eng.irls_fit(dev(Xp), dev(y[order]), offs)
+    assert r["status"] == [0] * K
+    assert rel_inf(r["coef"].cpu().numpy(), z["coef"]) < TOL_MLE
+    assert rel_inf(r["Sig_inv"].cpu().numpy(), z["Sig_inv"]) < TOL_MLE
+    assert rel_inf(r["Sig_invMcoef"].cpu().numpy(), z["Sig_invMcoef"]) < TOL_MLE
+    msg = eng.sum_blocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"])
+    p = Xp.shape[1]
+    S = msg[: p * p].view(p, p)
+    theta = eng.spd_solve(S, msg[p * p: p * p + p]).cpu().numpy()
+    assert rel_inf(S.cpu().numpy(), z["Sig_inv_sum"]) < TOL_MLE
+    assert rel_inf(theta, z["beta_byOLS"]) < TOL_MLE
+    assert rel_inf((msg[p * p + p:] / K).cpu().numpy(), z["beta_byONESHOT"]) < TOL_MLE
+
+
+def test_irls_fit_matches_oracle_p500(eng, orc):
+    """The metric's column count with ragged partitions and an empty one."""
+    n, p = 24000, 500
+    X, y = orc.synth_logistic(20260101, 0, n, p, orc.SYNTH_UNIFORM)
+    offs = [0, 9000, 9000, 16001, n]
+    r = eng.irls_fit(dev(X), dev(y), offs)
+    assert r["status"] == [0, 4, 0, 0]
+    assert float(r["Sig_inv"][1].abs().max()) == 0.0 and float(r["coef"][1].abs().max()) == 0.0
+    for k in (0, 2, 3):
+        c, smc, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]], y[offs[k]:offs[k + 1]])
+        assert rel_inf(r["coef"][k].cpu().numpy(), c) < TOL_MLE
+        assert rel_inf(r["Sig_inv"][k].cpu().numpy(), sig) < TOL_MLE
+        assert rel_inf(r["Sig_invMcoef"][k].cpu().numpy(), smc) < TOL_MLE
+
+
+def test_irls_separable_data_reports_not_converged_or_spd(eng):
+    X = np.array([[-2.0], [-1.0], [1.0], [2.0]] * 8)
+    y = (X[:, 0] > 0).astype(np.float64)
+    r = eng.irls_fit(dev(X), dev(y), [0, X.shape[0]], max_iter=25)
+    assert r["status"][0] in (1, 2, 3)      # perfectly separable: no finite MLE, must not claim OK
+
+
+F3 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "F3_*.npz")))
+
+
+@pytest.mark.parametrize("name", F3)
+def test_lars_path_matches_reference_golden(eng, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    typ = "lasso" if name.endswith("lasso") else "lar"
+    r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), False, float(z["n"]), type=typ)
+    beta = r["beta"].cpu().numpy()
+    assert beta.shape == z["beta"].shape
+    assert rel_inf(beta, z["beta"]) < 1e-8
+    assert rel_inf(r["AIC"].cpu().numpy(), z["AIC"]) < 1e-8
+    assert rel_inf(r["BIC"].cpu().numpy(), z["BIC"]) < 1e-8
+    assert float(r["beta0"].abs().max()) == 0.0
+
+
+def test_lars_intercept_matches_oracle(eng, orc):
+    rng = np.random.default_rng(5)
+    p, n = 30, 2000
+    X = np.column_stack([np.ones(n), rng.random((n, p - 1)) - 0.5])
+    S = X.T @ (rng.random(n)[:, None] * 0.25 * X)
+    b = orc.true_beta(p) + 0.05 * rng.standard_normal(p)
+    ro = orc.lars_lsa(S, b, True, n)
+    r = eng.lars_path(dev(S), dev(b), True, n)
+    assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-8
+    assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-8
+    assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-8
+
+
+def test_loglik_columns(eng, orc):
+    rng = np.random.default_rng(8)
+    n, p = 5000, 60
+    X, y = orc.synth_logistic(3, 0, n, p)
+    par = rng.standard_normal((p, 4)) * 0.3
+    out = eng.loglik(dev(X), dev(y), dev(par)).cpu().numpy()
+    assert rel_inf(out, orc.logistic_loglik(X, y, par)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------
+def test_full_size_properties_p500(eng):
+    """BASELINE config 3's per-GPU shard (2.5e7 x 500 fp64 = 100 GB): size-independent checks.
+    linearity over row blocks, exact symmetry, and trace(H) = sum_i w_i |x_i|^2 computed by an
+    independent (torch elementwise) path in chunks."""
+    free, _ = torch.cuda.mem_get_info()
+    n, p = 25_000_000, 500
+    if free < 130e9:
+        n = int(free * 0.6 / (p * 8))
+    X, _ = eng.synth(20260101, 0, n, p, kind=eng.SYNTH_GAUSSIAN, labels=False)
+    w = torch.rand(n, dtype=torch.float64, device="cuda") * 0.25
+    H = eng.gram(X, w)
+    assert torch.equal(H, H.T)
+    half = (n // 2 // 7) * 7 + 3
+    H1 = eng.gram(X[:half], w[:half])
+    H2 = eng.gram(X[half:], w[half:])
+    scale = float(H.abs().max())
+    assert float((H1 + H2 - H).abs().max()) < 1e-11 * scale
+    tr = 0.0
+    diag = torch.zeros(p, dtype=torch.float64, device="cuda")
+    step = 1_000_000
+    for r in range(0, n, step):
+        xs = X[r:r + step]
+        diag += (xs * xs * w[r:r + step, None]).sum(0)
+    assert float((diag - torch.diagonal(H)).abs().max()) < 1e-11 * scale
+    # one off-diagonal band through an independent path
+    col = torch.zeros(p, dtype=torch.float64, device="cuda")
+    for r in range(0, n, step):
+        xs = X[r:r + step]
+        col += (xs * (xs[:, 3] * w[r:r + step])[:, None]).sum(0)
+    assert float((col - H[3]).abs().max()) < 1e-11 * scale
