@@ -58,6 +58,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: the HIP extension has not been built (run `make`). "
                           "dlsa_amd has no CPU fallback." % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one libdlsa_hip.so binds to, so that device
+    # pointers and streams are shared (loading the system libamdhip64 first gives two runtimes).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch

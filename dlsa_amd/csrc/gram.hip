@@ -3,20 +3,26 @@
 //
 // Shape of the problem: M = N = p (<= a few thousand), K = n rows (10^7..10^8).  It is a
 // split-K GEMM whose output is tiny and symmetric, so
-//   * only upper-triangular 16x16 tiles of H are computed, the reduce kernel mirrors them;
-//   * the p columns are cut into 128-column PANELS; a work ITEM owns a pair of panels and a
-//     balanced list of output tiles whose operands live in those two panels;
-//   * a workgroup (8 waves, one per CU) = one item x one SLAB of rows.  It streams the slab
-//     through LDS in 32-row chunks (double buffered), every wave keeps its tiles in VGPRs for
-//     the whole slab and finally writes them to a per-slab partial buffer;
-//   * blocks that share a slab are dispatched to the same XCD back to back so that the slab's
-//     panels are fetched from HBM once and re-read from that XCD's L2;
+//   * only tiles on or above the diagonal of H are stored, the reduce kernel mirrors them;
+//   * the p columns are cut into 128-column PANELS (8 tiles of 16).  A WAVE owns a 4x4 block of
+//     16x16 output tiles (64x64 of H, 128 accumulator VGPRs in fp64): per 4-row k-step it reads
+//     4 A fragments + 4 B fragments from LDS and issues 16 MFMAs -- the register blocking is
+//     what lets v_mfma_f64_16x16x4_f64 run at its 64-cycle issue rate (measured: 70 TF with
+//     4x4 blocking from LDS vs 56 TF with one fragment pair per MFMA; bench/ubench_gram_inner.hip);
+//   * a WORKGROUP is 4 such waves whose blocks need at most two panels (an off-diagonal panel
+//     pair = 4 blocks; the three blocks of a diagonal panel ride together with a neighbour's),
+//     x one SLAB of rows.  It streams the slab's two panels through LDS in 16-row chunks
+//     (double buffered, 74 KB -> two workgroups per CU so one's staging hides under the other's
+//     MFMAs) and finally writes its tiles to a per-slab partial buffer;
+//   * workgroups that share a slab are dispatched to the same XCD back to back, so the slab's
+//     panels come from HBM once and are re-read from that XCD's L2;
 //   * a second kernel sums the slab partials in a fixed order (deterministic) into H.
 //
 // MFMA operand layout (v_mfma_f64_16x16x4_f64): A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
-// C/D reg r of lane l = C[4r + (l>>4)][l&15].  With A[i][k] = X[r0+k][ca+i] and
-// B[k][j] = w[r0+k] X[r0+k][cb+j] both fragments are the SAME LDS read pattern
-// "lane l <- chunk[(4ks + l>>4)][16t + (l&15)]", conflict-free at a row pitch of 144.
+// C/D reg r of lane l = C[4r + (l>>4)][l&15]  (the fp64 C/D map differs from every other dtype).
+// With A[i][k] = X[r0+k][ca+i] and B[k][j] = w[r0+k] X[r0+k][cb+j] both fragments are the SAME
+// LDS read pattern "lane l <- chunk[4ks + (l>>4)][16t + (l&15)]", bank-conflict-free at a row
+// pitch of 144 elements.  fp32 uses v_mfma_f32_16x16x4_f32 with the same fragments.
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -27,16 +33,21 @@ namespace dlsa {
 
 constexpr int TILE = 16;
 constexpr int PANEL = 128;        // columns per panel = 8 tiles
-constexpr int KC = 32;            // rows per staged chunk = 8 MFMA k-steps
+constexpr int KC = 16;            // rows per staged chunk = 4 MFMA k-steps
 constexpr int LDP = 144;          // LDS row pitch (elements): 144 mod 32 == 16 -> conflict-free frags
-constexpr int GRAM_WAVES = 8;
+constexpr int GRAM_WAVES = 4;
 constexpr int GRAM_THREADS = 64 * GRAM_WAVES;
-constexpr int NT_CAP = 11;        // max tiles per wave (11*8 = 88 accumulator VGPRs in fp64)
+constexpr int MR = 4, NR = 4;     // tiles per wave block
 
+struct WaveBlock {
+    unsigned char a[MR];          // sel<<3 | local tile index (0..7) of the A (row) tiles
+    unsigned char b[NR];          // same for the B (column) tiles
+    unsigned short mask;          // bit i*NR+j: tile (a[i], b[j]) is stored (on/above the diagonal, inside p)
+    unsigned short pad;
+};
 struct GramItem {
     int panA, panB;               // panel indices (panB == panA: single-panel item)
-    int nt[GRAM_WAVES];           // tiles per wave
-    unsigned short tile[GRAM_WAVES][NT_CAP];  // selA<<7 | tiA<<4 | selB<<3 | tjB   (ti,tj local 0..7)
+    WaveBlock wb[GRAM_WAVES];
 };
 
 template <typename T>
@@ -61,7 +72,6 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
-    // C/D register r of lane l is row 4r + (l>>4)   (f64 layout differs from every other dtype)
     static __device__ __forceinline__ int crow(int lane, int r) { return 4 * r + (lane >> 4); }
 };
 template <> struct Mfma<float> {
@@ -98,11 +108,11 @@ __device__ __forceinline__ typename Vec2<T>::type load_pair(const T* __restrict_
     return v;
 }
 
-template <typename T, int NT, bool HASW, bool VEC>
+template <typename T, bool HASW, bool VEC>
 __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Vec2<T>::type vec2_t;
-    constexpr int PASSES = KC / GRAM_WAVES;                     // staging passes per panel
+    constexpr int PASSES = KC / GRAM_WAVES;              // staging passes per panel
     constexpr int PANEL_ELEMS = KC * LDP;
     constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + KC;      // two panels + the w chunk
     __shared__ __attribute__((aligned(16))) T lds[2 * BUF_ELEMS];
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // block -> (item, slab)
+    // workgroup -> (item, slab)
     int item_id, slab;
     {
         const int b = blockIdx.x;
@@ -127,25 +137,26 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
     const GramItem* __restrict__ it = a.items + item_id;
     const int panA = it->panA, panB = it->panB;
     const int npanels = (panA == panB) ? 1 : 2;
-    const int nt = it->nt[wave];
+    const WaveBlock wb = it->wb[wave];
+    const bool active = wb.mask != 0;                    // wave-uniform
 
-    // LDS element offsets of every tile's A and B fragment origin (wave-uniform)
-    int offA[NT], offB[NT];
+    // LDS element offsets of the block's A and B fragment origins (wave-uniform)
+    int offA[MR], offB[NR];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int code = (t < nt) ? it->tile[wave][t] : 0;
-        offA[t] = ((code >> 7) & 1) * PANEL_ELEMS + ((code >> 4) & 7) * TILE;
-        offB[t] = ((code >> 3) & 1) * PANEL_ELEMS + (code & 7) * TILE;
-    }
+    for (int i = 0; i < MR; ++i) offA[i] = ((wb.a[i] >> 3) & 1) * PANEL_ELEMS + (wb.a[i] & 7) * TILE;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) offB[j] = ((wb.b[j] >> 3) & 1) * PANEL_ELEMS + (wb.b[j] & 7) * TILE;
     const int lane_off = (lane >> 4) * LDP + (lane & 15);
 
     const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
     const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
     const int nchunks = rbeg < rend ? (int)((rend - rbeg + KC - 1) / KC) : 0;
 
-    acc_t acc[NT];
+    acc_t acc[MR][NR];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     vec2_t st[2][PASSES];
     T wreg = T(0);
@@ -189,37 +200,44 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
 
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) stage_load(c + 1);
-        const T* base = lds + (c & 1) * BUF_ELEMS;
+        if (active) {
+            const T* base = lds + (c & 1) * BUF_ELEMS;
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-            T wv = T(1);
-            if (HASW) wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
-            const T* kb = base + ks * 4 * LDP + lane_off;
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const T* kb = base + ks * 4 * LDP + lane_off;
+                T av[MR], bv[NR];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t < nt) {
-                    const T av = kb[offA[t]];
-                    T bv = kb[offB[t]];
-                    if (HASW) bv *= wv;
-                    acc[t] = Mfma<T>::run(av, bv, acc[t]);
+                for (int i = 0; i < MR; ++i) av[i] = kb[offA[i]];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) bv[j] = kb[offB[j]];
+                if (HASW) {
+                    const T wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) bv[j] *= wv;
                 }
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
             }
         }
         if (c + 1 < nchunks) stage_write((c + 1) & 1);
         __syncthreads();
     }
 
-    // epilogue: accumulator tiles -> this slab's partial buffer
+    // epilogue: stored tiles -> this slab's partial buffer
     T* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
-            const int code = it->tile[wave][t];
-            const int r0 = ((((code >> 7) & 1) ? panB : panA) * 8 + ((code >> 4) & 7)) * TILE;
-            const int c0 = ((((code >> 3) & 1) ? panB : panA) * 8 + (code & 7)) * TILE;
+    for (int i = 0; i < MR; ++i) {
+        const int r0 = ((((wb.a[i] >> 3) & 1) ? panB : panA) * 8 + (wb.a[i] & 7)) * TILE;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = acc[t][r];
+        for (int j = 0; j < NR; ++j) {
+            if ((wb.mask >> (i * NR + j)) & 1) {
+                const int c0 = ((((wb.b[j] >> 3) & 1) ? panB : panA) * 8 + (wb.b[j] & 7)) * TILE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = acc[i][j][r];
+            }
         }
     }
 }
@@ -233,96 +251,104 @@ __global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int
     if (j >= p) return;
     const int r = min(i, j), c = max(i, j);
     const T* src = partial + (int64_t)r * PP + c;
-    T s = T(0);
+    T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
     const int64_t stride = (int64_t)PP * PP;
-    for (int k = 0; k < nslab; ++k) s += src[k * stride];
+    int k = 0;
+    for (; k + 3 < nslab; k += 4) {      // 4 independent chains, combined in a fixed order
+        s0 += src[(k + 0) * stride];
+        s1 += src[(k + 1) * stride];
+        s2 += src[(k + 2) * stride];
+        s3 += src[(k + 3) * stride];
+    }
+    for (; k < nslab; ++k) s0 += src[k * stride];
+    const T s = (s0 + s1) + (s2 + s3);
     T* dst = H + (int64_t)i * ldh + j;
     *dst = accumulate ? (*dst + s) : s;
 }
 
 // ---------------------------------------------------------------------------------------
-// Host side: tile -> item -> wave assignment, cached per p on the device.
+// Host side: wave blocks -> workgroup items, cached per p on the device.
 // ---------------------------------------------------------------------------------------
 struct GramPlan {
-    int p = 0, ntile = 0, npan = 0, PP = 0, nitems = 0, nt_max = 0;
+    int p = 0, ntile = 0, npan = 0, PP = 0, nitems = 0;
     GramItem* d_items = nullptr;
 };
 
-static bool try_build_items(int p, int sub, std::vector<GramItem>& items, int& nt_max) {
+// A wave block in global tile coordinates: tile rows ra[0..3], tile cols cb[0..3] (-1 = unused)
+struct HostBlock {
+    int ra[MR], cb[NR];
+    int pr, pc;      // panel of the rows / of the columns
+};
+
+static void build_items(int p, std::vector<GramItem>& items) {
     const int ntile = (p + TILE - 1) / TILE;
-    const int npan = (p + PANEL - 1) / PANEL;
-    struct Tile { int ti, tj; };
-    std::vector<std::pair<int, int>> pairs;
-    if (npan == 1) pairs.push_back({0, 0});
-    else for (int x = 0; x < npan; ++x) for (int y = x + 1; y < npan; ++y) pairs.push_back({x, y});
-    std::vector<std::vector<Tile>> lists;
-    std::vector<std::pair<int, int>> item_pair;
-    for (auto& pr : pairs) for (int s = 0; s < sub; ++s) { item_pair.push_back(pr); lists.emplace_back(); }
-    auto pan_of = [](int t) { return t / 8; };
-    auto pair_index = [&](int x, int y) {
-        for (size_t k = 0; k < pairs.size(); ++k) if (pairs[k].first == x && pairs[k].second == y) return (int)k;
-        return -1;
+    // all 4x4 tile blocks that contain at least one tile on/above the diagonal
+    std::vector<HostBlock> blocks;
+    const int nb4 = (ntile + 3) / 4;                     // blocks of 4 tiles per dimension
+    for (int bi = 0; bi < nb4; ++bi)
+        for (int bj = bi; bj < nb4; ++bj) {
+            HostBlock hb;
+            for (int i = 0; i < MR; ++i) hb.ra[i] = (bi * 4 + i < ntile) ? bi * 4 + i : -1;
+            for (int j = 0; j < NR; ++j) hb.cb[j] = (bj * 4 + j < ntile) ? bj * 4 + j : -1;
+            hb.pr = (bi * 4) / 8;
+            hb.pc = (bj * 4) / 8;
+            blocks.push_back(hb);
+        }
+    // pack blocks into workgroups of GRAM_WAVES blocks touching at most two panels:
+    // first the off-diagonal panel pairs (exactly 4 blocks when both panels are full), then the
+    // blocks that live inside one panel, greedily appended to a workgroup that already stages it.
+    struct Group { int pa, pb; std::vector<HostBlock> bl; };
+    std::vector<Group> groups;
+    auto find_or_new = [&](int pa, int pb) -> Group& {
+        for (auto& g : groups)
+            if ((int)g.bl.size() < GRAM_WAVES && g.pa == pa && g.pb == pb) return g;
+        groups.push_back(Group{pa, pb, {}});
+        return groups.back();
     };
-    // tiles whose operands sit in two different panels belong to that panel pair
-    std::vector<int> rr(pairs.size(), 0);
-    for (int ti = 0; ti < ntile; ++ti)
-        for (int tj = ti; tj < ntile; ++tj) {
-            if (pan_of(ti) == pan_of(tj)) continue;
-            const int k = pair_index(pan_of(ti), pan_of(tj));
-            lists[k * sub + (rr[k]++ % sub)].push_back({ti, tj});
+    for (auto& hb : blocks)
+        if (hb.pr != hb.pc) find_or_new(hb.pr, hb.pc).bl.push_back(hb);
+    for (auto& hb : blocks) {
+        if (hb.pr != hb.pc) continue;
+        Group* best = nullptr;
+        for (auto& g : groups) {
+            if ((int)g.bl.size() >= GRAM_WAVES) continue;
+            const bool has = (g.pa == hb.pr || g.pb == hb.pr);
+            const bool room = (g.pa == g.pb);            // single-panel group can adopt a second panel
+            if (has) { best = &g; break; }
+            if (room && !best) best = &g;
         }
-    // tiles inside one panel go to the least loaded item that stages that panel; the panels are
-    // visited round-robin (one tile each per turn) so that no item fills up early
-    {
-        std::vector<std::vector<Tile>> diag(npan);
-        for (int ti = 0; ti < ntile; ++ti)
-            for (int tj = ti; tj < ntile; ++tj)
-                if (pan_of(ti) == pan_of(tj)) diag[pan_of(ti)].push_back({ti, tj});
-        bool any = true;
-        for (size_t turn = 0; any; ++turn) {
-            any = false;
-            for (int pn = 0; pn < npan; ++pn) {
-                if (turn >= diag[pn].size()) continue;
-                any = true;
-                int best = -1;
-                for (size_t k = 0; k < lists.size(); ++k) {
-                    if (item_pair[k].first != pn && item_pair[k].second != pn) continue;
-                    if (best < 0 || lists[k].size() < lists[best].size()) best = (int)k;
-                }
-                lists[best].push_back(diag[pn][turn]);
-            }
-        }
+        if (!best) { groups.push_back(Group{hb.pr, hb.pr, {}}); best = &groups.back(); }
+        if (best->pa != hb.pr && best->pb != hb.pr) best->pb = hb.pr;   // adopt as second panel
+        best->bl.push_back(hb);
     }
     items.clear();
-    nt_max = 0;
-    for (size_t k = 0; k < lists.size(); ++k) {
-        if (lists[k].empty()) continue;
-        if ((int)lists[k].size() > NT_CAP * GRAM_WAVES) return false;
-        GramItem g{};
-        g.panA = item_pair[k].first;
-        g.panB = item_pair[k].second;
-        std::sort(lists[k].begin(), lists[k].end(), [](const Tile& x, const Tile& y) {
-            return x.ti != y.ti ? x.ti < y.ti : x.tj < y.tj; });
-        int wv = 0;
-        for (auto& t : lists[k]) {
-            const int selA = (pan_of(t.ti) == g.panA) ? 0 : 1;
-            const int selB = (pan_of(t.tj) == g.panA) ? 0 : 1;
-            const int n = g.nt[wv];
-            g.tile[wv][n] = (unsigned short)((selA << 7) | ((t.ti & 7) << 4) | (selB << 3) | (t.tj & 7));
-            g.nt[wv] = n + 1;
-            nt_max = std::max(nt_max, n + 1);
-            wv = (wv + 1) % GRAM_WAVES;
+    for (auto& g : groups) {
+        GramItem it{};
+        it.panA = std::min(g.pa, g.pb);
+        it.panB = std::max(g.pa, g.pb);
+        for (size_t wv = 0; wv < g.bl.size(); ++wv) {
+            const HostBlock& hb = g.bl[wv];
+            WaveBlock& w = it.wb[wv];
+            const int selr = (hb.pr == it.panA) ? 0 : 1, selc = (hb.pc == it.panA) ? 0 : 1;
+            int first_r = -1, first_c = -1;
+            for (int i = 0; i < MR; ++i) if (hb.ra[i] >= 0 && first_r < 0) first_r = hb.ra[i];
+            for (int j = 0; j < NR; ++j) if (hb.cb[j] >= 0 && first_c < 0) first_c = hb.cb[j];
+            unsigned short mask = 0;
+            for (int i = 0; i < MR; ++i) {
+                const int tr = hb.ra[i] >= 0 ? hb.ra[i] : first_r;      // unused slots alias a valid tile
+                w.a[i] = (unsigned char)((selr << 3) | (tr & 7));
+            }
+            for (int j = 0; j < NR; ++j) {
+                const int tc = hb.cb[j] >= 0 ? hb.cb[j] : first_c;
+                w.b[j] = (unsigned char)((selc << 3) | (tc & 7));
+            }
+            for (int i = 0; i < MR; ++i)
+                for (int j = 0; j < NR; ++j)
+                    if (hb.ra[i] >= 0 && hb.cb[j] >= 0 && hb.ra[i] <= hb.cb[j]) mask |= (unsigned short)(1u << (i * NR + j));
+            w.mask = mask;
         }
-        items.push_back(g);
+        items.push_back(it);
     }
-    return nt_max <= NT_CAP;
-}
-
-// Items: one or more per panel pair so that no wave holds more than NT_CAP tiles.
-// p = 500: 6 panel pairs x 88 tiles = 528 upper-triangular tiles, exactly 11 per wave.
-static void build_items(int p, std::vector<GramItem>& items, int& nt_max) {
-    for (int sub = 1; sub < 64; ++sub)
-        if (try_build_items(p, sub, items, nt_max)) return;
 }
 
 static std::mutex g_plan_mu;
@@ -341,8 +367,7 @@ static int get_plan(int p, GramPlan& out) {
     pl.npan = (p + PANEL - 1) / PANEL;
     pl.PP = pl.ntile * TILE;
     std::vector<GramItem> items;
-    build_items(p, items, pl.nt_max);
-    if (pl.nt_max > NT_CAP) { set_error("gram plan: %d tiles per wave exceeds %d", pl.nt_max, NT_CAP); return DLSA_ERR_INVALID; }
+    build_items(p, items);
     pl.nitems = (int)items.size();
     // the item table is a few KB of immutable metadata, created once per (device, p)
     DLSA_HIP_CHECK(hipMalloc((void**)&pl.d_items, items.size() * sizeof(GramItem)));
@@ -352,12 +377,12 @@ static int get_plan(int p, GramPlan& out) {
     return DLSA_OK;
 }
 
-static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_slab) {
-    // ~6 rounds of 256 resident workgroups for large n; at least 512 rows per slab
-    const int target_blocks = 6 * kNumCU;   // one 8-wave workgroup per CU, ~6 rounds
-    int64_t want = std::max<int64_t>(1, target_blocks / std::max(1, nitems));
-    int64_t by_rows = std::max<int64_t>(1, (n + 511) / 512);
-    int64_t ns = std::min(want, by_rows);
+static void choose_slabs(int64_t n, int& nslab, int64_t& rows_per_slab) {
+    // nslab = 512 makes nitems*nslab an exact multiple of the 512 resident workgroups (2 per CU),
+    // i.e. nitems full rounds with no tail; small inputs get >= 256 rows per slab.
+    int64_t ns = 2 * kNumCU;
+    const int64_t by_rows = std::max<int64_t>(1, (n + 255) / 256);
+    ns = std::min(ns, by_rows);
     if (ns >= kNumXCD) ns = ns / kNumXCD * kNumXCD;
     rows_per_slab = ((n + ns - 1) / ns + KC - 1) / KC * KC;
     if (rows_per_slab < KC) rows_per_slab = KC;
@@ -368,24 +393,10 @@ static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_sl
 
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
-    std::vector<GramItem> items;
-    int nt_max = 0;
-    build_items(p, items, nt_max);   // host-only, cheap; gives the exact item count
     int nslab; int64_t rps;
-    choose_slabs(n, (int)items.size(), nslab, rps);
+    choose_slabs(n, nslab, rps);
     const size_t PP = (size_t)ntile * TILE;
     return align_up((size_t)nslab * PP * PP * elem_bytes, 256);
-}
-
-template <typename T, int NT>
-static void launch_gram(const GramArgs<T>& a, bool hasw, bool vec, int blocks, hipStream_t s) {
-    if (hasw) {
-        if (vec) hipLaunchKernelGGL((gram_kernel<T, NT, true, true>), dim3(blocks), dim3(GRAM_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((gram_kernel<T, NT, true, false>), dim3(blocks), dim3(GRAM_THREADS), 0, s, a);
-    } else {
-        if (vec) hipLaunchKernelGGL((gram_kernel<T, NT, false, true>), dim3(blocks), dim3(GRAM_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((gram_kernel<T, NT, false, false>), dim3(blocks), dim3(GRAM_THREADS), 0, s, a);
-    }
 }
 
 template <typename T>
@@ -398,7 +409,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     int rc = get_plan(p, pl);
     if (rc) return rc;
     int nslab; int64_t rps;
-    choose_slabs(n, pl.nitems, nslab, rps);
+    choose_slabs(n, nslab, rps);
     const size_t need = (size_t)nslab * pl.PP * pl.PP * sizeof(T);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
@@ -410,8 +421,13 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
     const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
     const int blocks = pl.nitems * nslab;
-    if (pl.nt_max <= 6) launch_gram<T, 6>(a, w != nullptr, vec, blocks, stream);
-    else launch_gram<T, NT_CAP>(a, w != nullptr, vec, blocks, stream);
+    if (w) {
+        if (vec) hipLaunchKernelGGL((gram_kernel<T, true, true>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((gram_kernel<T, true, false>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((gram_kernel<T, false, true>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((gram_kernel<T, false, false>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+    }
     DLSA_HIP_CHECK(hipGetLastError());
     dim3 rg((p + 127) / 128, p);
     hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, (const T*)ws, nslab, pl.PP, p, H, ldh, accumulate);
@@ -429,29 +445,34 @@ int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
     return gram_impl<double>(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
 }
 
-// host-only self check of the tile plan: every upper-triangular tile exactly once, inside an
-// item that stages both of its panels.  Used by the CPU test-suite.
-int gram_plan_check(int p, int* nitems, int* nt_max_out, int* ntiles) {
+// host-only self check of the tile plan: every tile on/above the diagonal is stored exactly once,
+// by a wave whose workgroup stages both of its panels.  Used by the CPU test-suite.
+// Outputs: number of workgroup items, tile slots computed (incl. waste), tiles stored.
+int gram_plan_check(int p, int* nitems, int* nslots, int* ntiles) {
     std::vector<GramItem> items;
-    int nt_max = 0;
-    build_items(p, items, nt_max);
+    build_items(p, items);
     const int ntile = (p + TILE - 1) / TILE;
     std::vector<int> seen((size_t)ntile * ntile, 0);
-    int count = 0;
-    for (auto& g : items)
-        for (int wv = 0; wv < GRAM_WAVES; ++wv)
-            for (int t = 0; t < g.nt[wv]; ++t) {
-                const int code = g.tile[wv][t];
-                const int ti = (((code >> 7) & 1) ? g.panB : g.panA) * 8 + ((code >> 4) & 7);
-                const int tj = (((code >> 3) & 1) ? g.panB : g.panA) * 8 + (code & 7);
-                if (ti > tj || tj >= ntile) return -1;
-                if (seen[(size_t)ti * ntile + tj]++) return -2;
-                ++count;
-            }
+    int count = 0, slots = 0;
+    for (auto& g : items) {
+        if (g.panA > g.panB) return -5;
+        for (int wv = 0; wv < GRAM_WAVES; ++wv) {
+            const WaveBlock& w = g.wb[wv];
+            if (w.mask) slots += MR * NR;
+            for (int i = 0; i < MR; ++i)
+                for (int j = 0; j < NR; ++j) {
+                    if (!((w.mask >> (i * NR + j)) & 1)) continue;
+                    const int ti = (((w.a[i] >> 3) & 1) ? g.panB : g.panA) * 8 + (w.a[i] & 7);
+                    const int tj = (((w.b[j] >> 3) & 1) ? g.panB : g.panA) * 8 + (w.b[j] & 7);
+                    if (ti > tj || tj >= ntile) return -1;
+                    if (seen[(size_t)ti * ntile + tj]++) return -2;
+                    ++count;
+                }
+        }
+    }
     if (count != ntile * (ntile + 1) / 2) return -3;
-    if (nt_max > NT_CAP) return -4;
     if (nitems) *nitems = (int)items.size();
-    if (nt_max_out) *nt_max_out = nt_max;
+    if (nslots) *nslots = slots;
     if (ntiles) *ntiles = count;
     return 0;
 }
@@ -461,8 +482,8 @@ int gram_plan_check(int p, int* nitems, int* nt_max_out, int* ntiles) {
 extern "C" {
 
 // debugging/test hook (not part of the drop-in surface): validates the tile plan for p
-int dlsa_gram_plan_check(int p, int* nitems, int* nt_max, int* ntiles) {
-    return dlsa::gram_plan_check(p, nitems, nt_max, ntiles);
+int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles) {
+    return dlsa::gram_plan_check(p, nitems, nslots, ntiles);
 }
 
 size_t dlsa_gram_workspace_bytes(int64_t n, int p, int elem_bytes) {

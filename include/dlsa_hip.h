@@ -127,9 +127,9 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
                       double* beta_path, double* beta0, double* aic, double* bic,
                       int* n_steps_host, void* ws, size_t ws_bytes, void* stream);
 
-/* test hook: host-only validation of the Gram tile plan for p (0 = every upper-triangular
- * 16x16 tile is assigned exactly once).  Not part of the drop-in surface. */
-int dlsa_gram_plan_check(int p, int* nitems, int* nt_max, int* ntiles);
+/* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
+ * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */
+int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles);
 
 #ifdef __cplusplus
 }

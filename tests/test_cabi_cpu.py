@@ -40,20 +40,22 @@ def test_version_and_error_text(lib):
     assert lib.dlsa_irls_workspace_bytes(1000, 50) > lib.dlsa_gram_workspace_bytes(1000, 50, 8)
 
 
-@pytest.mark.parametrize("p", [1, 15, 16, 17, 50, 100, 127, 128, 129, 250, 256, 257, 300, 384, 385, 500,
-                               512, 513, 640, 1000, 1024, 2000, 2048])
+@pytest.mark.parametrize("p", [1, 15, 16, 17, 50, 64, 65, 100, 127, 128, 129, 250, 256, 257, 300, 384, 385,
+                               500, 512, 513, 640, 1000, 1024, 2000, 2048])
 def test_gram_tile_plan_covers_upper_triangle_once(lib, p):
-    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert lib.dlsa_gram_plan_check(p, a, b, c) == 0
+    items, slots, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_plan_check(p, items, slots, tiles) == 0
     nt = (p + 15) // 16
-    assert c.value == nt * (nt + 1) // 2
-    assert 1 <= b.value <= 11
+    assert tiles.value == nt * (nt + 1) // 2           # every tile on/above the diagonal, once
+    assert slots.value >= tiles.value and slots.value % 16 == 0
+    assert items.value * 4 * 16 >= slots.value         # 4 waves x (4x4 tiles) per workgroup
 
 
 def test_metric_config_plan_is_perfectly_balanced(lib):
-    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert lib.dlsa_gram_plan_check(500, a, b, c) == 0
-    assert (a.value, b.value, c.value) == (6, 11, 528)     # 6 panel pairs x 8 waves x 11 tiles
+    items, slots, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_plan_check(500, items, slots, tiles) == 0
+    # 6 off-diagonal panel pairs + 3 workgroups of diagonal blocks, every wave holds a full 4x4 block
+    assert (items.value, slots.value, tiles.value) == (9, 576, 528)
 
 
 def test_engine_refuses_cpu_tensors():
