@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <mutex>
 #include <map>
+#include <stdlib.h>
 
 namespace dlsa {
 
@@ -43,7 +44,7 @@ struct WaveBlock {
     unsigned char a[MR];          // sel<<3 | local tile index (0..7) of the A (row) tiles
     unsigned char b[NR];          // same for the B (column) tiles
     unsigned short mask;          // bit i*NR+j: tile (a[i], b[j]) is stored (on/above the diagonal, inside p)
-    unsigned short pad;
+    unsigned short tri;           // 1: diagonal block (a == b): only tiles j >= i are computed
 };
 struct GramItem {
     int panA, panB;               // panel indices (panB == panA: single-panel item)
@@ -64,6 +65,7 @@ struct GramArgs {
     int nitems;
     int nslab;
     int xcd_map;         // 1: XCD-aware block->(item,slab) mapping (needs nslab % 8 == 0)
+    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0
 };
 
 template <typename T> struct Mfma;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
     const int npanels = (panA == panB) ? 1 : 2;
     const WaveBlock wb = it->wb[wave];
     const bool active = wb.mask != 0;                    // wave-uniform
+    const bool tri = wb.tri != 0;                        // wave-uniform
 
     // LDS element offsets of the block's A and B fragment origins (wave-uniform)
     int offA[MR], offB[NR];
@@ -159,19 +162,41 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
         for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     vec2_t st[2][PASSES];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) { st[s][ps].x = T(0); st[s][ps].y = T(0); }
     T wreg = T(0);
     const int srow = wave;          // + GRAM_WAVES*pass
     const int scol = lane * 2;
+    // per-thread column class of each panel: 2 = both columns inside p, 1 = boundary, 0 = outside
+    int colk[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int gcol = (s == 0 ? panA : panB) * PANEL + scol;
+        colk[s] = (s < npanels) ? ((gcol + 1 < a.p) ? 2 : (gcol < a.p ? 1 : 0)) : 0;
+    }
+    const int lane_boff = scol * (int)sizeof(T);
 
+    // Steady state: the whole chunk is inside the slab, so a load is "wave-uniform row pointer
+    // (SALU) + constant per-lane byte offset" with no per-element bounds checks; the generic
+    // load_pair path only runs for the slab's last chunk, unaligned inputs and boundary columns.
     auto stage_load = [&](int chunk) {
         const int64_t r0 = rbeg + (int64_t)chunk * KC;
+        const bool fast = VEC && (r0 + KC <= rend);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (s < npanels) {
-                const int gcol = (s == 0 ? panA : panB) * PANEL + scol;
+            const int pan = (s == 0 ? panA : panB);
+            if (fast && colk[s] == 2) {
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps) {
+                    const T* rowp = a.X + (r0 + srow + GRAM_WAVES * ps) * a.ldx + pan * PANEL;   // wave-uniform
+                    st[s][ps] = *reinterpret_cast<const vec2_t*>(reinterpret_cast<const char*>(rowp) + lane_boff);
+                }
+            } else if (colk[s] != 0) {
 #pragma unroll
                 for (int ps = 0; ps < PASSES; ++ps)
-                    st[s][ps] = load_pair<T, VEC>(a.X, a.ldx, r0 + srow + GRAM_WAVES * ps, rend, gcol, a.p);
+                    st[s][ps] = load_pair<T, VEC>(a.X, a.ldx, r0 + srow + GRAM_WAVES * ps, rend, pan * PANEL + scol, a.p);
             }
         }
         if (HASW && tid < KC) {
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) stage_load(c + 1);
+        if (c + 1 < nchunks && !(a.dbg & 1)) stage_load(c + 1);
         if (active) {
             const T* base = lds + (c & 1) * BUF_ELEMS;
 #pragma unroll
@@ -218,7 +243,13 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                    for (int j = i; j < NR; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                if (!tri) {     // wave-uniform: a diagonal block skips its 6 below-diagonal tiles
+#pragma unroll
+                    for (int i = 1; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < i; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                }
             }
         }
         if (c + 1 < nchunks) stage_write((c + 1) & 1);
@@ -346,6 +377,7 @@ static void build_items(int p, std::vector<GramItem>& items) {
                 for (int j = 0; j < NR; ++j)
                     if (hb.ra[i] >= 0 && hb.cb[j] >= 0 && hb.ra[i] <= hb.cb[j]) mask |= (unsigned short)(1u << (i * NR + j));
             w.mask = mask;
+            w.tri = (hb.ra[0] == hb.cb[0] && hb.pr == hb.pc) ? 1 : 0;
         }
         items.push_back(it);
     }
@@ -419,6 +451,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     a.X = X; a.w = w; a.partial = (T*)ws; a.items = pl.d_items; a.ldx = ldx; a.n = n;
     a.rows_per_slab = rps; a.p = p; a.PP = pl.PP; a.nitems = pl.nitems; a.nslab = nslab;
     a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
+    { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; if (a.dbg & 2) a.xcd_map = 0; }
     const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
     const int blocks = pl.nitems * nslab;
     if (w) {
@@ -458,7 +491,7 @@ int gram_plan_check(int p, int* nitems, int* nslots, int* ntiles) {
         if (g.panA > g.panB) return -5;
         for (int wv = 0; wv < GRAM_WAVES; ++wv) {
             const WaveBlock& w = g.wb[wv];
-            if (w.mask) slots += MR * NR;
+            if (w.mask) slots += w.tri ? 10 : MR * NR;
             for (int i = 0; i < MR; ++i)
                 for (int j = 0; j < NR; ++j) {
                     if (!((w.mask >> (i * NR + j)) & 1)) continue;

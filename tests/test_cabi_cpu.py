@@ -47,7 +47,7 @@ def test_gram_tile_plan_covers_upper_triangle_once(lib, p):
     assert lib.dlsa_gram_plan_check(p, items, slots, tiles) == 0
     nt = (p + 15) // 16
     assert tiles.value == nt * (nt + 1) // 2           # every tile on/above the diagonal, once
-    assert slots.value >= tiles.value and slots.value % 16 == 0
+    assert slots.value >= tiles.value                  # computed tile slots (diagonal blocks: 10 of 16)
     assert items.value * 4 * 16 >= slots.value         # 4 waves x (4x4 tiles) per workgroup
 
 
@@ -55,7 +55,7 @@ def test_metric_config_plan_is_perfectly_balanced(lib):
     items, slots, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.dlsa_gram_plan_check(500, items, slots, tiles) == 0
     # 6 off-diagonal panel pairs + 3 workgroups of diagonal blocks, every wave holds a full 4x4 block
-    assert (items.value, slots.value, tiles.value) == (9, 576, 528)
+    assert (items.value, slots.value, tiles.value) == (9, 528, 528)     # no wasted tile slot at p=500
 
 
 def test_engine_refuses_cpu_tensors():
