@@ -1,0 +1,88 @@
+"""Reduce / combine / shrink -- host mirror of the reference's dlsa/dlsa.py.
+
+`dlsa_mapred` (dlsa.py:21-61) sums the per-partition blocks (on this rank, then across ranks with
+ONE all-reduce when torch.distributed is initialised -- the algorithm's single round of
+communication), solves the WLS system on the GPU and returns the reference's frame
+`beta_byOLS, beta_byONESHOT, <names...>`.  `dlsa` (dlsa.py:70-107) runs the LARS path on the GPU
+and picks the AIC / BIC minimisers.  Aliases `dlsa_mapreduce` / `dlsa_fit` follow README.md:25-27.
+"""
+import numpy as np
+import pandas as pd
+import torch
+
+from . import distributed, engine
+from .lsa import lars_path_device
+from .models import MappedBlocks
+
+
+def _blocks_from_frame(pdf):
+    """Stacked reference layout (K*p rows, columns par_id | coef | Sig_invMcoef | names...) ->
+    per-par_id sums on the device (dlsa.py:30-34 groupby('par_id').sum)."""
+    cols = list(pdf.columns)
+    names = cols[3:]
+    p = len(names)
+    par_id = torch.from_numpy(pdf.iloc[:, 0].to_numpy(dtype=np.int64)).cuda()
+    vals = torch.from_numpy(np.ascontiguousarray(pdf.iloc[:, 1:].to_numpy(dtype=np.float64))).cuda()
+    if vals.shape[0] == 0:
+        raise Exception("Zero-length grouped pandas DataFrame obtained, check the input.")   # dlsa.py:36-39
+    summed = torch.zeros((p, 2 + p), dtype=torch.float64, device="cuda").index_add_(0, par_id, vals)
+    # message layout [Sig_inv (p*p) | Sig_invMcoef (p) | coef (p)]
+    msg = torch.cat([summed[:, 2:].reshape(-1), summed[:, 1], summed[:, 0]])
+    return msg, names, p
+
+
+def dlsa_mapred(model_mapped_sdf, num_partitions=None):
+    """MapReduce for partitioned data with a given model (dlsa.py:21-61).
+
+    Accepts the device-resident `MappedBlocks` of `fit_logistic_partitions`, a pandas frame in the
+    reference's stacked layout, or any object with `.toPandas()` (and optionally
+    `.rdd.getNumPartitions()`) such as a Spark DataFrame.  `num_partitions` is the divisor of the
+    one-shot mean (dlsa.py:51-52 uses the number of Spark partitions); default = number of blocks.
+    In a torch.distributed job every rank passes ITS blocks; the sums are all-reduced."""
+    if isinstance(model_mapped_sdf, MappedBlocks):
+        mb = model_mapped_sdf
+        names, p = mb.names, mb.coef.shape[1]
+        msg = engine.sum_blocks(mb.coef, mb.Sig_invMcoef, mb.Sig_inv)
+        nblocks = mb.num_partitions
+    else:
+        pdf = model_mapped_sdf
+        if not isinstance(pdf, pd.DataFrame):
+            if num_partitions is None and hasattr(pdf, "rdd"):
+                num_partitions = pdf.rdd.getNumPartitions()
+            pdf = pdf.toPandas()
+        msg, names, p = _blocks_from_frame(pdf)
+        nblocks = max(1, pdf.shape[0] // max(1, p))
+    counts = torch.tensor([float(nblocks if num_partitions is None else num_partitions)],
+                          dtype=torch.float64, device=msg.device)
+    msg = distributed.allreduce_message(torch.cat([msg, counts]))
+    K = float(msg[-1].item())
+    Sig_inv_sum = msg[: p * p].view(p, p)
+    Sig_invMcoef_sum = msg[p * p: p * p + p]
+    # least-squares solution of an SPD system = Cholesky solve (dlsa.py:48-49)
+    beta_byOLS = engine.spd_solve(Sig_inv_sum, Sig_invMcoef_sum)
+    beta_byONESHOT = msg[p * p + p: p * p + 2 * p] / K                                  # dlsa.py:51-52
+    out = torch.cat([beta_byOLS[:, None], beta_byONESHOT[:, None], Sig_inv_sum], 1).cpu().numpy()
+    return pd.DataFrame(out, columns=["beta_byOLS", "beta_byONESHOT"] + list(names))
+
+
+def dlsa(Sig_inv_, beta_, sample_size, fit_intercept=False, type="lar"):
+    """Distributed Least Squares Approximation (dlsa.py:70-107): LARS path of the quadratic
+    (theta - beta_)' Sig_inv_ (theta - beta_) and the path points minimising AIC and BIC.
+    With an intercept the intercept estimate is beta0[idx] + beta_[0] (the rpy2 original,
+    dlsa.py:97 comment).  Returns DataFrame {beta_byAIC, beta_byBIC}."""
+    S = np.asarray(Sig_inv_, dtype=np.float64) if not isinstance(Sig_inv_, torch.Tensor) else Sig_inv_
+    b = np.asarray(beta_, dtype=np.float64) if not isinstance(beta_, torch.Tensor) else beta_
+    fit = lars_path_device(S, b, fit_intercept, sample_size, type=type)
+    ia = int(torch.argmin(fit["AIC"]).item())
+    ib = int(torch.argmin(fit["BIC"]).item())
+    by_aic, by_bic = fit["beta"][ia], fit["beta"][ib]
+    if fit_intercept:
+        b0 = float(b[0])
+        by_aic = torch.cat([(fit["beta0"][ia] + b0).reshape(1), by_aic])
+        by_bic = torch.cat([(fit["beta0"][ib] + b0).reshape(1), by_bic])
+    return pd.DataFrame({"beta_byAIC": by_aic.cpu().numpy(), "beta_byBIC": by_bic.cpu().numpy()})
+
+
+# README.md:25-27 names
+dlsa_mapreduce = dlsa_mapred
+dlsa_fit = dlsa

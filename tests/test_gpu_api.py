@@ -1,0 +1,164 @@
+"""GPU tests of the reference-compatible Python surface (dlsa_amd.models / .dlsa / .lsa):
+same call sequence, column names and results as the reference's own run (golden fixtures)."""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL_MLE = 1e-10
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def api():
+    assert torch.cuda.is_available()
+    import dlsa_amd
+    return dlsa_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+def _frame(X, y, K, names):
+    pid = np.arange(X.shape[0]) % K
+    return pd.DataFrame(np.column_stack([pid, y, X]), columns=["partition_id", "label"] + names)
+
+
+F1 = sorted(os.path.basename(f)[3:-8] for f in glob.glob(os.path.join(GOLDEN, "F1_*_mle.npz")))
+
+
+@pytest.mark.parametrize("name", F1)
+def test_reference_call_sequence_matches_golden(api, orc, name):
+    """logistic_model per partition -> dlsa_mapred -> dlsa, exactly as projects/logistic_dlsa.py
+    drives them (:305-316, :337, :341-344), against the reference's own outputs."""
+    z = np.load(os.path.join(GOLDEN, "F1_%s_mle.npz" % name))
+    if name.startswith("synth"):
+        X, y = orc.synth_logistic(int(z["seed"]), 0, int(z["n"]), int(z["p"]))
+    else:
+        g = np.load(os.path.join(GOLDEN, "games_expand_input.npz"))
+        X, y = g["X"].astype(float), g["y"].astype(float)
+    K, icpt = int(z["K"]), bool(z["fit_intercept"])
+    names = ["x%d" % i for i in range(X.shape[1])]
+    df = _frame(X, y, K, names)
+    outs = [api.logistic_model(df[df.partition_id == k].reset_index(drop=True), "label", fit_intercept=icpt)
+            for k in range(K)]
+    assert list(outs[0].columns) == list(z["columns"])
+    for k in range(K):
+        assert list(outs[k]["par_id"]) == list(range(outs[k].shape[0]))
+        assert rel_inf(outs[k]["coef"], z["coef"][k]) < TOL_MLE
+        assert rel_inf(outs[k].iloc[:, 3:], z["Sig_inv"][k]) < TOL_MLE
+        assert rel_inf(outs[k]["Sig_invMcoef"], z["Sig_invMcoef"][k]) < TOL_MLE
+    mapped = pd.concat(outs, ignore_index=True)
+    mr = api.dlsa_mapred(mapped)
+    assert list(mr.columns) == list(z["mapred_columns"])
+    assert rel_inf(mr["beta_byOLS"], z["beta_byOLS"]) < TOL_MLE
+    assert rel_inf(mr["beta_byONESHOT"], z["beta_byONESHOT"]) < TOL_MLE
+    assert rel_inf(mr.iloc[:, 2:], z["Sig_inv_sum"]) < TOL_MLE
+    out = api.dlsa(Sig_inv_=mr.iloc[:, 2:], beta_=mr["beta_byOLS"], sample_size=X.shape[0], fit_intercept=icpt)
+    assert list(out.columns) == ["beta_byAIC", "beta_byBIC"]
+    by_aic, by_bic, _ = orc.dlsa(z["Sig_inv_sum"], z["beta_byOLS"], X.shape[0], fit_intercept=icpt)
+    assert rel_inf(out["beta_byAIC"], by_aic) < 1e-8
+    assert rel_inf(out["beta_byBIC"], by_bic) < 1e-8
+
+
+def test_tensor_fast_path_equals_frame_path(api, orc):
+    n, p, K = 12000, 30, 6
+    X, y = orc.synth_logistic(5, 0, n, p)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    for icpt in (False, True):
+        mb = api.fit_logistic_partitions(Xd, yd, partition_num=K, fit_intercept=icpt)
+        assert mb.status == [0] * K
+        mr = api.dlsa_mapred(mb)
+        frame = mb.to_frame()
+        assert frame.shape == (K * (p + icpt), 3 + p + icpt)
+        mr2 = api.dlsa_mapred(frame)
+        assert rel_inf(mr2.to_numpy(), mr.to_numpy()) < 1e-12
+        parts = orc.partition_rows(n, K)
+        blocks = [orc.logistic_model_block(X[q], y[q], icpt) for q in parts]
+        ols, oneshot, S = orc.dlsa_mapred_blocks([b[0] for b in blocks], [b[1] for b in blocks], [b[2] for b in blocks])
+        assert rel_inf(mr["beta_byOLS"], ols) < TOL_MLE
+        assert rel_inf(mr["beta_byONESHOT"], oneshot) < TOL_MLE
+
+
+def test_lars_lsa_signature_and_golden(api):
+    z = np.load(os.path.join(GOLDEN, "F3_lars_p50_lasso.npz"))
+    r = api.lars_lsa(np.matrix(z["Sigma"]), z["b"], False, int(z["n"]), type="lasso")
+    assert set(r) == {"AIC", "BIC", "beta", "beta0"}
+    assert rel_inf(r["beta"], z["beta"]) < 1e-8 and rel_inf(r["BIC"], z["BIC"]) < 1e-8
+
+
+def test_dummy_path_standardise_and_zero_block(api, orc):
+    """models.py:56-104: level folding, one-hot, baseline drop, canonical column order,
+    standardisation; :84-91 zero block when a level is missing from the chunk."""
+    rng = np.random.default_rng(2)
+    n = 4000
+    df = pd.DataFrame({"partition_id": np.zeros(n), "label": 0.0,
+                       "dist": rng.normal(5.0, 2.0, n), "dep": rng.normal(-1.0, 0.5, n),
+                       "carrier": rng.choice(["AA", "BB", "CC", "ZZ"], n, p=[0.5, 0.3, 0.15, 0.05]),
+                       "dow": rng.choice(["1", "2", "3"], n)})
+    eta = 0.4 * (df["dist"] - 5) / 2 - 0.3 * (df["carrier"] == "BB") + 0.5 * (df["dow"] == "3")
+    df["label"] = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    dummy_info = {"factor_selected": {"carrier": ["AA", "BB", "CC"], "dow": ["1", "2", "3"]},
+                  "factor_dropped": {"carrier": ["ZZ"], "dow": []},
+                  "factor_selected_names": {"carrier": ["carrier_AA", "carrier_BB", "carrier_CC", "carrier_000_OTHERS"],
+                                            "dow": ["dow_1", "dow_2", "dow_3"]}}
+    baseline = ["carrier_000_OTHERS", "dow_1"]
+    data_info = df[["dist", "dep"]].describe()
+    data_info = pd.DataFrame({c: [str(n), data_info[c]["mean"], data_info[c]["std"]] for c in ["dist", "dep"]})
+    out = api.logistic_model(df, "label", fit_intercept=True, dummy_info=dummy_info,
+                             dummy_factors_baseline=baseline, data_info=data_info)
+    want = ["par_id", "coef", "Sig_invMcoef", "intercept", "dep", "dist",
+            "carrier_AA", "carrier_BB", "carrier_CC", "dow_2", "dow_3"]
+    assert list(out.columns) == want
+    # oracle on the same design matrix
+    Xo = np.column_stack([(df["dep"] - float(data_info["dep"][1])) / float(data_info["dep"][2]),
+                          (df["dist"] - float(data_info["dist"][1])) / float(data_info["dist"][2]),
+                          df["carrier"] == "AA", df["carrier"] == "BB", df["carrier"] == "CC",
+                          df["dow"] == "2", df["dow"] == "3"]).astype(float)
+    c, smc, sig = orc.logistic_model_block(Xo, df["label"].to_numpy(), True)
+    assert rel_inf(out["coef"], c) < TOL_MLE and rel_inf(out.iloc[:, 3:], sig) < TOL_MLE
+    # a chunk without any "CC" carrier -> all-zero block + warning
+    sub = df[df["carrier"] != "CC"].reset_index(drop=True)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        zero = api.logistic_model(sub, "label", fit_intercept=True, dummy_info=dummy_info,
+                                  dummy_factors_baseline=baseline, data_info=data_info)
+    assert any("missing in this data chunk" in str(w.message) for w in wlist)
+    assert zero.shape == (8, 11) and float(np.abs(zero.to_numpy()).max()) == 0.0
+    assert list(zero.columns) == want
+
+
+def test_simulate_and_eval(api, orc):
+    df = api.simulate_logistic(5000, 8, "systematic", 4, seed=77)
+    assert list(df.columns) == ["partition_id", "label"] + ["x%d" % i for i in range(8)]
+    assert df["partition_id"].tolist()[:6] == [0, 1, 2, 3, 0, 1]
+    Xo, yo = orc.synth_logistic(77, 0, 5000, 8)
+    assert np.array_equal(df.iloc[:, 2:].to_numpy(), Xo)
+    with pytest.raises(Exception):
+        api.simulate_logistic(10, 2, "random", 2)
+    par = pd.DataFrame({"beta_byOLS": orc.true_beta(8), "beta_byONESHOT": np.zeros(8)})
+    ev = api.logistic_model_eval(df, "label", par)
+    ll = orc.logistic_loglik(df.iloc[:, 2:].to_numpy(), df["label"].to_numpy(), par.to_numpy())
+    assert list(ev.columns) == ["beta_byOLS", "beta_byONESHOT"]
+    assert rel_inf(ev.to_numpy()[0], ll) < 1e-12
+
+
+def test_mapred_rejects_empty(api):
+    empty = pd.DataFrame(columns=["par_id", "coef", "Sig_invMcoef", "x0", "x1"])
+    with pytest.raises(Exception, match="Zero-length"):
+        api.dlsa_mapred(empty)
