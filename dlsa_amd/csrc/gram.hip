@@ -65,7 +65,7 @@ struct GramArgs {
     int nitems;
     int nslab;
     int xcd_map;         // 1: XCD-aware block->(item,slab) mapping (needs nslab % 8 == 0)
-    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0
+    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0, 2 = no XCD map, 4 = no LDS-DMA
 };
 
 template <typename T> struct Mfma;
@@ -110,8 +110,13 @@ __device__ __forceinline__ typename Vec2<T>::type load_pair(const T* __restrict_
     return v;
 }
 
-template <typename T, bool HASW, bool VEC>
+// MODE 0: scalar global loads -> registers -> LDS (any alignment);  MODE 1: 16-byte loads -> registers -> LDS;
+// MODE 2 (fp64): direct global->LDS DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass,
+// addresses are SGPR offsets, rows past the slab end read as zeros through the buffer descriptor.
+template <typename T, bool HASW, int MODE>
 __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
+    constexpr bool VEC = MODE >= 1;
+    constexpr bool DMA = MODE == 2;
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Vec2<T>::type vec2_t;
     constexpr int PASSES = KC / GRAM_WAVES;              // staging passes per panel
@@ -217,14 +222,55 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
         if (HASW && tid < KC) base[2 * PANEL_ELEMS + tid] = wreg;
     };
 
-    if (nchunks > 0) {
-        stage_load(0);
-        stage_write(0);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __amdgpu_buffer_rsrc_t rsrcX, rsrcW;
+    if constexpr (DMA) {
+        const int64_t nrows = rend > rbeg ? rend - rbeg : 0;
+        const unsigned xbytes = nrows > 0 ? (unsigned)(((nrows - 1) * a.ldx + a.p) * (int64_t)sizeof(T)) : 0u;
+        rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
+        rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)(HASW ? a.w + rbeg : a.X), 0, HASW ? (int)(nrows * sizeof(T)) : 0, 0x00020000);
+        // columns past p are never written by the DMA (lanes masked): zero the buffers once
+        for (int e = tid; e < 2 * BUF_ELEMS; e += GRAM_THREADS) lds[e] = T(0);
+    }
+    auto stage_dma = [&](int chunk, int buf) {
+        if constexpr (DMA) {
+            T* base = lds + buf * BUF_ELEMS;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (colk[s] == 2) {                      // per-lane: both columns inside p
+                    const int pan = (s == 0 ? panA : panB);
+#pragma unroll
+                    for (int ps = 0; ps < PASSES; ++ps) {
+                        const int row = srow + GRAM_WAVES * ps;
+                        const int soff = (int)((((int64_t)chunk * KC + row) * a.ldx + pan * PANEL) * (int64_t)sizeof(T));
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + s * PANEL_ELEMS + row * LDP), 16,
+                                                                 lane_boff, soff, 0, 0);
+                    }
+                }
+            }
+            if (HASW && wave == 0 && lane < KC / 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + 2 * PANEL_ELEMS), 16, lane * 16,
+                                                         chunk * KC * (int)sizeof(T), 0, 0);
+        }
+    };
+
+    if constexpr (DMA) {
+        __syncthreads();                                 // zero fill done before the first DMA lands
+        if (nchunks > 0) stage_dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (nchunks > 0) {
+            stage_load(0);
+            stage_write(0);
+        }
     }
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks && !(a.dbg & 1)) stage_load(c + 1);
+        if (c + 1 < nchunks && !(a.dbg & 1)) {
+            if constexpr (DMA) stage_dma(c + 1, (c + 1) & 1);
+            else stage_load(c + 1);
+        }
         if (active) {
             const T* base = lds + (c & 1) * BUF_ELEMS;
 #pragma unroll
@@ -252,7 +298,11 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
                 }
             }
         }
-        if (c + 1 < nchunks) stage_write((c + 1) & 1);
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c+1 has landed in the other buffer
+        } else {
+            if (c + 1 < nchunks) stage_write((c + 1) & 1);
+        }
         __syncthreads();
     }
 
@@ -453,14 +503,23 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
     { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; if (a.dbg & 2) a.xcd_map = 0; }
     const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
+    int mode = vec ? 1 : 0;
+    if (sizeof(T) == 8 && vec && (p % 2 == 0) && (!w || ((uintptr_t)w % 16) == 0) &&
+        (double)rps * (double)ldx * sizeof(T) < 2.0e9)
+        mode = 2;                                        // direct global->LDS DMA
+    if (a.dbg & 4) mode = vec ? 1 : 0;
     const int blocks = pl.nitems * nslab;
+#define DLSA_LAUNCH_GRAM(HW, MD) hipLaunchKernelGGL((gram_kernel<T, HW, MD>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a)
     if (w) {
-        if (vec) hipLaunchKernelGGL((gram_kernel<T, true, true>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
-        else hipLaunchKernelGGL((gram_kernel<T, true, false>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+        if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(true, 2); }
+        else if (mode == 1) DLSA_LAUNCH_GRAM(true, 1);
+        else DLSA_LAUNCH_GRAM(true, 0);
     } else {
-        if (vec) hipLaunchKernelGGL((gram_kernel<T, false, true>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
-        else hipLaunchKernelGGL((gram_kernel<T, false, false>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a);
+        if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(false, 2); }
+        else if (mode == 1) DLSA_LAUNCH_GRAM(false, 1);
+        else DLSA_LAUNCH_GRAM(false, 0);
     }
+#undef DLSA_LAUNCH_GRAM
     DLSA_HIP_CHECK(hipGetLastError());
     dim3 rg((p + 127) / 128, p);
     hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, (const T*)ws, nslab, pl.PP, p, H, ldh, accumulate);
