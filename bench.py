@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the end-to-end fit (IRLS + combine + LARS); off by default so that every\n"
+                         "gram_kernel launch of the default command has the benchmark's size (rocprof averages)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     return ap.parse_args()
 
@@ -140,6 +143,15 @@ def main():
         flops_row = p * (p + 1) + p             # algorithmic: upper triangle outer product + w scaling
         bytes_row = 8 * (p + 1)                 # algorithmic: the X row + w_i
         ach_tf = R * flops_row / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:    # HBM-side bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            assert prof.get("p", 500) == p
+            kk = [k for k in prof["kernels"] if "gram_kernel<double" in k][0]
+            per_row = (2.0 * prof["kernels"][kk]["FETCH_SIZE"] + prof["kernels"][kk]["WRITE_SIZE"]) * 1024.0 / prof["rows_per_gpu"]
+            traffic, traffic_src = per_row * R, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, KB; FETCH x2 per MI355X_MICROARCH.md)"
+        except Exception:
+            pass
         out = {
             "metric": "rows/sec through X'WX kernel at p=%d" % p, "value": value, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,8 +162,9 @@ def main():
                                    (R, p, R * p * 8 / 1e9, " + 1 RCCL all-reduce of p^2+2p f64" if world > 1 else ""),
                        "rows_per_gpu": R, "p": p, "partitions_per_gpu": 1, "parallelism": "row-shards x%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": None,
-                         "kernel": "gram_kernel<double,11> (+reduce)", "kernel_ms": kern_ms,
+                         "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": R * bytes_row,
+                         "kernel": "dlsa::gram_kernel<double,true,2> (+gram_reduce_kernel, ~0.9 ms)", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_row": flops_row, "algorithmic_bytes_per_row": bytes_row,
                          "hbm_GBps_algorithmic": R * bytes_row / (kern_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": R * bytes_row / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -172,22 +185,23 @@ def main():
         extra["logit_pass"] = {"ms": ms, "rows_per_s": R / (ms * 1e-3),
                                "hbm_GBps": R * 8 * (p + 2) / (ms * 1e-3) / 1e9,
                                "hbm_frac_of_8TBps": R * 8 * (p + 2) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        t1 = time.perf_counter()
-        fit = engine.irls_fit(X, y, [0, R])
-        msgv = engine.sum_blocks(fit["coef"], fit["Sig_invMcoef"], fit["Sig_inv"])
-        S = msgv[: p * p].view(p, p)
-        theta = engine.spd_solve(S, msgv[p * p: p * p + p])
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        path = engine.lars_path(S, theta, False, float(R))
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        extra["end_to_end_fit"] = {"irls_iters": fit["n_iter"][0], "status": fit["status"][0],
-                                   "map_plus_combine_s": t2 - t1, "lars_s": t3 - t2,
-                                   "rows_per_s_whole_fit": R / (t3 - t1),
-                                   "theta_err_vs_truth_linf": float((theta - beta_true).abs().max())}
+        if args.e2e:
+            t1 = time.perf_counter()
+            fit = engine.irls_fit(X, y, [0, R])
+            msgv = engine.sum_blocks(fit["coef"], fit["Sig_invMcoef"], fit["Sig_inv"])
+            S = msgv[: p * p].view(p, p)
+            theta = engine.spd_solve(S, msgv[p * p: p * p + p])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            path = engine.lars_path(S, theta, False, float(R))
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            extra["end_to_end_fit"] = {"irls_iters": fit["n_iter"][0], "status": fit["status"][0],
+                                       "map_plus_combine_s": t2 - t1, "lars_s": t3 - t2,
+                                       "rows_per_s_whole_fit": R / (t3 - t1),
+                                       "theta_err_vs_truth_linf": float((theta - beta_true).abs().max())}
+            del fit
         out["extra"] = extra
-        del fit
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del X, y, w
         torch.cuda.empty_cache()

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 ./bench/ubench_gram_inner > $OUT/ubench_gram_inner.txt 2>&1
 ./bench/probe_mfma4x4 > $OUT/probe_mfma4x4.txt 2>&1
 # 1. per-kernel time of the default bench command
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 bench.py --steps 5 --warmup 1 --rows-per-gpu $ROWS --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 bench.py --rows-per-gpu $ROWS --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 # 2. PMC passes (own runs, kernel-trace only)
 pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py --steps 2 --warmup 1 --rows-per-gpu $ROWS --no-cpu-baseline > $OUT/$name.log 2>&1; }
 pmc pmc_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
@@ -22,7 +22,7 @@ pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 python3 - <<PY
 import csv, collections, glob, json, os
-out = {"rows_per_gpu": $ROWS, "kernels": {}}
+out = {"rows_per_gpu": $ROWS, "p": 500, "kernels": {}}
 for f in sorted(glob.glob("$OUT/pmc_*/*_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):

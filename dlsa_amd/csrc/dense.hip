@@ -17,7 +17,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void chol_solve_kernel(
         const double* __restrict__ rhs, int64_t stride_rhs,
         const double* __restrict__ ref, int64_t stride_ref,
         int p, double* __restrict__ Lws, double* __restrict__ xout, int64_t stride_x,
-        double* __restrict__ stats, int64_t stride_stats) {
+        double* __restrict__ stats, int64_t stride_stats, int reuse_factor) {
     // all LDS lives in the one dynamic array (keeps its base 16-byte aligned)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* col = sm;                    // p
@@ -37,15 +37,18 @@ __global__ __launch_bounds__(CHOL_THREADS) void chol_solve_kernel(
     const int nth = blockDim.x;
 
     if (tid == 0) info = 0;
-    // copy the lower triangle (A is symmetric; read the stored row i, columns <= i)
-    for (int64_t e = tid; e < (int64_t)p * p; e += nth) {
-        const int i = (int)(e / p), k = (int)(e % p);
-        L[e] = (k <= i) ? A[(int64_t)i * lda + k] : 0.0;
+    if (!reuse_factor) {
+        // copy the lower triangle (A is symmetric; read the stored row i, columns <= i)
+        for (int64_t e = tid; e < (int64_t)p * p; e += nth) {
+            const int i = (int)(e / p), k = (int)(e % p);
+            L[e] = (k <= i) ? A[(int64_t)i * lda + k] : 0.0;
+        }
     }
     for (int i = tid; i < p; i += nth) vec[i] = rhs[i];
     __syncthreads();
 
-    for (int j = 0; j < p; ++j) {
+    // reuse_factor != 0: L already holds the factor of an earlier (frozen) Hessian -- solves only
+    for (int j = 0; j < (reuse_factor ? 0 : p); ++j) {
         if (tid == 0) {
             const double d = L[(int64_t)j * p + j];
             if (!(d > 0.0) || !isfinite(d)) { info = isfinite(d) ? 1 : 2; pivot = 1.0; }
@@ -148,13 +151,13 @@ __global__ void sum_blocks_kernel(const double* __restrict__ in, int64_t stride,
 
 int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const double* rhs, int64_t stride_rhs,
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
-                      int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s) {
+                      int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor) {
     const size_t shm = ((size_t)2 * p + 2 * (CHOL_THREADS / 64) + 4) * sizeof(double);
     DLSA_REQUIRE(shm <= 60 * 1024, "spd solve: p=%d too large for the single-workgroup solver", p);
     int threads = CHOL_THREADS;
     if (p <= 64) threads = 256;
     hipLaunchKernelGGL(chol_solve_kernel, dim3(nsys), dim3(threads), shm, s, A, lda, strideA, rhs, stride_rhs,
-                       ref, stride_ref, p, Lws, xout, stride_x, stats, stride_stats);
+                       ref, stride_ref, p, Lws, xout, stride_x, stats, stride_stats, reuse_factor);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
@@ -193,7 +196,7 @@ int dlsa_spd_solve_f64(const double* S, int64_t lds, const double* v, int p, dou
     Arena ar(ws, ws_bytes);
     double* L = (double*)ar.take((size_t)p * p * sizeof(double));
     double* stats = (double*)ar.take(4 * sizeof(double));
-    int rc = launch_chol_solve(S, lds, 0, v, 0, nullptr, 0, p, 1, L, theta, 0, stats, 0, s);
+    int rc = launch_chol_solve(S, lds, 0, v, 0, nullptr, 0, p, 1, L, theta, 0, stats, 0, s, 0);
     if (rc) return rc;
     double h[3];
     DLSA_HIP_CHECK(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));

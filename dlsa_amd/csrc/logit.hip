@@ -169,20 +169,38 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
 }
 
-// g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b]   (fixed order -> deterministic)
-__global__ void logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart,
-                                    int nblocks, int pitch, int p, double* __restrict__ g,
-                                    double* __restrict__ loglik) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g && col < p) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += gpart[(int64_t)b * pitch + col];
-        g[col] = s;
+// g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b].  One workgroup per 64 columns; 16 row
+// groups sum interleaved block ranges and are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void logit_finish_kernel(const double* __restrict__ gpart,
+                                                            const double* __restrict__ llpart, int nblocks,
+                                                            int pitch, int p, double* __restrict__ g,
+                                                            double* __restrict__ loglik) {
+    __shared__ double red[16][65];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    double s = 0.0;
+    if (g && col < p)
+        for (int b = ry; b < nblocks; b += 16) s += gpart[(int64_t)b * pitch + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && g && col < p) {
+        double t = red[0][cx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][cx];
+        g[col] = t;
     }
-    if (loglik && blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += llpart[b];
-        *loglik = s;
+    if (loglik && blockIdx.x == 0) {
+        __syncthreads();
+        double t = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 1024) t += llpart[b];
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if (cx == 0) red[ry][64] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double u = 0.0;
+            for (int k = 0; k < 16; ++k) u += red[k][64];
+            *loglik = u;
+        }
     }
 }
 
@@ -240,7 +258,7 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     }
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 127) / 128), dim3(128), 0, stream,
+        hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, stream,
                            (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, loglik);
         DLSA_HIP_CHECK(hipGetLastError());
     }
