@@ -1,0 +1,133 @@
+#! /usr/bin/env python3
+"""Counterpart of the reference's driver script (projects/logistic_dlsa.py) for GPU row-shards.
+
+Same call sequence and result objects as the reference driver --
+    map (logistic_model per partition, :305-316) -> dlsa_mapred (:337) -> dlsa (:341-344)
+    -> out_par columns beta_byAIC, beta_byBIC, beta_byOLS, beta_byONESHOT (:353-355)
+    -> log-likelihood evaluation (:357-363) -> out_time table (:393-407)
+    -> pickle [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time] (:411-412)
+-- but the Spark partitions are contiguous row ranges of a device-resident shard and the reduce is
+one all-reduce.  Settings are module-level constants in the reference (:66-175); here they are
+command-line flags with the reference's "simulated_pdf" defaults (n=1e5, K=20, p=200).
+
+  python projects/logistic_dlsa.py                                   # 1 GPU
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 projects/logistic_dlsa.py ...
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np          # noqa: E402
+import pandas as pd         # noqa: E402
+import torch                # noqa: E402
+
+import dlsa_amd             # noqa: E402
+from dlsa_amd import distributed, engine  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sample-size", type=int, default=100000)      # sample_size_sub, reference :90
+    ap.add_argument("--partition-num", type=int, default=20)        # partition_num_sub, reference :89
+    ap.add_argument("--p", type=int, default=200)                   # reference :92
+    ap.add_argument("--fit-intercept", action="store_true")         # reference :80 (True for the airline data)
+    ap.add_argument("--gaussian", action="store_true", help="N(0,1/12) features instead of U(-0.5,0.5)")
+    ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--save", default="", help="pickle path for [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time]")
+    args = ap.parse_args()
+
+    rank, world = distributed.init_from_env()
+    tic_init = time.perf_counter()
+    tictoc = {}
+    n, K, p = args.sample_size, args.partition_num, args.p
+    Y_name = "label"
+
+    # ---- this rank's partitions: k % world == rank, each a contiguous row range (repartition, :295)
+    tictoc["repartition"] = [time.perf_counter()]
+    mine = distributed.owned_partitions(K, world, rank)
+    sizes = [len(range(k, n, K)) for k in mine]                     # partition_id = i % K  (models.py:33)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_local = int(offs[-1])
+    kind = engine.SYNTH_GAUSSIAN if args.gaussian else engine.SYNTH_UNIFORM
+    # rows of partition k are the global rows k, k+K, k+2K, ...: generate the full stream once per rank in
+    # chunks and keep this rank's rows grouped by partition (device gather)
+    Xl = torch.empty((n_local, p), dtype=torch.float64, device="cuda")
+    yl = torch.empty((n_local,), dtype=torch.float64, device="cuda")
+    fill = [int(o) for o in offs[:-1]]
+    chunk = max(K, (1 << 22) // max(1, p) // K * K)
+    for r0 in range(0, n, chunk):
+        m = min(chunk, n - r0)
+        Xc, yc = engine.synth(args.seed, r0, m, p, kind=kind)
+        pid = (torch.arange(r0, r0 + m, device="cuda") % K)
+        for j, k in enumerate(mine):
+            sel = (pid == k).nonzero().flatten()
+            Xl[fill[j]: fill[j] + sel.numel()] = Xc[sel]
+            yl[fill[j]: fill[j] + sel.numel()] = yc[sel]
+            fill[j] += sel.numel()
+    torch.cuda.synchronize()
+    tictoc["repartition"].append(time.perf_counter())
+    memsize_total = n * (p + 2) * 8
+
+    # ---- map + reduce (dlsa part 1)
+    tictoc["mapred"] = [time.perf_counter()]
+    names = ["x" + str(i) for i in range(p)]
+    mapped = dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=offs, fit_intercept=args.fit_intercept, names=names)
+    bad = [s for s in mapped.status if s != 0]
+    if bad and rank == 0:
+        print("warning: partitions with status", mapped.status)
+    Sig_inv_beta = dlsa_amd.dlsa_mapred(mapped, num_partitions=len(mine))
+    torch.cuda.synchronize()
+    tictoc["mapred"].append(time.perf_counter())
+
+    # ---- shrinkage on every rank (dlsa part 2)
+    tictoc["dlsa"] = [time.perf_counter()]
+    out_dlsa = dlsa_amd.dlsa(Sig_inv_=Sig_inv_beta.iloc[:, 2:], beta_=Sig_inv_beta["beta_byOLS"],
+                             sample_size=n, fit_intercept=args.fit_intercept)
+    tictoc["dlsa"].append(time.perf_counter())
+    tictoc["model_fit"] = [tic_init, time.perf_counter()]
+
+    # ---- model evaluation: total log-likelihood of each estimator column (model_eval.py:10-42)
+    tictoc["model_eval"] = [time.perf_counter()]
+    out_par = out_dlsa.copy()
+    out_par["beta_byOLS"] = Sig_inv_beta["beta_byOLS"]
+    out_par["beta_byONESHOT"] = Sig_inv_beta["beta_byONESHOT"]
+    Xe = torch.cat([torch.ones((n_local, 1), dtype=torch.float64, device="cuda"), Xl], 1) if args.fit_intercept else Xl
+    par = torch.from_numpy(out_par.to_numpy(dtype=np.float64)).cuda()
+    ll = engine.loglik(Xe.contiguous(), yl, par)
+    ll = distributed.allreduce_message(ll)
+    out_model_eval = pd.DataFrame({c: [float(v)] for c, v in zip(out_par.columns, ll.cpu().numpy())})
+    tictoc["model_eval"].append(time.perf_counter())
+
+    time_mapred = tictoc["mapred"][1] - tictoc["mapred"][0]
+    time_dlsa = tictoc["dlsa"][1] - tictoc["dlsa"][0]
+    time_model_fit = tictoc["model_fit"][1] - tictoc["model_fit"][0]
+    out_time = pd.DataFrame({
+        "sample_size": n, "sample_size_per_partition": n / K, "n_par": p + int(args.fit_intercept),
+        "partition_num": K, "memsize_total": memsize_total,
+        "time_repartition": tictoc["repartition"][1] - tictoc["repartition"][0],
+        "time_mapred": time_mapred, "time_dlsa": time_dlsa, "time_model_fit": time_model_fit,
+        "time_model_eval": tictoc["model_eval"][1] - tictoc["model_eval"][0]}, index=[0])
+    if rank == 0:
+        if args.save:
+            with open(os.path.expanduser(args.save), "wb") as f:
+                pickle.dump([Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time], f)
+            print("Model results are saved to:\t" + args.save)
+        print("\nModel Summary:\n")
+        print(out_time.to_string(index=False))
+        print("\nModel Evaluation:")
+        print("\tlog likelihood:\n")
+        print(out_model_eval.to_string(index=False))
+        print("\nDLSA Coefficients:\n")
+        print(out_par.head(12).to_string())
+    if distributed.is_distributed():
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,3 +162,31 @@ def test_mapred_rejects_empty(api):
     empty = pd.DataFrame(columns=["par_id", "coef", "Sig_invMcoef", "x0", "x1"])
     with pytest.raises(Exception, match="Zero-length"):
         api.dlsa_mapred(empty)
+
+
+def test_driver_script_pickle_layout(api, orc, tmp_path):
+    """projects/logistic_dlsa.py counterpart: call order map -> dlsa_mapred -> dlsa -> eval and the
+    reference's result pickle [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time] (:411)."""
+    import pickle
+    import subprocess
+    import sys
+    from conftest import ROOT
+    pkl = str(tmp_path / "out.pkl")
+    n, K, p = 20000, 4, 10
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "projects", "logistic_dlsa.py"), "--sample-size", str(n),
+                           "--partition-num", str(K), "--p", str(p), "--seed", "123", "--save", pkl])
+    Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time = pickle.load(open(pkl, "rb"))
+    assert list(Sig_inv_beta.columns) == ["beta_byOLS", "beta_byONESHOT"] + ["x%d" % i for i in range(p)]
+    assert list(out_par.columns) == ["beta_byAIC", "beta_byBIC", "beta_byOLS", "beta_byONESHOT"]
+    assert list(out_model_eval.columns) == list(out_par.columns)
+    for col in ("sample_size", "sample_size_per_partition", "n_par", "partition_num", "memsize_total",
+                "time_repartition", "time_mapred", "time_dlsa", "time_model_fit", "time_model_eval"):
+        assert col in out_time.columns
+    X, y = orc.synth_logistic(123, 0, n, p)
+    parts = orc.partition_rows(n, K)
+    blocks = [orc.logistic_model_block(X[q], y[q]) for q in parts]
+    ols, oneshot, S = orc.dlsa_mapred_blocks([b[0] for b in blocks], [b[1] for b in blocks], [b[2] for b in blocks])
+    assert rel_inf(Sig_inv_beta["beta_byOLS"], ols) < TOL_MLE
+    assert rel_inf(Sig_inv_beta["beta_byONESHOT"], oneshot) < TOL_MLE
+    ll = orc.logistic_loglik(X, y, out_par.to_numpy())
+    assert rel_inf(out_model_eval.to_numpy()[0], ll) < 1e-11
