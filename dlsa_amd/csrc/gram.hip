@@ -34,7 +34,13 @@ namespace dlsa {
 
 constexpr int TILE = 16;
 constexpr int PANEL = 128;        // columns per panel = 8 tiles
-constexpr int KC = 16;            // rows per staged chunk = 4 MFMA k-steps
+#ifndef DLSA_GRAM_KC
+#define DLSA_GRAM_KC 16
+#endif
+#ifndef DLSA_GRAM_OCC
+#define DLSA_GRAM_OCC 2
+#endif
+constexpr int KC = DLSA_GRAM_KC;  // rows per staged chunk = KC/4 MFMA k-steps
 constexpr int LDP = 144;          // LDS row pitch (elements): 144 mod 32 == 16 -> conflict-free frags
 constexpr int GRAM_WAVES = 4;
 constexpr int GRAM_THREADS = 64 * GRAM_WAVES;
@@ -114,7 +120,7 @@ __device__ __forceinline__ typename Vec2<T>::type load_pair(const T* __restrict_
 // MODE 2 (fp64): direct global->LDS DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass,
 // addresses are SGPR offsets, rows past the slab end read as zeros through the buffer descriptor.
 template <typename T, bool HASW, int MODE>
-__global__ __launch_bounds__(GRAM_THREADS, 2) void gram_kernel(GramArgs<T> a) {
+__global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramArgs<T> a) {
     constexpr bool VEC = MODE >= 1;
     constexpr bool DMA = MODE == 2;
     typedef typename Mfma<T>::acc_t acc_t;
@@ -459,10 +465,16 @@ static int get_plan(int p, GramPlan& out) {
     return DLSA_OK;
 }
 
-static void choose_slabs(int64_t n, int& nslab, int64_t& rows_per_slab) {
-    // nslab = 512 makes nitems*nslab an exact multiple of the 512 resident workgroups (2 per CU),
-    // i.e. nitems full rounds with no tail; small inputs get >= 256 rows per slab.
-    int64_t ns = 2 * kNumCU;
+static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_slab) {
+    // Workgroups resident at once: OCC per CU.  Pick nslab so that nitems*nslab is (just under) a whole
+    // number of rounds of resident workgroups -- no tail -- with about 32k rows per slab (few, large
+    // partials: 1 round for a 1e6-row partition, nitems rounds for the 2.5e7-row shard), at least 256
+    // rows per slab for small inputs, and a multiple of 8 slabs for the XCD-aware mapping.
+    const int64_t resident = (int64_t)DLSA_GRAM_OCC * kNumCU;
+    nitems = std::max(1, nitems);
+    int64_t rounds = (n * nitems + resident * 16384) / (resident * 32768);
+    rounds = std::min<int64_t>(std::max<int64_t>(rounds, 1), nitems);
+    int64_t ns = std::max<int64_t>(1, resident * rounds / nitems);
     const int64_t by_rows = std::max<int64_t>(1, (n + 255) / 256);
     ns = std::min(ns, by_rows);
     if (ns >= kNumXCD) ns = ns / kNumXCD * kNumXCD;
@@ -475,8 +487,10 @@ static void choose_slabs(int64_t n, int& nslab, int64_t& rows_per_slab) {
 
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
+    std::vector<GramItem> items;
+    build_items(p, items);                // host-only, cheap: the exact item count
     int nslab; int64_t rps;
-    choose_slabs(n, nslab, rps);
+    choose_slabs(n, (int)items.size(), nslab, rps);
     const size_t PP = (size_t)ntile * TILE;
     return align_up((size_t)nslab * PP * PP * elem_bytes, 256);
 }
@@ -491,7 +505,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     int rc = get_plan(p, pl);
     if (rc) return rc;
     int nslab; int64_t rps;
-    choose_slabs(n, nslab, rps);
+    choose_slabs(n, pl.nitems, nslab, rps);
     const size_t need = (size_t)nslab * pl.PP * pl.PP * sizeof(T);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
