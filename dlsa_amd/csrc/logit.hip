@@ -265,37 +265,244 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     return DLSA_OK;
 }
 
-__global__ void gather_column_kernel(const double* __restrict__ par, int64_t ldpar, int col, int p,
-                                     double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p) out[i] = par[(int64_t)i * ldpar + col];
+// ---------------------------------------------------------------------------------------------
+// N1: log-likelihood of C estimator columns in ONE read of X (dlsa/models.py:217-222).
+// Same row layout as logit_kernel; the RB x C dot products of a batch are reduced with one merged
+// butterfly, after which every lane holds eta for one fixed (row-in-batch, column) pair.
+// ---------------------------------------------------------------------------------------------
+struct LoglikArgs {
+    const double* X;
+    const double* y;
+    const double* par;     // p x c row-major
+    double* llpart;        // [nblocks][C]
+    int64_t ldx, ldpar, n;
+    int p, c;
+};
+
+template <int NC, int RB, int C, bool VEC>
+__global__ __launch_bounds__(LOGIT_THREADS) void loglik_kernel(LoglikArgs a) {
+    __shared__ double red[LOGIT_WAVES][C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double2 b[C][NC];
+#pragma unroll
+    for (int j = 0; j < C; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 128 + 2 * lane;
+            b[j][c].x = (col < a.p && j < a.c) ? a.par[(int64_t)col * a.ldpar + j] : 0.0;
+            b[j][c].y = (col + 1 < a.p && j < a.c) ? a.par[(int64_t)(col + 1) * a.ldpar + j] : 0.0;
+        }
+    const int myv = row_of_lane<RB * C>(lane);           // value index = row * C + column
+    const int myrow = myv / C, mycol = myv % C;
+    const bool rep = (lane & rep_mask<RB * C>()) == 0;
+    double ll = 0.0;
+    const int64_t nbatch = (a.n + RB - 1) / RB;
+    const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
+    for (int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave; bt < nbatch; bt += stride) {
+        const int64_t row0 = bt * RB;
+        double dot[RB * C];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int64_t r = row0 + i;
+            const double* src = a.X + r * a.ldx + 2 * lane;
+            double2 x[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = c * 128 + 2 * lane;
+                double2 v; v.x = 0.0; v.y = 0.0;
+                if (r < a.n) {
+                    if (col + 1 < a.p) {
+                        if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
+                        else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
+                    } else if (col < a.p) v.x = src[c * 128];
+                }
+                x[c] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s = fma(x[c].x, b[j][c].x, fma(x[c].y, b[j][c].y, s));
+                dot[i * C + j] = s;
+            }
+        }
+        const double eta = merged_reduce<RB * C>(dot, lane);
+        const int64_t r = row0 + myrow;
+        if (rep && r < a.n && mycol < a.c) {
+            const double yv = a.y[r];
+            ll += yv * eta - (fmax(eta, 0.0) + log1p(exp(-fabs(eta))));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        double s = (rep && mycol == j) ? ll : 0.0;
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (tid < C) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int wv = 1; wv < LOGIT_WAVES; ++wv) s += red[wv][tid];
+        a.llpart[(int64_t)blockIdx.x * C + tid] = s;
+    }
+}
+
+template <int C>
+__global__ void loglik_finish_kernel(const double* __restrict__ llpart, int nblocks, int c, double* __restrict__ out) {
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;      // one wave per column
+    if (j >= c) return;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += llpart[(int64_t)b * C + j];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[j] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N3 (linear-model map): g = X'v and vv = v'v in one read of X (v = the response).  Same row layout.
+// ---------------------------------------------------------------------------------------------
+template <int NC, int RB, bool VEC>
+__global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
+    __shared__ double red[NC * 128 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double2 g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { g[c].x = 0.0; g[c].y = 0.0; }
+    double vv = 0.0;
+    const int64_t nbatch = (a.n + RB - 1) / RB;
+    const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
+    for (int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave; bt < nbatch; bt += stride) {
+        const int64_t row0 = bt * RB;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int64_t r = row0 + i;
+            if (r >= a.n) continue;
+            const double yv = a.y[r];
+            const double* src = a.X + r * a.ldx + 2 * lane;
+            if (lane == 0) vv = fma(yv, yv, vv);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = c * 128 + 2 * lane;
+                double2 v; v.x = 0.0; v.y = 0.0;
+                if (col + 1 < a.p) {
+                    if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
+                    else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
+                } else if (col < a.p) v.x = src[c * 128];
+                g[c].x = fma(yv, v.x, g[c].x);
+                g[c].y = fma(yv, v.y, g[c].y);
+            }
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) vv += __shfl_xor(vv, m, 64);
+    for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double* dst = red + c * 128 + 2 * lane;
+                if (wv == 0) { dst[0] = g[c].x; dst[1] = g[c].y; }
+                else { dst[0] += g[c].x; dst[1] += g[c].y; }
+            }
+            if (lane == 0) { if (wv == 0) red[NC * 128] = vv; else red[NC * 128] += vv; }
+        }
+        __syncthreads();
+    }
+    double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 128);
+    for (int col = tid; col < NC * 128; col += LOGIT_THREADS) gp[col] = red[col];
+    if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
+}
+
+template <int NC, int RB>
+static void launch_xtv(const LogitArgs& a, bool vec, int blocks, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((xtv_kernel<NC, RB, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((xtv_kernel<NC, RB, false>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+}
+
+template <int NC, int RB, int C>
+static void launch_loglik(const LoglikArgs& a, bool vec, int blocks, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((loglik_kernel<NC, RB, C, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((loglik_kernel<NC, RB, C, false>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
 }
 
 }  // namespace dlsa
 
 extern "C" {
 
-// N1 (dlsa/models.py:217-222).  First cut: one fused logit pass per estimator column (c reads
-// of X); the single-read multi-column variant is a planned optimisation.
+// N1 (dlsa/models.py:217-222): all c <= 8 estimator columns in one read of X.
 int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
                     int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream) {
     using namespace dlsa;
     DLSA_REQUIRE(X && y && par && out, "loglik: null argument");
+    DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "loglik: bad shape n=%lld p=%d", (long long)n, p);
     DLSA_REQUIRE(c > 0 && c <= 8 && ldpar >= c, "loglik: need 1 <= c <= 8 and ldpar >= c");
-    const size_t need = logit_workspace_bytes_impl(n, p) + 256 + align_up((size_t)p * sizeof(double), 256);
+    const size_t need = align_up((size_t)LOGIT_MAX_BLOCKS * 8 * sizeof(double), 256);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("loglik: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    Arena ar(ws, ws_bytes);
-    double* bcol = (double*)ar.take((size_t)p * sizeof(double));
-    void* lws = ar.take(logit_workspace_bytes_impl(n, p));
-    for (int j = 0; j < c; ++j) {
-        hipLaunchKernelGGL(gather_column_kernel, dim3((p + 255) / 256), dim3(256), 0, s, par, ldpar, j, p, bcol);
-        int rc = logit_pass_impl(X, ldx, y, bcol, n, p, nullptr, nullptr, out + j, lws, logit_workspace_bytes_impl(n, p), s);
-        if (rc) return rc;
+    LoglikArgs a;
+    a.X = X; a.y = y; a.par = par; a.llpart = (double*)ws; a.ldx = ldx; a.ldpar = ldpar; a.n = n; a.p = p; a.c = c;
+    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    const int nc = logit_nc(p);
+    int blocks;
+    // RB*C = 16 values per merged butterfly (8 for the widest rows)
+    if (c <= 4) {
+        switch (nc) {
+            case 1: blocks = logit_blocks(n, 4); launch_loglik<1, 4, 4>(a, vec, blocks, s); break;
+            case 2: blocks = logit_blocks(n, 4); launch_loglik<2, 4, 4>(a, vec, blocks, s); break;
+            case 4: blocks = logit_blocks(n, 4); launch_loglik<4, 4, 4>(a, vec, blocks, s); break;
+            case 8: blocks = logit_blocks(n, 2); launch_loglik<8, 2, 4>(a, vec, blocks, s); break;
+            default: blocks = logit_blocks(n, 1); launch_loglik<16, 1, 4>(a, vec, blocks, s); break;
+        }
+        hipLaunchKernelGGL((loglik_finish_kernel<4>), dim3(1), dim3(64 * 4), 0, s, (const double*)a.llpart, blocks, c, out);
+    } else {
+        switch (nc) {
+            case 1: blocks = logit_blocks(n, 2); launch_loglik<1, 2, 8>(a, vec, blocks, s); break;
+            case 2: blocks = logit_blocks(n, 2); launch_loglik<2, 2, 8>(a, vec, blocks, s); break;
+            case 4: blocks = logit_blocks(n, 2); launch_loglik<4, 2, 8>(a, vec, blocks, s); break;
+            case 8: blocks = logit_blocks(n, 1); launch_loglik<8, 1, 8>(a, vec, blocks, s); break;
+            default: {      // p > 1024 with more than 4 columns: two passes of 4 columns
+                int rc = dlsa_loglik_f64(X, ldx, y, n, p, par, ldpar, 4, out, ws, ws_bytes, stream);
+                if (rc) return rc;
+                return dlsa_loglik_f64(X, ldx, y, n, p, par + 4, ldpar, c - 4, out + 4, ws, ws_bytes, stream);
+            }
+        }
+        hipLaunchKernelGGL((loglik_finish_kernel<8>), dim3(1), dim3(64 * 8), 0, s, (const double*)a.llpart, blocks, c, out);
     }
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+// N3: g = X'v (p values) and vv = v'v (1 value, nullable) in one read of X -- the linear-model map
+// step's X'y (no DLSA implementation in the reference; README.md:6 claims the method).
+int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv,
+                 void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(X && v && g, "xtv: null argument");
+    DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "xtv: bad shape n=%lld p=%d", (long long)n, p);
+    const int nc = logit_nc(p);
+    if (!ws || ws_bytes < logit_workspace_bytes_impl(n, p) || ((uintptr_t)ws & 255)) {
+        set_error("xtv: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    LogitArgs a;
+    a.X = X; a.y = v; a.beta = nullptr; a.w_out = nullptr; a.ldx = ldx; a.n = n; a.p = p;
+    a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
+    a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    int blocks;
+    switch (nc) {
+        case 1: blocks = logit_blocks(n, 8); launch_xtv<1, 8>(a, vec, blocks, s); break;
+        case 2: blocks = logit_blocks(n, 8); launch_xtv<2, 8>(a, vec, blocks, s); break;
+        case 4: blocks = logit_blocks(n, 4); launch_xtv<4, 4>(a, vec, blocks, s); break;
+        case 8: blocks = logit_blocks(n, 2); launch_xtv<8, 2>(a, vec, blocks, s); break;
+        default: blocks = logit_blocks(n, 1); launch_xtv<16, 1>(a, vec, blocks, s); break;
+    }
+    hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, s,
+                       (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv);
+    DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
 

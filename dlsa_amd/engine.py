@@ -118,11 +118,25 @@ def loglik(X, y, par):
     par = par.contiguous()
     c = par.shape[1]
     out = torch.empty((c,), dtype=torch.float64, device=X.device)
-    nb = lib.dlsa_logit_workspace_bytes(n, p) + 8 * p + 1024
+    nb = lib.dlsa_logit_workspace_bytes(n, p)
     ws = _workspace(nb, X.device)
     check(lib.dlsa_loglik_f64(_ptr(X), _rowmajor(X), _ptr(y), n, p, _ptr(par), par.stride(0), c, _ptr(out),
                               _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def xtv(X, v):
+    """g = X'v and v'v in one read of X (linear-model map step).  Returns (g [p], vv [1])."""
+    lib = _lib.load()
+    _require_gpu(X, v)
+    n, p = X.shape
+    g = torch.empty((p,), dtype=torch.float64, device=X.device)
+    vv = torch.empty((1,), dtype=torch.float64, device=X.device)
+    nb = lib.dlsa_logit_workspace_bytes(n, p)
+    ws = _workspace(nb, X.device)
+    check(lib.dlsa_xtv_f64(_ptr(X), _rowmajor(X), _ptr(v.contiguous()), n, p, _ptr(g), _ptr(vv),
+                           _ptr(ws), ws.numel(), _stream()))
+    return g, vv
 
 
 def irls_fit(X, y, part_offsets, tol=1e-13, max_iter=100):

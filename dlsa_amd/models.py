@@ -184,3 +184,72 @@ def logistic_model_eval(sample_df, Y_name, par, fit_intercept=False, dummy_info=
     pard = torch.from_numpy(np.ascontiguousarray(np.asarray(par, dtype=np.float64))).cuda()
     ll = engine.loglik(Xd, yd, pard).cpu().numpy()
     return pd.DataFrame({par.columns[i]: [ll[i]] for i in range(par.shape[1])})
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear-regression map step.  The reference claims linear DLSA (README.md:6) but ships
+# only the logistic map; this sibling keeps the same block layout so dlsa_mapred / dlsa apply unchanged:
+#   coef = OLS estimate, Sig_inv = X'X, Sig_invMcoef = X'y (= X'X coef).
+# With these blocks the WLS combine of dlsa_mapred equals the global OLS estimate exactly.
+# ---------------------------------------------------------------------------------------------
+def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_intercept=False, names=None):
+    """Tensor fast path: one Gram pass X'X + one X'y pass per partition.  Returns MappedBlocks whose
+    `loglik` slot carries the residual sum of squares of each partition."""
+    if not X.is_cuda:
+        raise RuntimeError("fit_linear_partitions runs on the GPU only (no CPU fallback)")
+    n, p = X.shape
+    if part_offsets is None:
+        K = int(partition_num) if partition_num else 1
+        if K > 1:
+            idx = torch.arange(n, device=X.device)
+            order = torch.argsort(idx % K, stable=True)
+            X, y = X[order], y[order]
+            counts = torch.bincount(idx % K, minlength=K).cpu().tolist()
+        else:
+            counts = [n]
+        part_offsets = np.concatenate([[0], np.cumsum(counts)])
+    if fit_intercept:
+        X = torch.cat([torch.ones((n, 1), dtype=X.dtype, device=X.device), X], dim=1)
+    X, y = X.contiguous(), y.contiguous()
+    pp = X.shape[1]
+    if names is None:
+        names = ["x" + str(i) for i in range(p)]
+    names = (["intercept"] if fit_intercept else []) + list(names)
+    offs = [int(v) for v in part_offsets]
+    K = len(offs) - 1
+    coef = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
+    smc = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
+    sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=X.device)
+    status, rss = [], []
+    for k in range(K):
+        lo, hi = offs[k], offs[k + 1]
+        if hi <= lo:
+            status.append(4); rss.append(0.0)
+            continue
+        engine.gram(X[lo:hi], None, out=sig[k])
+        g, yy = engine.xtv(X[lo:hi], y[lo:hi])
+        smc[k] = g
+        try:
+            coef[k] = engine.spd_solve(sig[k], g)
+            status.append(0)
+            rss.append(float((yy - torch.dot(coef[k], g)).item()))       # y'y - theta'X'y
+        except Exception:
+            status.append(2); rss.append(float("nan"))
+            warnings.warn("linear_model: X'X not positive definite (collinear design)")
+    return MappedBlocks(coef, smc, sig, names, status, [1] * K, rss, sample_size=n)
+
+
+def linear_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[], data_info=[]):
+    """Frame-level sibling of logistic_model for a linear response: same arguments, same
+    p x (3+p) output frame `par_id, coef, Sig_invMcoef, [intercept,] <features>`."""
+    x_train, usecols_full, _ = _design_frame(sample_df, Y_name, fit_intercept, dummy_info,
+                                             dummy_factors_baseline, data_info)
+    if x_train is None:
+        return pd.DataFrame(0, index=np.arange(len(usecols_full) - 3), columns=usecols_full)
+    Xd = torch.from_numpy(np.ascontiguousarray(x_train.to_numpy(dtype=np.float64))).cuda()
+    yd = torch.from_numpy(np.ascontiguousarray(sample_df[Y_name].to_numpy(dtype=np.float64))).cuda()
+    mb = fit_linear_partitions(Xd, yd, fit_intercept=fit_intercept, names=list(x_train.columns))
+    out = mb.block_frame(0)
+    if out.isna().values.any():
+        warnings.warn("NAs appear in the final output")
+    return out

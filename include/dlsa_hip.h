@@ -82,10 +82,17 @@ int dlsa_logit_pass_f64(const double* X, int64_t ldx, const double* y, const dou
                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- N1: log-likelihood of c estimator columns (dlsa/models.py:217-222) ---------------
- * par: p x c row-major (ldpar >= c), c <= 8; out: c values. */
+ * par: p x c row-major (ldpar >= c), c <= 8; out: c values.  One read of X for all columns.
+ * Workspace: dlsa_logit_workspace_bytes(n, p) is sufficient. */
 int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p,
                     const double* par, int64_t ldpar, int c, double* out,
                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- N3: g = X'v and vv = v'v (nullable) in one read of X: the X'y of a linear-model map step
+ * (the reference claims linear DLSA, README.md:6, but ships no implementation).  Workspace as
+ * dlsa_logit_workspace_bytes. */
+int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p,
+                 double* g, double* vv, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a2-a6: per-partition exact-MLE fit + local quadratic approximation ---------------
  * Replaces logistic_model's numeric core (dlsa/models.py:110-131) for K partitions stored

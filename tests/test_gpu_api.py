@@ -190,3 +190,52 @@ def test_driver_script_pickle_layout(api, orc, tmp_path):
     assert rel_inf(Sig_inv_beta["beta_byONESHOT"], oneshot) < TOL_MLE
     ll = orc.logistic_loglik(X, y, out_par.to_numpy())
     assert rel_inf(out_model_eval.to_numpy()[0], ll) < 1e-11
+
+
+def test_linear_model_blocks_combine_to_global_ols(api, orc):
+    """N3: linear-model map step; the WLS combine of the OLS blocks is the global OLS estimate."""
+    rng = np.random.default_rng(4)
+    n, p, K = 30000, 40, 6
+    X = orc.synth_features(9, 0, n, p)
+    beta = orc.true_beta(p)
+    y = 0.5 + X @ beta + rng.standard_normal(n)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    mb = api.fit_linear_partitions(Xd, yd, partition_num=K, fit_intercept=True)
+    assert mb.status == [0] * K
+    mr = api.dlsa_mapred(mb)
+    Xi = np.column_stack([np.ones(n), X])
+    ols = np.linalg.lstsq(Xi, y, rcond=None)[0]
+    assert rel_inf(mr["beta_byOLS"], ols) < 1e-10
+    assert rel_inf(mr.iloc[:, 2:], Xi.T @ Xi) < 1e-12
+    parts = orc.partition_rows(n, K)
+    c0 = np.linalg.lstsq(Xi[parts[0]], y[parts[0]], rcond=None)[0]
+    assert rel_inf(mb.coef[0].cpu().numpy(), c0) < 1e-10
+    rss0 = float(np.sum((y[parts[0]] - Xi[parts[0]] @ c0) ** 2))
+    assert abs(mb.loglik[0] - rss0) < 1e-8 * rss0
+    df = pd.DataFrame(np.column_stack([np.zeros(n), y, X]), columns=["partition_id", "label"] + ["x%d" % i for i in range(p)])
+    out = api.linear_model(df, "label", fit_intercept=True)
+    assert list(out.columns)[:4] == ["par_id", "coef", "Sig_invMcoef", "intercept"]
+    assert rel_inf(out["coef"], ols) < 1e-10
+    sel = api.dlsa(mr.iloc[:, 2:], mr["beta_byOLS"], n, fit_intercept=True)
+    assert sel.shape == (p + 1, 2)
+
+
+def test_loglik_single_pass_many_columns(api, orc):
+    from dlsa_amd import engine
+    rng = np.random.default_rng(12)
+    for (n, p, c) in [(3000, 7, 1), (5000, 130, 3), (4000, 500, 4), (3000, 300, 7), (1500, 1100, 8), (2000, 1500, 5)]:
+        X, y = orc.synth_logistic(21, 0, n, p)
+        par = rng.standard_normal((p, c)) * (2.0 / np.sqrt(p))
+        out = engine.loglik(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(par).cuda()).cpu().numpy()
+        assert rel_inf(out, orc.logistic_loglik(X, y, par)) < 1e-12
+
+
+def test_xtv(api, orc):
+    from dlsa_amd import engine
+    rng = np.random.default_rng(3)
+    for (n, p) in [(1, 1), (1000, 5), (4099, 129), (3000, 500), (700, 1000)]:
+        X = rng.random((n, p)) - 0.5
+        v = rng.standard_normal(n)
+        g, vv = engine.xtv(torch.from_numpy(X).cuda(), torch.from_numpy(v).cuda())
+        assert rel_inf(g.cpu().numpy(), X.T @ v) < 1e-12
+        assert abs(vv.item() - v @ v) <= 1e-12 * (v @ v)
