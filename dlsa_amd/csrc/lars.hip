@@ -20,7 +20,10 @@
 
 namespace dlsa {
 
-constexpr int LARS_THREADS = 1024;
+#ifndef DLSA_LARS_THREADS
+#define DLSA_LARS_THREADS 1024
+#endif
+constexpr int LARS_THREADS = DLSA_LARS_THREADS;
 constexpr int LARS_WAVES = LARS_THREADS / 64;
 
 struct LarsArgs {
@@ -98,9 +101,16 @@ __device__ int append_column(const double* __restrict__ S, double* __restrict__ 
     __syncthreads();
     // r = R^{-T} xold :  r[i] = sum_{l<=i} Rinv[l][i] xold[l]   (coalesced over i)
     for (int i = tid; i < na; i += LARS_THREADS) {
-        double s = 0.0;
-        for (int l = 0; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], xold[l], s);
-        r[i] = s;
+        double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int l = 0;
+        for (; l + 3 <= i; l += 4) {
+            s = fma(Rinv[(int64_t)l * m + i], xold[l], s);
+            s1 = fma(Rinv[(int64_t)(l + 1) * m + i], xold[l + 1], s1);
+            s2 = fma(Rinv[(int64_t)(l + 2) * m + i], xold[l + 2], s2);
+            s3 = fma(Rinv[(int64_t)(l + 3) * m + i], xold[l + 3], s3);
+        }
+        for (; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], xold[l], s);
+        r[i] = (s + s1) + (s2 + s3);
     }
     __syncthreads();
     double part = 0.0;
@@ -112,9 +122,14 @@ __device__ int append_column(const double* __restrict__ S, double* __restrict__ 
     // new column of R^{-1}: [-R^{-1} r / rpp ; 1/rpp]   (one wave per row, coalesced over l)
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < na; i += LARS_WAVES) {
-        double s = 0.0;
-        for (int l = i + lane; l < na; l += 64) s = fma(Rinv[(int64_t)i * m + l], r[l], s);
-        s = wave_sum(s);
+        double s = 0.0, s1 = 0.0;
+        int l = i + lane;
+        for (; l + 64 < na; l += 128) {
+            s = fma(Rinv[(int64_t)i * m + l], r[l], s);
+            s1 = fma(Rinv[(int64_t)i * m + l + 64], r[l + 64], s1);
+        }
+        if (l < na) s = fma(Rinv[(int64_t)i * m + l], r[l], s);
+        s = wave_sum(s + s1);
         if (lane == 0) Rinv[(int64_t)i * m + na] = -s / rpp;
     }
     if (tid == 0) Rinv[(int64_t)na * m + na] = 1.0 / rpp;
@@ -125,12 +140,20 @@ __device__ int append_column(const double* __restrict__ S, double* __restrict__ 
 __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
     __shared__ double red[LARS_WAVES + 1];
     __shared__ int sh_i[4];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // sh_w[m] | sh_part[LARS_THREADS] | sh_act[m]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int p = a.p;
     const int off = a.intercept ? 1 : 0;
     const int m = p - off;
     const double eps = a.eps;
+    double* sh_w = dyn;
+    double* sh_part = dyn + m;
+    int* sh_act = reinterpret_cast<int*>(dyn + m + LARS_THREADS);
+    // thread groups for the mat-vec over the active set: JT threads along j, G groups along i
+    int JT = 64;
+    while (JT < m && JT < LARS_THREADS) JT *= 2;
+    const int G = LARS_THREADS / JT;
     double* __restrict__ S = a.S;
     double* __restrict__ Rinv = a.Rinv;
     double* b = a.vec + 0 * (int64_t)m;       // sign(b0)
@@ -236,15 +259,27 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
         if (na == 0) break;   // nothing could enter (degenerate input)
         // ---- equiangular direction: Gi1 = R^{-1} R^{-T} Sign (lsa.py:151-153)
         for (int i = tid; i < na; i += LARS_THREADS) {
-            double s = 0.0;
-            for (int l = 0; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], sgn[l], s);
-            t1[i] = s;
+            double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int l = 0;
+            for (; l + 3 <= i; l += 4) {
+                s = fma(Rinv[(int64_t)l * m + i], sgn[l], s);
+                s1 = fma(Rinv[(int64_t)(l + 1) * m + i], sgn[l + 1], s1);
+                s2 = fma(Rinv[(int64_t)(l + 2) * m + i], sgn[l + 2], s2);
+                s3 = fma(Rinv[(int64_t)(l + 3) * m + i], sgn[l + 3], s3);
+            }
+            for (; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], sgn[l], s);
+            t1[i] = (s + s1) + (s2 + s3);
         }
         __syncthreads();
         for (int i = wave; i < na; i += LARS_WAVES) {
-            double s = 0.0;
-            for (int l = i + lane; l < na; l += 64) s = fma(Rinv[(int64_t)i * m + l], t1[l], s);
-            s = wave_sum(s);
+            double s = 0.0, s1 = 0.0;
+            int l = i + lane;
+            for (; l + 64 < na; l += 128) {
+                s = fma(Rinv[(int64_t)i * m + l], t1[l], s);
+                s1 = fma(Rinv[(int64_t)i * m + l + 64], t1[l + 64], s1);
+            }
+            if (l < na) s = fma(Rinv[(int64_t)i * m + l], t1[l], s);
+            s = wave_sum(s + s1);
             if (lane == 0) t2[i] = s;
         }
         __syncthreads();
@@ -253,13 +288,35 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
         const double A = 1.0 / sqrt(block_sum(part, red));
         for (int i = tid; i < na; i += LARS_THREADS) w[i] = A * t2[i];
         __syncthreads();
-        // ---- u = Sigma[:,active] w  (rows of S, coalesced over j)
-        for (int j = tid; j < m; j += LARS_THREADS) {
-            double s = 0.0;
-            for (int i = 0; i < na; ++i) s = fma(w[i], S[(int64_t)active[i] * m + j], s);
-            u[j] = s;
-        }
+        // ---- u = Sigma[:,active] w  (rows of S, coalesced over j).  w and the active list are cached in
+        // LDS (no dependent global loads); the i range is split over G thread groups of JT threads.
+        for (int i = tid; i < na; i += LARS_THREADS) { sh_w[i] = w[i]; sh_act[i] = active[i]; }
         __syncthreads();
+        {
+            const int jx = tid % JT, g = tid / JT;
+            for (int j0 = 0; j0 < m; j0 += JT) {
+                const int j = j0 + jx;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                if (j < m) {
+                    int i = g;
+                    for (; i + 3 * G < na; i += 4 * G) {
+                        s0 = fma(sh_w[i], S[(int64_t)sh_act[i] * m + j], s0);
+                        s1 = fma(sh_w[i + G], S[(int64_t)sh_act[i + G] * m + j], s1);
+                        s2 = fma(sh_w[i + 2 * G], S[(int64_t)sh_act[i + 2 * G] * m + j], s2);
+                        s3 = fma(sh_w[i + 3 * G], S[(int64_t)sh_act[i + 3 * G] * m + j], s3);
+                    }
+                    for (; i < na; i += G) s0 = fma(sh_w[i], S[(int64_t)sh_act[i] * m + j], s0);
+                }
+                sh_part[g * JT + jx] = (s0 + s1) + (s2 + s3);
+                __syncthreads();
+                if (g == 0 && j < m) {
+                    double t = sh_part[jx];
+                    for (int q = 1; q < G; ++q) t += sh_part[q * JT + jx];
+                    u[j] = t;
+                }
+                __syncthreads();
+            }
+        }
         // ---- step length (lsa.py:154-162)
         double gamhat = Cmax / A;
         if (na < m) {
@@ -377,7 +434,8 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.n_steps = (int*)ar.take(256);
     a.beta_path = beta_path; a.beta0 = beta0; a.aic = aic; a.bic = bic;
     DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, m * m * 8, s));
-    hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), 0, s, a);
+    const size_t shm = ((size_t)(p - (intercept ? 1 : 0)) * 12 + (size_t)LARS_THREADS * 8 + 64);
+    hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
     DLSA_HIP_CHECK(hipGetLastError());
     int steps = 0;
     DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
