@@ -1,0 +1,128 @@
+"""Per-GPU-shard timings of every BASELINE.json configuration on ONE MI355X (evidence table for
+DESIGN.md; the headline metric lives in bench.py).  Synthetic inputs as SURVEY.md section 8(d)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+import dlsa_amd      # noqa: E402
+from dlsa_amd import engine  # noqa: E402
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    return sorted(ts)[len(ts) // 2], out
+
+
+def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
+    X, y = Xy if Xy is not None else engine.synth(20260101, 0, n, p, kind=kind)
+    p = X.shape[1]
+    offs = [int(n * k / K) for k in range(K + 1)]
+    beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[: int(0.4 * p)] = 1.0
+    w, _, _ = engine.logit_pass(X, y, beta)
+    t_gram, H = timed(lambda: engine.gram(X, w))
+    t_logit, _ = timed(lambda: engine.logit_pass(X, y, beta))
+    def whole():
+        mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs)
+        out = dlsa_amd.dlsa_mapred(mb)
+        sel = dlsa_amd.dlsa(out.iloc[:, 2:], out["beta_byOLS"], n)
+        return mb, out, sel
+    t_all, (mb, out, sel) = timed(whole, reps=2)
+    t_fit, _ = timed(lambda: engine.irls_fit(X, y, offs), reps=2)
+    fl = p * (p + 1) + p
+    return {"config": name, "n": n, "p": p, "K": K, "dtype": "f64",
+            "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
+            "gram_GBps_alg": n * 8 * (p + 1) / t_gram / 1e9,
+            "logit_ms": t_logit * 1e3, "logit_GBps": n * 8 * (p + 2) / t_logit / 1e9,
+            "map_fit_s": t_fit, "map_reduce_lars_s": t_all, "irls_iters": mb.n_iter[:3], "status_ok": all(s == 0 for s in mb.status)}
+
+
+def airline_shaped(n, seed=7):
+    """Config 4 surrogate: 7 standardised Gaussian columns + 5 Zipf factors one-hot to p~250."""
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    cols = [torch.randn((n, 7), dtype=torch.float64, device="cuda", generator=g)]
+    for levels in (11, 6, 20, 110, 110):
+        pr = 1.0 / torch.arange(1, levels + 1, dtype=torch.float64, device="cuda")
+        codes = torch.multinomial(pr / pr.sum(), n, replacement=True, generator=g)
+        oh = torch.zeros((n, levels - 1), dtype=torch.float64, device="cuda")      # baseline level dropped
+        m = codes > 0
+        oh[m.nonzero().flatten(), codes[m] - 1] = 1.0
+        cols.append(oh)
+    X = torch.cat([torch.ones((n, 1), dtype=torch.float64, device="cuda")] + cols, 1)
+    if X.shape[1] % 2:
+        X = torch.cat([X, torch.randn((n, 1), dtype=torch.float64, device="cuda", generator=g)], 1)
+    beta = torch.randn(X.shape[1], dtype=torch.float64, device="cuda", generator=g) * 0.15
+    y = (torch.rand(n, dtype=torch.float64, device="cuda", generator=g) < torch.sigmoid(X @ beta)).double()
+    return X.contiguous(), y
+
+
+def linear_config(name, n, p, K):
+    X, _ = engine.synth(20260101, 0, n, p, kind=engine.SYNTH_GAUSSIAN, labels=False, dtype=torch.float32)
+    beta = torch.zeros(p, dtype=torch.float32, device="cuda"); beta[: int(0.4 * p)] = 1.0
+    y = torch.randn(n, dtype=torch.float32, device="cuda")
+    for r in range(0, n, 1_000_000):                 # chunked: one giant sgemv (4.8e10 elements) returned NaNs under memory pressure
+        y[r:r + 1_000_000] += X[r:r + 1_000_000] @ beta
+    if os.environ.get("DLSA_DIAG"):
+        print("y finite", bool(torch.isfinite(y).all()), file=sys.stderr, flush=True)
+        offs = [int(n * k / K) for k in range(K + 1)]
+        for k in range(K):
+            lo, hi = offs[k], offs[k + 1]
+            H = engine.gram(X[lo:hi], None); g, vv = engine.xtv(X[lo:hi], y[lo:hi])
+            Hd, gd = H.double(), g.double()
+            msg = "part %d H finite %s g finite %s Hmax %.3e" % (k, bool(torch.isfinite(H).all()), bool(torch.isfinite(g).all()), float(H.abs().max()))
+            try:
+                engine.spd_solve(Hd, gd); msg += " solve ok"
+            except Exception as e:
+                msg += " SOLVE FAIL %s" % e
+                try:
+                    ev = torch.linalg.eigvalsh(Hd); msg += " eig [%.3e, %.3e]" % (float(ev.min()), float(ev.max()))
+                except Exception as e2:
+                    msg += " eig fail"
+                bad = (~torch.isfinite(H)).nonzero()
+                msg += " nonfinite count %d first %s" % (bad.shape[0], bad[:3].tolist())
+                asym = float((H - H.T).abs().max()); msg += " asym %.3e" % asym
+            print(msg, file=sys.stderr, flush=True)
+    t_gram, _ = timed(lambda: engine.gram(X, None))
+    t_xty, _ = timed(lambda: engine.xtv(X, y))
+    t_all, mb = timed(lambda: dlsa_amd.fit_linear_partitions(X, y, part_offsets=[int(n * k / K) for k in range(K + 1)]), reps=2)
+    out = dlsa_amd.dlsa_mapred(mb)
+    fl = p * (p + 1)
+    return {"config": name, "n": n, "p": p, "K": K, "dtype": "f32",
+            "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
+            "gram_GBps_alg": n * 4 * p / t_gram / 1e9, "xty_ms": t_xty * 1e3, "xty_GBps": n * 4 * (p + 1) / t_xty / 1e9,
+            "map_fit_s": t_all, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max())}
+
+
+def main():
+    class _P(list):
+        def append(self, r):
+            print(json.dumps(r), flush=True)
+    rows = _P()
+    sel = set(sys.argv[1:]) or {"C1", "C2", "C2b", "C3", "C3b", "C4", "C5"}
+    if "C1" in sel:
+        rows.append(logistic_config("C1 n=1e5 p=50 K=20 (uniform, reference simulated_pdf)", 100_000, 50, 20, kind=engine.SYNTH_UNIFORM))
+    if "C2" in sel:
+        rows.append(logistic_config("C2 n=1e7 p=100 K=1", 10_000_000, 100, 1))
+    if "C2b" in sel:
+        rows.append(logistic_config("C2 n=1e7 p=100 K=10", 10_000_000, 100, 10))
+    if "C3" in sel:
+        rows.append(logistic_config("C3 shard n=2.5e7 p=500 K=1 (one shard per GPU)", 25_000_000, 500, 1))
+    if "C3b" in sel:
+        rows.append(logistic_config("C3 shard n=2.5e7 p=500 K=25 (1e6 rows per partition)", 25_000_000, 500, 25))
+    if "C4" in sel:
+        n4 = 14_000_000
+        rows.append(logistic_config("C4 shard airline-shaped synthetic n=1.4e7 (113.9M/8) p~250 K=14", n4, 0, 14, Xy=airline_shaped(n4)))
+    torch.cuda.empty_cache()
+    if "C5" in sel:
+        rows.append(linear_config("C5 shard (capped) linear n=2.4e7 p=2000 fp32 K=8", 24_000_000, 2000, 8))
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@
 // per RB rows instead of once per row, and the residuals are broadcast back through SGPRs for
 // the rank-1 update of g, which stays in registers for the whole kernel.
 #include "common.h"
+#include <algorithm>
 
 namespace dlsa {
 
@@ -411,6 +412,98 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
     if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
 }
 
+// fp32 rows (config 5, wide-p linear model): lane l holds columns 256c + 4l + {0..3} (16-byte loads);
+// products are accumulated in fp64 and written back as fp32.
+struct XtvF32Args {
+    const float* X;
+    const float* v;
+    double* gpart;     // [nblocks][NC*256]
+    double* vvpart;    // [nblocks]
+    int64_t ldx, n;
+    int p;
+};
+
+template <int NC, bool VEC>
+__global__ __launch_bounds__(LOGIT_THREADS) void xtv_f32_kernel(XtvF32Args a) {
+    __shared__ double red[NC * 256 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double g[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[c][e] = 0.0;
+    double vv = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
+    for (int64_t r = (int64_t)blockIdx.x * LOGIT_WAVES + wave; r < a.n; r += stride) {
+        const double yv = (double)a.v[r];
+        if (lane == 0) vv = fma(yv, yv, vv);
+        const float* src = a.X + r * a.ldx + 4 * lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 256 + 4 * lane;
+            float4 x; x.x = x.y = x.z = x.w = 0.f;
+            if (col + 3 < a.p) {
+                if (VEC) x = *reinterpret_cast<const float4*>(src + c * 256);
+                else { x.x = src[c * 256]; x.y = src[c * 256 + 1]; x.z = src[c * 256 + 2]; x.w = src[c * 256 + 3]; }
+            } else {
+                if (col < a.p) x.x = src[c * 256];
+                if (col + 1 < a.p) x.y = src[c * 256 + 1];
+                if (col + 2 < a.p) x.z = src[c * 256 + 2];
+            }
+            g[c][0] = fma(yv, (double)x.x, g[c][0]);
+            g[c][1] = fma(yv, (double)x.y, g[c][1]);
+            g[c][2] = fma(yv, (double)x.z, g[c][2]);
+            g[c][3] = fma(yv, (double)x.w, g[c][3]);
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) vv += __shfl_xor(vv, m, 64);
+    for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    double* dst = red + c * 256 + 4 * lane + e;
+                    if (wv == 0) *dst = g[c][e]; else *dst += g[c][e];
+                }
+            if (lane == 0) { if (wv == 0) red[NC * 256] = vv; else red[NC * 256] += vv; }
+        }
+        __syncthreads();
+    }
+    double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 256);
+    for (int col = tid; col < NC * 256; col += LOGIT_THREADS) gp[col] = red[col];
+    if (tid == 0) a.vvpart[blockIdx.x] = red[NC * 256];
+}
+
+__global__ __launch_bounds__(1024) void xtv_f32_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ vvpart,
+                                                              int nblocks, int pitch, int p, float* __restrict__ g,
+                                                              float* __restrict__ vv) {
+    __shared__ double red[16][65];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    double s = 0.0;
+    if (col < p)
+        for (int b = ry; b < nblocks; b += 16) s += gpart[(int64_t)b * pitch + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < p) {
+        double t = red[0][cx];
+        for (int k = 1; k < 16; ++k) t += red[k][cx];
+        g[col] = (float)t;
+    }
+    if (vv && blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += vvpart[b];
+        *vv = (float)t;
+    }
+}
+
+template <int NC>
+static void launch_xtv_f32(const XtvF32Args& a, bool vec, int blocks, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((xtv_f32_kernel<NC, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((xtv_f32_kernel<NC, false>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+}
+
 template <int NC, int RB>
 static void launch_xtv(const LogitArgs& a, bool vec, int blocks, hipStream_t s) {
     if (vec) hipLaunchKernelGGL((xtv_kernel<NC, RB, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
@@ -502,6 +595,40 @@ int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p
     }
     hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, s,
                        (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+int dlsa_xtv_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, float* g, float* vv,
+                 void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(X && v && g, "xtv_f32: null argument");
+    DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "xtv_f32: bad shape n=%lld p=%d", (long long)n, p);
+    const int chunks = (p + 255) / 256;
+    int nc = 1;
+    while (nc < chunks) nc *= 2;
+    const size_t need = align_up((size_t)LOGIT_MAX_BLOCKS * nc * 256 * sizeof(double), 256) + align_up((size_t)LOGIT_MAX_BLOCKS * 8, 256);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("xtv_f32: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    XtvF32Args a;
+    a.X = X; a.v = v; a.ldx = ldx; a.n = n; a.p = p;
+    a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 256 * sizeof(double));
+    a.vvpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    const bool vec = (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    int64_t blocks64 = (n + LOGIT_WAVES * 16 - 1) / (LOGIT_WAVES * 16);
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(blocks64, 1), LOGIT_MAX_BLOCKS);
+    switch (nc) {
+        case 1: launch_xtv_f32<1>(a, vec, blocks, s); break;
+        case 2: launch_xtv_f32<2>(a, vec, blocks, s); break;
+        case 4: launch_xtv_f32<4>(a, vec, blocks, s); break;
+        default: launch_xtv_f32<8>(a, vec, blocks, s); break;
+    }
+    hipLaunchKernelGGL(xtv_f32_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, s, (const double*)a.gpart,
+                       (const double*)a.vvpart, blocks, nc * 256, p, g, vv);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

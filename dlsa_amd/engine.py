@@ -126,14 +126,18 @@ def loglik(X, y, par):
 
 
 def xtv(X, v):
-    """g = X'v and v'v in one read of X (linear-model map step).  Returns (g [p], vv [1])."""
+    """g = X'v and v'v in one read of X (linear-model map step).  Returns (g [p], vv [1]) in X's dtype."""
     lib = _lib.load()
     _require_gpu(X, v)
     n, p = X.shape
-    g = torch.empty((p,), dtype=torch.float64, device=X.device)
-    vv = torch.empty((1,), dtype=torch.float64, device=X.device)
-    nb = lib.dlsa_logit_workspace_bytes(n, p)
+    g = torch.empty((p,), dtype=X.dtype, device=X.device)
+    vv = torch.empty((1,), dtype=X.dtype, device=X.device)
+    nb = lib.dlsa_logit_workspace_bytes(n, p) * (2 if X.dtype == torch.float32 else 1)
     ws = _workspace(nb, X.device)
+    if X.dtype == torch.float32:
+        check(lib.dlsa_xtv_f32(_ptr(X), _rowmajor(X), _ptr(v.contiguous()), n, p, _ptr(g), _ptr(vv),
+                               _ptr(ws), ws.numel(), _stream()))
+        return g, vv
     check(lib.dlsa_xtv_f64(_ptr(X), _rowmajor(X), _ptr(v.contiguous()), n, p, _ptr(g), _ptr(vv),
                            _ptr(ws), ws.numel(), _stream()))
     return g, vv

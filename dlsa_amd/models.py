@@ -220,14 +220,21 @@ def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_inter
     coef = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
     smc = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
     sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=X.device)
+    f32 = X.dtype == torch.float32       # config 5: fp32 rows, fp32 Gram; the p x p blocks are kept in fp64
+    Hk = torch.empty((pp, pp), dtype=X.dtype, device=X.device) if f32 else None
     status, rss = [], []
     for k in range(K):
         lo, hi = offs[k], offs[k + 1]
         if hi <= lo:
             status.append(4); rss.append(0.0)
             continue
-        engine.gram(X[lo:hi], None, out=sig[k])
+        if f32:
+            engine.gram(X[lo:hi], None, out=Hk)
+            sig[k] = Hk.double()
+        else:
+            engine.gram(X[lo:hi], None, out=sig[k])
         g, yy = engine.xtv(X[lo:hi], y[lo:hi])
+        g, yy = g.double(), yy.double()
         smc[k] = g
         try:
             coef[k] = engine.spd_solve(sig[k], g)

@@ -93,6 +93,9 @@ int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, in
  * dlsa_logit_workspace_bytes. */
 int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p,
                  double* g, double* vv, void* ws, size_t ws_bytes, void* stream);
+/* fp32 rows (wide-p linear config): fp64 accumulation, fp32 results; workspace 2x the fp64 query */
+int dlsa_xtv_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p,
+                 float* g, float* vv, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a2-a6: per-partition exact-MLE fit + local quadratic approximation ---------------
  * Replaces logistic_model's numeric core (dlsa/models.py:110-131) for K partitions stored

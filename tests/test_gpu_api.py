@@ -239,3 +239,20 @@ def test_xtv(api, orc):
         g, vv = engine.xtv(torch.from_numpy(X).cuda(), torch.from_numpy(v).cuda())
         assert rel_inf(g.cpu().numpy(), X.T @ v) < 1e-12
         assert abs(vv.item() - v @ v) <= 1e-12 * (v @ v)
+
+
+def test_linear_model_fp32_rows(api, orc):
+    """Config-5 shape in miniature: fp32 rows, wide p, fp32 Gram + fp64-accumulated X'y."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(6)
+    n, p, K = 20000, 300, 2
+    X = (rng.random((n, p)) - 0.5).astype(np.float32)
+    y = (X.astype(np.float64) @ orc.true_beta(p) + rng.standard_normal(n)).astype(np.float32)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    g, vv = engine.xtv(Xd, yd)
+    assert rel_inf(g.cpu().numpy(), X.astype(np.float64).T @ y.astype(np.float64)) < 1e-6
+    assert abs(vv.item() - float(y.astype(np.float64) @ y.astype(np.float64))) < 1e-6 * vv.item()
+    mb = api.fit_linear_partitions(Xd, yd, partition_num=K)
+    mr = api.dlsa_mapred(mb)
+    ols = np.linalg.lstsq(X.astype(np.float64), y.astype(np.float64), rcond=None)[0]
+    assert rel_inf(mr["beta_byOLS"], ols) < 2e-3          # fp32 Gram accumulation
