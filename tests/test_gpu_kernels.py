@@ -85,6 +85,35 @@ def test_gram_strided_rows_and_accumulate(eng, orc):
     assert rel_inf(H.cpu().numpy(), H0 + orc.gram(buf[:, :p], w)) < 1e-11
 
 
+@pytest.mark.parametrize("n,p,ld", [(5000, 36, 40), (777, 500, 512), (20000, 130, 256), (33, 2, 6), (100000, 64, 64)])
+def test_gram_dma_path_with_row_pitch(eng, orc, n, p, ld):
+    """Even p and even leading dimension > p: the direct global->LDS DMA path with a row pitch that
+    differs from p (buffer descriptor bounds, column masking, slab tails)."""
+    rng = np.random.default_rng(n + p)
+    buf = rng.random((n, ld)) - 0.5
+    buf[:, p:] = np.nan                      # anything read beyond column p would poison the result
+    Xd = dev(buf)[:, :p]
+    w = rng.random(n) * 0.25
+    H = eng.gram(Xd, dev(w)).cpu().numpy()
+    assert np.all(np.isfinite(H))
+    assert rel_inf(H, orc.gram(buf[:, :p], w)) < TOL_KERNEL
+    H1 = eng.gram(Xd).cpu().numpy()
+    assert rel_inf(H1, orc.gram(buf[:, :p])) < TOL_KERNEL
+
+
+def test_logit_pass_with_row_pitch(eng, orc):
+    rng = np.random.default_rng(17)
+    n, p, ld = 3000, 70, 96
+    buf = rng.random((n, ld)) - 0.5
+    buf[:, p:] = np.nan
+    beta = rng.standard_normal(p) * 0.3
+    y = (rng.random(n) < 0.5).astype(np.float64)
+    w, g, ll = eng.logit_pass(dev(buf)[:, :p], dev(y), dev(beta))
+    wo, go, llo = orc.logit_pass(buf[:, :p], y, beta)
+    assert rel_inf(w.cpu().numpy(), wo) < TOL_KERNEL and rel_inf(g.cpu().numpy(), go) < 1e-11
+    assert abs(ll.item() - llo) < 1e-12 * abs(llo)
+
+
 def test_gram_identity_operand_layout(eng):
     """A = I check with asymmetric B (guide section 3): X = [I_p ; B] rows -> X'X = I + B'B."""
     p = 48
