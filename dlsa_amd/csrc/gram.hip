@@ -71,7 +71,7 @@ struct GramArgs {
     int nitems;
     int nslab;
     int xcd_map;         // 1: XCD-aware block->(item,slab) mapping (needs nslab % 8 == 0)
-    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0, 2 = no XCD map, 4 = no LDS-DMA, 8 = loader wave
+    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0, 2 = no XCD map, 4 = no LDS-DMA
 };
 
 template <typename T> struct Mfma;
@@ -119,13 +119,11 @@ __device__ __forceinline__ typename Vec2<T>::type load_pair(const T* __restrict_
 // MODE 0: scalar global loads -> registers -> LDS (any alignment);  MODE 1: 16-byte loads -> registers -> LDS;
 // MODE 2 (fp64): direct global->LDS DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass,
 // addresses are SGPR offsets, rows past the slab end read as zeros through the buffer descriptor.
-// MODE 3 (fp64, experiment behind DLSA_GRAM_DBG=8): MODE 2 plus a fifth LOADER wave that issues all the
-// DMA so the four MFMA waves never spend issue slots on loads -- measured SLOWER (109 vs 101.7 ms).
+// (A fifth "loader" wave issuing all the DMA was tried and measured slower: 109 vs 101.7 ms.)
 template <typename T, bool HASW, int MODE>
-__global__ __launch_bounds__(MODE == 3 ? GRAM_THREADS + 64 : GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramArgs<T> a) {
+__global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramArgs<T> a) {
     constexpr bool VEC = MODE >= 1;
-    constexpr bool DMA = MODE >= 2;
-    constexpr bool LOADER = MODE == 3;
+    constexpr bool DMA = MODE == 2;
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Vec2<T>::type vec2_t;
     constexpr int PASSES = KC / GRAM_WAVES;              // staging passes per panel
@@ -153,8 +151,8 @@ __global__ __launch_bounds__(MODE == 3 ? GRAM_THREADS + 64 : GRAM_THREADS, DLSA_
     const GramItem* __restrict__ it = a.items + item_id;
     const int panA = it->panA, panB = it->panB;
     const int npanels = (panA == panB) ? 1 : 2;
-    const WaveBlock wb = it->wb[wave < GRAM_WAVES ? wave : 0];
-    const bool active = wave < GRAM_WAVES && wb.mask != 0;   // wave-uniform (the loader wave owns no tiles)
+    const WaveBlock wb = it->wb[wave];
+    const bool active = wb.mask != 0;                    // wave-uniform
     const bool tri = wb.tri != 0;                        // wave-uniform
 
     // LDS element offsets of the block's A and B fragment origins (wave-uniform)
@@ -239,26 +237,25 @@ __global__ __launch_bounds__(MODE == 3 ? GRAM_THREADS + 64 : GRAM_THREADS, DLSA_
         rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
         rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)(HASW ? a.w + rbeg : a.X), 0, HASW ? (int)(nrows * sizeof(T)) : 0, 0x00020000);
         // columns past p are never written by the DMA (lanes masked): zero the buffers once
-        for (int e = tid; e < 2 * BUF_ELEMS; e += (int)blockDim.x) lds[e] = T(0);
+        for (int e = tid; e < 2 * BUF_ELEMS; e += GRAM_THREADS) lds[e] = T(0);
     }
     auto stage_dma = [&](int chunk, int buf) {
         if constexpr (DMA) {
             T* base = lds + buf * BUF_ELEMS;
-            if (LOADER && wave != GRAM_WAVES) return;    // only the loader wave issues loads
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (colk[s] == 2) {                      // per-lane: both columns inside p
                     const int pan = (s == 0 ? panA : panB);
 #pragma unroll
-                    for (int ps = 0; ps < (LOADER ? KC : PASSES); ++ps) {
-                        const int row = LOADER ? ps : srow + GRAM_WAVES * ps;
+                    for (int ps = 0; ps < PASSES; ++ps) {
+                        const int row = srow + GRAM_WAVES * ps;
                         const int soff = (int)((((int64_t)chunk * KC + row) * a.ldx + pan * PANEL) * (int64_t)sizeof(T));
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + s * PANEL_ELEMS + row * LDP), 16,
                                                                  lane_boff, soff, 0, 0);
                     }
                 }
             }
-            if (HASW && wave == (LOADER ? GRAM_WAVES : 0) && lane < KC / 2)
+            if (HASW && wave == 0 && lane < KC / 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + 2 * PANEL_ELEMS), 16, lane * 16,
                                                          chunk * KC * (int)sizeof(T), 0, 0);
         }
@@ -323,7 +320,7 @@ __global__ __launch_bounds__(MODE == 3 ? GRAM_THREADS + 64 : GRAM_THREADS, DLSA_
         const int r0 = ((((wb.a[i] >> 3) & 1) ? panB : panA) * 8 + (wb.a[i] & 7)) * TILE;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            if (active && ((wb.mask >> (i * NR + j)) & 1)) {
+            if ((wb.mask >> (i * NR + j)) & 1) {
                 const int c0 = ((((wb.b[j] >> 3) & 1) ? panB : panA) * 8 + (wb.b[j] & 7)) * TILE;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -526,17 +523,14 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
         (double)rps * (double)ldx * sizeof(T) < 2.0e9)
         mode = 2;                                        // direct global->LDS DMA
     if (a.dbg & 4) mode = vec ? 1 : 0;
-    if (mode == 2 && (a.dbg & 8)) mode = 3;              // experiment: dedicated loader wave (measured slower: 109 vs 101.7 ms)
     const int blocks = pl.nitems * nslab;
-#define DLSA_LAUNCH_GRAM(HW, MD) hipLaunchKernelGGL((gram_kernel<T, HW, MD>), dim3(blocks), dim3((MD) == 3 ? GRAM_THREADS + 64 : GRAM_THREADS), 0, stream, a)
+#define DLSA_LAUNCH_GRAM(HW, MD) hipLaunchKernelGGL((gram_kernel<T, HW, MD>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a)
     if (w) {
-        if (mode == 3) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(true, 3); }
-        else if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(true, 2); }
+        if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(true, 2); }
         else if (mode == 1) DLSA_LAUNCH_GRAM(true, 1);
         else DLSA_LAUNCH_GRAM(true, 0);
     } else {
-        if (mode == 3) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(false, 3); }
-        else if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(false, 2); }
+        if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(false, 2); }
         else if (mode == 1) DLSA_LAUNCH_GRAM(false, 1);
         else DLSA_LAUNCH_GRAM(false, 0);
     }
