@@ -310,7 +310,7 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
         } else {
             if (c + 1 < nchunks) stage_write((c + 1) & 1);
         }
-        __syncthreads();
+        if (!(a.dbg & 16)) __syncthreads();                    // dbg 16: timing experiment only (wrong results)
     }
 
     // epilogue: stored tiles -> this slab's partial buffer
