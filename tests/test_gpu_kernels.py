@@ -114,6 +114,32 @@ def test_logit_pass_with_row_pitch(eng, orc):
     assert abs(ll.item() - llo) < 1e-12 * abs(llo)
 
 
+def test_gram_and_logit_random_shapes(eng, orc):
+    """40 random (n, p, row pitch, weighted?) shapes: every staging mode (scalar / 16-byte / DMA), ragged
+    slabs, partial panels and tiles."""
+    rng = np.random.default_rng(20260101)
+    for case in range(40):
+        n = int(rng.integers(1, 6000))
+        p = int(rng.integers(1, 620))
+        ld = p + int(rng.integers(0, 9))
+        buf = rng.random((n, ld)) - 0.5
+        buf[:, p:] = np.nan
+        Xd = dev(buf)[:, :p]
+        X = buf[:, :p]
+        w = rng.random(n) * 0.25 if case % 3 else None
+        H = eng.gram(Xd, dev(w) if w is not None else None).cpu().numpy()
+        assert np.all(np.isfinite(H)), (n, p, ld)
+        assert rel_inf(H, orc.gram(X, w)) < 1e-11, (n, p, ld)
+        assert np.array_equal(H, H.T)
+        beta = rng.standard_normal(p) / np.sqrt(p)
+        y = (rng.random(n) < 0.5).astype(np.float64)
+        wv, g, ll = eng.logit_pass(Xd, dev(y), dev(beta))
+        wo, go, llo = orc.logit_pass(X, y, beta)
+        assert rel_inf(wv.cpu().numpy(), wo) < 1e-11, (n, p, ld)
+        assert np.max(np.abs(g.cpu().numpy() - go)) < 1e-10 * max(1.0, np.max(np.abs(go))), (n, p, ld)
+        assert abs(ll.item() - llo) < 1e-11 * abs(llo), (n, p, ld)
+
+
 def test_gram_identity_operand_layout(eng):
     """A = I check with asymmetric B (guide section 3): X = [I_p ; B] rows -> X'X = I + B'B."""
     p = 48
