@@ -52,9 +52,14 @@ struct WaveBlock {
     unsigned short mask;          // bit i*NR+j: tile (a[i], b[j]) is stored (on/above the diagonal, inside p)
     unsigned short tri;           // 1: diagonal block (a == b): only tiles j >= i are computed
 };
+constexpr int LIST_CAP = 12;      // list mode: at most 12 tiles per wave (16 makes hipcc spill in fp64)
 struct GramItem {
     int panA, panB;               // panel indices (panB == panA: single-panel item)
-    WaveBlock wb[GRAM_WAVES];
+    WaveBlock wb[GRAM_WAVES];     // blocked mode: one 4x4 tile block per wave
+    // list mode (ragged / small p): an explicit, balanced tile list per wave, padded with dummies;
+    // code = dummy<<8 | selA<<7 | tiA<<4 | selB<<3 | tjB   (ti, tj local 0..7)
+    unsigned short list[GRAM_WAVES][LIST_CAP];
+    int lnt[GRAM_WAVES];          // real tiles per wave
 };
 
 template <typename T>
@@ -71,7 +76,7 @@ struct GramArgs {
     int nitems;
     int nslab;
     int xcd_map;         // 1: XCD-aware block->(item,slab) mapping (needs nslab % 8 == 0)
-    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0, 2 = no XCD map, 4 = no LDS-DMA
+    int dbg;             // DLSA_GRAM_DBG (profiling experiments only): 1 = no global loads after chunk 0, 2 = no XCD map, 4 = no LDS-DMA, 16 = no barrier (timing only), 32 = never use the list plan
 };
 
 template <typename T> struct Mfma;
@@ -120,10 +125,16 @@ __device__ __forceinline__ typename Vec2<T>::type load_pair(const T* __restrict_
 // MODE 2 (fp64): direct global->LDS DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass,
 // addresses are SGPR offsets, rows past the slab end read as zeros through the buffer descriptor.
 // (A fifth "loader" wave issuing all the DMA was tried and measured slower: 109 vs 101.7 ms.)
-template <typename T, bool HASW, int MODE>
+// NT == 0: blocked mode (one 4x4 tile block per wave, 8 fragment reads per 16 MFMAs -- the fast path for
+// p that fills the blocks).  NT > 0: list mode -- every wave walks its own list of NT tiles with one fragment
+// pair per MFMA (~20 % slower per tile, bench/ubench_gram_inner.hip mode 5) but no wasted tile slot and
+// perfectly balanced waves: the better plan for small or ragged p (p=100: 7 tiles per wave instead of 16 slots).
+template <typename T, bool HASW, int MODE, int NT>
 __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramArgs<T> a) {
     constexpr bool VEC = MODE >= 1;
     constexpr bool DMA = MODE == 2;
+    constexpr bool LIST = NT > 0;
+    constexpr int NTL = LIST ? NT : 1;
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Vec2<T>::type vec2_t;
     constexpr int PASSES = KC / GRAM_WAVES;              // staging passes per panel
@@ -152,8 +163,17 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
     const int panA = it->panA, panB = it->panB;
     const int npanels = (panA == panB) ? 1 : 2;
     const WaveBlock wb = it->wb[wave];
-    const bool active = wb.mask != 0;                    // wave-uniform
+    const bool active = LIST ? (it->lnt[wave] > 0) : (wb.mask != 0);   // wave-uniform
     const bool tri = wb.tri != 0;                        // wave-uniform
+    int loffA[NTL], loffB[NTL];
+    if constexpr (LIST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int code = it->list[wave][t];
+            loffA[t] = ((code >> 7) & 1) * (KC * LDP) + ((code >> 4) & 7) * TILE;
+            loffB[t] = ((code >> 3) & 1) * (KC * LDP) + (code & 7) * TILE;
+        }
+    }
 
     // LDS element offsets of the block's A and B fragment origins (wave-uniform)
     int offA[MR], offB[NR];
@@ -172,6 +192,9 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    acc_t accl[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) accl[t] = acc_t{0, 0, 0, 0};
 
     vec2_t st[2][PASSES];
 #pragma unroll
@@ -283,25 +306,37 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
                 const T* kb = base + ks * 4 * LDP + lane_off;
-                T av[MR], bv[NR];
+                if constexpr (LIST) {
+                    T wv = T(1);
+                    if (HASW) wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
 #pragma unroll
-                for (int i = 0; i < MR; ++i) av[i] = kb[offA[i]];
+                    for (int t = 0; t < NT; ++t) {
+                        const T av = kb[loffA[t]];
+                        T bv = kb[loffB[t]];
+                        if (HASW) bv *= wv;
+                        accl[t] = Mfma<T>::run(av, bv, accl[t]);
+                    }
+                } else {
+                    T av[MR], bv[NR];
 #pragma unroll
-                for (int j = 0; j < NR; ++j) bv[j] = kb[offB[j]];
-                if (HASW) {
-                    const T wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
+                    for (int i = 0; i < MR; ++i) av[i] = kb[offA[i]];
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) bv[j] *= wv;
-                }
+                    for (int j = 0; j < NR; ++j) bv[j] = kb[offB[j]];
+                    if (HASW) {
+                        const T wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
 #pragma unroll
-                for (int i = 0; i < MR; ++i)
+                        for (int j = 0; j < NR; ++j) bv[j] *= wv;
+                    }
 #pragma unroll
-                    for (int j = i; j < NR; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
-                if (!tri) {     // wave-uniform: a diagonal block skips its 6 below-diagonal tiles
+                    for (int i = 0; i < MR; ++i)
 #pragma unroll
-                    for (int i = 1; i < MR; ++i)
+                        for (int j = i; j < NR; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                    if (!tri) {     // wave-uniform: a diagonal block skips its 6 below-diagonal tiles
 #pragma unroll
-                        for (int j = 0; j < i; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                        for (int i = 1; i < MR; ++i)
+#pragma unroll
+                            for (int j = 0; j < i; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
+                    }
                 }
             }
         }
@@ -315,16 +350,30 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
 
     // epilogue: stored tiles -> this slab's partial buffer
     T* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
+    if constexpr (LIST) {
 #pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        const int r0 = ((((wb.a[i] >> 3) & 1) ? panB : panA) * 8 + (wb.a[i] & 7)) * TILE;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            if ((wb.mask >> (i * NR + j)) & 1) {
-                const int c0 = ((((wb.b[j] >> 3) & 1) ? panB : panA) * 8 + (wb.b[j] & 7)) * TILE;
+        for (int t = 0; t < NT; ++t) {
+            const int code = it->list[wave][t];
+            if (!((code >> 8) & 1)) {
+                const int r0 = ((((code >> 7) & 1) ? panB : panA) * 8 + ((code >> 4) & 7)) * TILE;
+                const int c0 = ((((code >> 3) & 1) ? panB : panA) * 8 + (code & 7)) * TILE;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = acc[i][j][r];
+                    P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = accl[t][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int r0 = ((((wb.a[i] >> 3) & 1) ? panB : panA) * 8 + (wb.a[i] & 7)) * TILE;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if ((wb.mask >> (i * NR + j)) & 1) {
+                    const int c0 = ((((wb.b[j] >> 3) & 1) ? panB : panA) * 8 + (wb.b[j] & 7)) * TILE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = acc[i][j][r];
+                }
             }
         }
     }
@@ -358,8 +407,11 @@ __global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int
 // Host side: wave blocks -> workgroup items, cached per p on the device.
 // ---------------------------------------------------------------------------------------
 struct GramPlan {
-    int p = 0, ntile = 0, npan = 0, PP = 0, nitems = 0;
+    int p = 0, ntile = 0, npan = 0, PP = 0;
+    int nitems = 0;               // blocked plan
     GramItem* d_items = nullptr;
+    int nt_list = 0, nitems_list = 0;   // list plan (nt_list == 0: not worth it for this p)
+    GramItem* d_items_list = nullptr;
 };
 
 // A wave block in global tile coordinates: tile rows ra[0..3], tile cols cb[0..3] (-1 = unused)
@@ -440,6 +492,103 @@ static void build_items(int p, std::vector<GramItem>& items) {
     }
 }
 
+// List-mode plan: every tile on/above the diagonal goes to exactly one (item, wave) list; items are panel
+// pairs (split into sub-items when a pair holds more than 4*LIST_CAP tiles); lists are padded with dummy
+// tiles up to nt_max.  Returns false if no split up to 64 sub-items fits.
+static bool build_list_items(int p, std::vector<GramItem>& items, int& nt_max) {
+    const int ntile = (p + TILE - 1) / TILE;
+    const int npan = (p + PANEL - 1) / PANEL;
+    struct Tile { int ti, tj; };
+    auto pan_of = [](int t) { return t / 8; };
+    std::vector<std::pair<int, int>> pairs;
+    if (npan == 1) pairs.push_back({0, 0});
+    else for (int x = 0; x < npan; ++x) for (int y = x + 1; y < npan; ++y) pairs.push_back({x, y});
+    for (int sub = 1; sub <= 64; ++sub) {
+        std::vector<std::vector<Tile>> lists(pairs.size() * sub);
+        std::vector<std::pair<int, int>> item_pair;
+        for (auto& pr : pairs) for (int s2 = 0; s2 < sub; ++s2) item_pair.push_back(pr);
+        std::vector<int> rr(pairs.size(), 0);
+        for (int ti = 0; ti < ntile; ++ti)
+            for (int tj = ti; tj < ntile; ++tj) {
+                if (pan_of(ti) == pan_of(tj)) continue;
+                size_t k = 0;
+                for (; k < pairs.size(); ++k) if (pairs[k].first == pan_of(ti) && pairs[k].second == pan_of(tj)) break;
+                lists[k * sub + (rr[k]++ % sub)].push_back({ti, tj});
+            }
+        // tiles inside one panel: round-robin over the panels, each to the least loaded item staging that panel
+        std::vector<std::vector<Tile>> diag(npan);
+        for (int ti = 0; ti < ntile; ++ti)
+            for (int tj = ti; tj < ntile; ++tj)
+                if (pan_of(ti) == pan_of(tj)) diag[pan_of(ti)].push_back({ti, tj});
+        bool any = true;
+        for (size_t turn = 0; any; ++turn) {
+            any = false;
+            for (int pn = 0; pn < npan; ++pn) {
+                if (turn >= diag[pn].size()) continue;
+                any = true;
+                int best = -1;
+                for (size_t k = 0; k < lists.size(); ++k) {
+                    if (item_pair[k].first != pn && item_pair[k].second != pn) continue;
+                    if (best < 0 || lists[k].size() < lists[best].size()) best = (int)k;
+                }
+                lists[best].push_back(diag[pn][turn]);
+            }
+        }
+        bool ok = true;
+        nt_max = 0;
+        items.clear();
+        for (size_t k = 0; k < lists.size() && ok; ++k) {
+            if (lists[k].empty()) continue;
+            GramItem g{};
+            g.panA = item_pair[k].first;
+            g.panB = item_pair[k].second;
+            std::sort(lists[k].begin(), lists[k].end(), [](const Tile& x, const Tile& y) {
+                return x.ti != y.ti ? x.ti < y.ti : x.tj < y.tj; });
+            const int cnt = (int)lists[k].size();
+            int pos = 0;
+            for (int wv = 0; wv < GRAM_WAVES; ++wv) {
+                const int take = cnt / GRAM_WAVES + (wv < cnt % GRAM_WAVES ? 1 : 0);
+                if (take > LIST_CAP) { ok = false; break; }
+                for (int n = 0; n < take; ++n, ++pos) {
+                    const Tile& t = lists[k][pos];
+                    const int selA = (pan_of(t.ti) == g.panA) ? 0 : 1, selB = (pan_of(t.tj) == g.panA) ? 0 : 1;
+                    g.list[wv][n] = (unsigned short)((selA << 7) | ((t.ti & 7) << 4) | (selB << 3) | (t.tj & 7));
+                }
+                g.lnt[wv] = take;
+                nt_max = std::max(nt_max, take);
+            }
+            if (ok) {
+                for (int wv = 0; wv < GRAM_WAVES; ++wv)
+                    for (int n = g.lnt[wv]; n < LIST_CAP; ++n) g.list[wv][n] = (unsigned short)(0x100 | (g.list[0][0] & 0xFF));
+                items.push_back(g);
+            }
+        }
+        if (ok) return true;
+    }
+    return false;
+}
+
+// Decide between the blocked and the list plan from the measured per-tile-step costs
+// (bench/ubench_gram_inner.hip: ~68 cycles with 4x4 blocking, ~86 with one fragment pair per MFMA).
+// nt_list = 0 selects the blocked plan; otherwise the list template size (4, 8 or 12).
+static void build_plan_items(int p, std::vector<GramItem>& blocked, std::vector<GramItem>& listed, int& nt_list) {
+    build_items(p, blocked);
+    int nt_max = 0;
+    nt_list = 0;
+    double cost_blocked = 0.0;
+    for (auto& g : blocked) {
+        int worst = 0;
+        for (int wv = 0; wv < GRAM_WAVES; ++wv) if (g.wb[wv].mask) worst = std::max(worst, g.wb[wv].tri ? 10 : MR * NR);
+        cost_blocked += worst * 68.0;
+    }
+    if (build_list_items(p, listed, nt_max)) {
+        const int nt = nt_max <= 4 ? 4 : (nt_max <= 8 ? 8 : 12);
+        const double cost_list = (double)listed.size() * nt * 86.0;
+        if (cost_list < 0.9 * cost_blocked) nt_list = nt;
+    }
+    if (!nt_list) listed.clear();
+}
+
 static std::mutex g_plan_mu;
 static std::map<std::pair<int, int>, GramPlan> g_plans;   // (device, p)
 
@@ -455,12 +604,17 @@ static int get_plan(int p, GramPlan& out) {
     pl.ntile = (p + TILE - 1) / TILE;
     pl.npan = (p + PANEL - 1) / PANEL;
     pl.PP = pl.ntile * TILE;
-    std::vector<GramItem> items;
-    build_items(p, items);
+    std::vector<GramItem> items, listed;
+    build_plan_items(p, items, listed, pl.nt_list);
     pl.nitems = (int)items.size();
-    // the item table is a few KB of immutable metadata, created once per (device, p)
+    pl.nitems_list = (int)listed.size();
+    // the item tables are a few KB of immutable metadata, created once per (device, p)
     DLSA_HIP_CHECK(hipMalloc((void**)&pl.d_items, items.size() * sizeof(GramItem)));
     DLSA_HIP_CHECK(hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(GramItem), hipMemcpyHostToDevice));
+    if (pl.nt_list) {
+        DLSA_HIP_CHECK(hipMalloc((void**)&pl.d_items_list, listed.size() * sizeof(GramItem)));
+        DLSA_HIP_CHECK(hipMemcpy(pl.d_items_list, listed.data(), listed.size() * sizeof(GramItem), hipMemcpyHostToDevice));
+    }
     g_plans[key] = pl;
     out = pl;
     return DLSA_OK;
@@ -488,12 +642,14 @@ static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_sl
 
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
-    std::vector<GramItem> items;
-    build_items(p, items);                // host-only, cheap: the exact item count
-    int nslab; int64_t rps;
+    std::vector<GramItem> items, listed;
+    int nt_list = 0;
+    build_plan_items(p, items, listed, nt_list);      // host-only, cheap: the exact item counts
+    int nslab, nslab2 = 0; int64_t rps;
     choose_slabs(n, (int)items.size(), nslab, rps);
+    if (nt_list) choose_slabs(n, (int)listed.size(), nslab2, rps);
     const size_t PP = (size_t)ntile * TILE;
-    return align_up((size_t)nslab * PP * PP * elem_bytes, 256);
+    return align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
 }
 
 template <typename T>
@@ -505,26 +661,37 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     GramPlan pl;
     int rc = get_plan(p, pl);
     if (rc) return rc;
+    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
+    int dbg = 0;
+    { const char* e = getenv("DLSA_GRAM_DBG"); dbg = e ? atoi(e) : 0; }
+    int mode = vec ? 1 : 0;
+    const bool use_list = pl.nt_list != 0 && vec && !(dbg & 32);      // list plan needs the aligned staging paths
+    const int nitems = use_list ? pl.nitems_list : pl.nitems;
+    const int nt_list = use_list ? pl.nt_list : 0;
     int nslab; int64_t rps;
-    choose_slabs(n, pl.nitems, nslab, rps);
+    choose_slabs(n, nitems, nslab, rps);
     const size_t need = (size_t)nslab * pl.PP * pl.PP * sizeof(T);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
     GramArgs<T> a;
-    a.X = X; a.w = w; a.partial = (T*)ws; a.items = pl.d_items; a.ldx = ldx; a.n = n;
-    a.rows_per_slab = rps; a.p = p; a.PP = pl.PP; a.nitems = pl.nitems; a.nslab = nslab;
+    a.X = X; a.w = w; a.partial = (T*)ws; a.items = use_list ? pl.d_items_list : pl.d_items; a.ldx = ldx; a.n = n;
+    a.rows_per_slab = rps; a.p = p; a.PP = pl.PP; a.nitems = nitems; a.nslab = nslab;
     a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
-    { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; if (a.dbg & 2) a.xcd_map = 0; }
-    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
-    int mode = vec ? 1 : 0;
+    a.dbg = dbg;
+    if (a.dbg & 2) a.xcd_map = 0;
     if (sizeof(T) == 8 && vec && (p % 2 == 0) && (!w || ((uintptr_t)w % 16) == 0) &&
         (double)rps * (double)ldx * sizeof(T) < 2.0e9)
         mode = 2;                                        // direct global->LDS DMA
     if (a.dbg & 4) mode = vec ? 1 : 0;
-    const int blocks = pl.nitems * nslab;
-#define DLSA_LAUNCH_GRAM(HW, MD) hipLaunchKernelGGL((gram_kernel<T, HW, MD>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a)
+    const int blocks = nitems * nslab;
+#define DLSA_LAUNCH_GRAM_NT(HW, MD, NTV) hipLaunchKernelGGL((gram_kernel<T, HW, MD, NTV>), dim3(blocks), dim3(GRAM_THREADS), 0, stream, a)
+#define DLSA_LAUNCH_GRAM(HW, MD) do { \
+        if (MD == 0 || nt_list == 0) DLSA_LAUNCH_GRAM_NT(HW, MD, 0); \
+        else if (nt_list == 4) DLSA_LAUNCH_GRAM_NT(HW, (MD == 0 ? 1 : MD), 4); \
+        else if (nt_list == 8) DLSA_LAUNCH_GRAM_NT(HW, (MD == 0 ? 1 : MD), 8); \
+        else DLSA_LAUNCH_GRAM_NT(HW, (MD == 0 ? 1 : MD), 12); } while (0)
     if (w) {
         if (mode == 2) { if constexpr (sizeof(T) == 8) DLSA_LAUNCH_GRAM(true, 2); }
         else if (mode == 1) DLSA_LAUNCH_GRAM(true, 1);
@@ -535,6 +702,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
         else DLSA_LAUNCH_GRAM(false, 0);
     }
 #undef DLSA_LAUNCH_GRAM
+#undef DLSA_LAUNCH_GRAM_NT
     DLSA_HIP_CHECK(hipGetLastError());
     dim3 rg((p + 127) / 128, p);
     hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, (const T*)ws, nslab, pl.PP, p, H, ldh, accumulate);
@@ -556,8 +724,9 @@ int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
 // by a wave whose workgroup stages both of its panels.  Used by the CPU test-suite.
 // Outputs: number of workgroup items, tile slots computed (incl. waste), tiles stored.
 int gram_plan_check(int p, int* nitems, int* nslots, int* ntiles) {
-    std::vector<GramItem> items;
-    build_items(p, items);
+    std::vector<GramItem> items, listed;
+    int nt_list = 0;
+    build_plan_items(p, items, listed, nt_list);
     const int ntile = (p + TILE - 1) / TILE;
     std::vector<int> seen((size_t)ntile * ntile, 0);
     int count = 0, slots = 0;
@@ -578,7 +747,31 @@ int gram_plan_check(int p, int* nitems, int* nslots, int* ntiles) {
         }
     }
     if (count != ntile * (ntile + 1) / 2) return -3;
-    if (nitems) *nitems = (int)items.size();
+    if (nt_list) {      // the list plan must cover the same tiles exactly once as well
+        std::fill(seen.begin(), seen.end(), 0);
+        int lcount = 0;
+        for (auto& g : listed) {
+            if (g.panA > g.panB) return -15;
+            for (int wv = 0; wv < GRAM_WAVES; ++wv) {
+                if (g.lnt[wv] > nt_list) return -14;
+                for (int t = 0; t < LIST_CAP; ++t) {
+                    const int code = g.list[wv][t];
+                    if (t >= g.lnt[wv]) { if (!((code >> 8) & 1)) return -16; continue; }
+                    if ((code >> 8) & 1) return -17;
+                    const int ti = (((code >> 7) & 1) ? g.panB : g.panA) * 8 + ((code >> 4) & 7);
+                    const int tj = (((code >> 3) & 1) ? g.panB : g.panA) * 8 + (code & 7);
+                    if (ti > tj || tj >= ntile) return -11;
+                    if (seen[(size_t)ti * ntile + tj]++) return -12;
+                    ++lcount;
+                }
+            }
+        }
+        if (lcount != ntile * (ntile + 1) / 2) return -13;
+        slots = (int)listed.size() * GRAM_WAVES * nt_list;     // the plan that will run
+        if (nitems) *nitems = -(int)listed.size();              // negative = list plan selected
+    } else if (nitems) {
+        *nitems = (int)items.size();
+    }
     if (nslots) *nslots = slots;
     if (ntiles) *ntiles = count;
     return 0;

@@ -48,7 +48,7 @@ def test_gram_tile_plan_covers_upper_triangle_once(lib, p):
     nt = (p + 15) // 16
     assert tiles.value == nt * (nt + 1) // 2           # every tile on/above the diagonal, once
     assert slots.value >= tiles.value                  # computed tile slots (diagonal blocks: 10 of 16)
-    assert items.value * 4 * 16 >= slots.value         # 4 waves x (4x4 tiles) per workgroup
+    assert abs(items.value) * 4 * 16 >= slots.value    # 4 waves x 16 tile slots per workgroup (items < 0: list plan)
 
 
 def test_metric_config_plan_is_perfectly_balanced(lib):
