@@ -640,6 +640,13 @@ static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_sl
     nslab = (int)ns;
 }
 
+// gram_wide.hip: the 256-column-panel fp32 kernel for wide p
+bool gram_wide_f32_shape_ok(int64_t n, int p);
+bool gram_wide_f32_eligible(const float* X, int64_t ldx, const float* w, int64_t n, int p);
+size_t gram_wide_f32_ws_bytes(int64_t n, int p);
+int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H, int64_t ldh,
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
     std::vector<GramItem> items, listed;
@@ -649,7 +656,9 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     choose_slabs(n, (int)items.size(), nslab, rps);
     if (nt_list) choose_slabs(n, (int)listed.size(), nslab2, rps);
     const size_t PP = (size_t)ntile * TILE;
-    return align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
+    size_t bytes = align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
+    if (elem_bytes == 4 && gram_wide_f32_shape_ok(n, p)) bytes = std::max(bytes, gram_wide_f32_ws_bytes(n, p));
+    return bytes;
 }
 
 template <typename T>
@@ -658,6 +667,10 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     DLSA_REQUIRE(X && H, "gram: null X or H");
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p && ldh >= p, "gram: bad shape n=%lld p=%d ldx=%lld ldh=%lld",
                  (long long)n, p, (long long)ldx, (long long)ldh);
+    if constexpr (sizeof(T) == 4) {
+        if (gram_wide_f32_eligible(X, ldx, w, n, p))
+            return gram_wide_f32(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
+    }
     GramPlan pl;
     int rc = get_plan(p, pl);
     if (rc) return rc;

@@ -140,6 +140,9 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
 /* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
  * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */
 int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles);
+/* same for the 256-column-panel plan of the wide-p fp32 kernel (used by dlsa_gram_f32 when p >= 768,
+ * p % 4 == 0, 16-byte aligned rows). */
+int dlsa_gram_wide_plan_check(int p, int* nitems, int* nslots, int* ntiles);
 
 #ifdef __cplusplus
 }

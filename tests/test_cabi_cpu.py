@@ -58,6 +58,23 @@ def test_metric_config_plan_is_perfectly_balanced(lib):
     assert (items.value, slots.value, tiles.value) == (9, 528, 528)     # no wasted tile slot at p=500
 
 
+@pytest.mark.parametrize("p", [768, 772, 1000, 1024, 1028, 1500, 2000, 2048, 2052, 4096])
+def test_wide_f32_gram_plan_covers_upper_triangle_once(lib, p):
+    items, slots, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_wide_plan_check(p, items, slots, tiles) == 0
+    nt = (p + 15) // 16
+    assert tiles.value == nt * (nt + 1) // 2
+    assert items.value * 8 * 32 >= slots.value >= tiles.value      # 8 waves x (4 x 8) tiles per workgroup
+
+
+def test_wide_f32_plan_for_config5(lib):
+    items, slots, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dlsa_gram_wide_plan_check(2000, items, slots, tiles) == 0
+    # 8 panels of 256 columns: 28 off-diagonal pairs + 6 workgroups of diagonal blocks
+    assert items.value == 34 and tiles.value == 125 * 126 // 2
+    assert tiles.value / slots.value > 0.9
+
+
 def test_engine_refuses_cpu_tensors():
     import torch
     from dlsa_amd import engine

@@ -159,6 +159,29 @@ def test_gram_f32(eng):
         assert rel_inf(H, Ho) < 2e-5          # fp32 accumulate over n rows
 
 
+@pytest.mark.parametrize("n,p,hasw", [(16384, 768, True), (20011, 1000, False), (33000, 2000, True),
+                                      (16400, 2052, True), (70001, 1028, True)])
+def test_gram_f32_wide_panels(eng, n, p, hasw):
+    """dlsa_gram_f32 takes the 256-column-panel kernel (gram_wide.hip) for p >= 768: ragged last chunk,
+    ragged last panel, with and without weights; must agree with the 128-column kernel as well."""
+    import os
+    rng = np.random.default_rng(p + n)
+    X = (rng.random((n, p), dtype=np.float32) - 0.5)
+    w = (rng.random(n, dtype=np.float32) * 0.25) if hasw else None
+    Xd, wd = dev(X), (dev(w) if hasw else None)
+    H = eng.gram(Xd, wd).cpu().numpy()
+    X64 = X.astype(np.float64)
+    Ho = X64.T @ ((w.astype(np.float64)[:, None] if hasw else 1.0) * X64)
+    assert rel_inf(H, Ho) < 2e-5
+    assert np.array_equal(H, H.T)
+    os.environ["DLSA_GRAM_NOWIDE"] = "1"
+    try:
+        H2 = eng.gram(Xd, wd).cpu().numpy()
+    finally:
+        del os.environ["DLSA_GRAM_NOWIDE"]
+    assert rel_inf(H2, Ho) < 2e-5
+
+
 LOGIT_CASES = [(1, 1), (13, 3), (1000, 5), (4099, 100), (5000, 128), (3000, 129), (2048, 250),
                (3001, 500), (1500, 513), (700, 1000), (300, 2000)]
 
