@@ -40,6 +40,10 @@ SIGNATURES = {
     "dlsa_lars_workspace_bytes": (c_sz, [c_int]),
     "dlsa_lars_lsa_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_int,
                                   c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp, c_sz, c_vp]),
+    "dlsa_design_f64": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                c_vp, c_i64, c_vp, c_vp]),
+    "dlsa_design_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                c_vp, c_i64, c_vp, c_vp]),
     "dlsa_gram_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dlsa_gram_wide_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
 }

@@ -1,0 +1,126 @@
+"""Design-matrix construction on the GPU.
+
+The reference builds each chunk's design matrix with pandas inside `logistic_model`
+(dlsa/models.py:56-104): fold the dropped levels of every factor into "000_OTHERS", one-hot encode
+(`pd.get_dummies`), drop the baseline dummies, standardise the numeric columns with the global
+mean / std (`data_info`, rows 1 and 2 of Spark's describe()), `reindex` to the canonical column
+order (sorted numeric names, then each factor's sorted dummy names), and -- for the Hessian -- prepend
+a ones column (:121-122).  Here the host only turns the categorical strings into integer level codes;
+the n x p matrix itself is written by `dlsa_design_f64` on the device, so what crosses PCIe is
+n x (q numeric + f codes) instead of n x p, and a shard whose codes are already in HBM never touches
+the host at all.
+"""
+import numpy as np
+import pandas as pd
+import torch
+
+from . import engine
+
+OTHERS = "000_OTHERS"      # models.py:60
+
+
+class DesignSpec:
+    """Column plan of the design matrix.  `names` are the output columns in the reference's order
+    (`["intercept"] +` usecols_x of models.py:70-77); numeric_cols / factors say where each comes from."""
+
+    def __init__(self, numeric_cols, factors, levels, names, kind, src, level, shift, scale, dummy_cols):
+        self.numeric_cols = list(numeric_cols)      # sorted raw numeric column names (usecols_x0, models.py:70)
+        self.factors = list(factors)                # categorical columns in dummy_info["factor_selected"] order
+        self.levels = levels                        # factor -> list of level strings; code = position
+        self.names = list(names)
+        self.kind, self.src, self.level = kind, src, level
+        self.shift, self.scale = shift, scale
+        self.dummy_cols = list(dummy_cols)          # output positions of the dummy columns
+        self._dev = {}
+
+    @property
+    def p(self):
+        return len(self.names)
+
+    @classmethod
+    def from_reference(cls, columns, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[],
+                       data_info=[]):
+        """Same arguments as logistic_model (models.py:42); `columns` = the chunk frame's columns."""
+        columns = [c for c in columns if c not in ("partition_id", Y_name)]
+        factors = list(dummy_info["factor_selected"].keys()) if len(dummy_info) > 0 else []
+        if len(dummy_info) > 0:
+            numeric_cols = sorted(set(columns) - set(factors))                       # models.py:70
+            out_numeric = list(numeric_cols)
+        else:
+            numeric_cols = list(columns)                                             # models.py:93-95 (frame order)
+            out_numeric = [c for c in numeric_cols if c not in dummy_factors_baseline]
+        levels = {}
+        for fct in factors:
+            lv = [str(x) for x in dummy_info["factor_selected"][fct]]
+            if len(dummy_info["factor_dropped"][fct]) > 0:
+                lv = [OTHERS] + lv
+            levels[fct] = lv
+        names, kind, src, level, shift, scale, dummy_cols = [], [], [], [], [], [], []
+
+        def push(name, k, s, l, sh=0.0, sc=1.0):
+            names.append(name); kind.append(k); src.append(s); level.append(l); shift.append(sh); scale.append(sc)
+
+        if fit_intercept:
+            push("intercept", 0, 0, 0)
+        for c in out_numeric:
+            if len(data_info) > 0:                                                   # models.py:99-101
+                push(c, 1, numeric_cols.index(c), 0, float(data_info[c][1]), float(data_info[c][2]))
+            else:
+                push(c, 1, numeric_cols.index(c), 0)
+        for fi, fct in enumerate(factors):
+            for nm in sorted(dummy_info["factor_selected_names"][fct]):              # models.py:73-75
+                if nm in dummy_factors_baseline:
+                    continue
+                lv = nm[len(fct) + 1:]
+                if lv not in levels[fct]:
+                    raise ValueError("dummy column %r has no level in factor %r" % (nm, fct))
+                dummy_cols.append(len(names))
+                push(nm, 2, fi, levels[fct].index(lv))
+        return cls(numeric_cols, factors, levels, names,
+                   np.asarray(kind, np.int32), np.asarray(src, np.int32), np.asarray(level, np.int32),
+                   np.asarray(shift, np.float64), np.asarray(scale, np.float64), dummy_cols)
+
+    def encode(self, sample_df, dummy_info=[]):
+        """Host step: numeric columns as one fp64 array, categorical columns as int32 level codes
+        (dropped levels fold into the OTHERS code, models.py:60; a level that is neither selected nor
+        dropped gets -1 and `unknown` is set -- get_dummies would have produced an unexpected column)."""
+        n = len(sample_df)
+        num = np.ascontiguousarray(sample_df[self.numeric_cols].to_numpy(dtype=np.float64)) if self.numeric_cols \
+            else np.zeros((n, 0))
+        codes = np.zeros((n, len(self.factors)), dtype=np.int32)
+        unknown = False
+        for fi, fct in enumerate(self.factors):
+            col = sample_df[fct].astype(str)
+            dropped = set(str(x) for x in dummy_info["factor_dropped"][fct]) if len(dummy_info) > 0 else set()
+            if dropped:
+                col = col.where(~col.isin(dropped), OTHERS)
+            c = pd.Categorical(col, categories=self.levels[fct]).codes.astype(np.int32)
+            unknown |= bool((c < 0).any())
+            codes[:, fi] = c
+        return num, codes, unknown
+
+    def device_arrays(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in
+                                   (self.kind, self.src, self.level, self.shift, self.scale))
+        return self._dev[key]
+
+    def build(self, num, codes, dtype=torch.float64, out=None):
+        """Device step: num [n,q] / codes [n,f] (device tensors, either may be None when q or f is 0)
+        -> (X [n,p], missing: names of dummy columns without any non-zero entry in this chunk)."""
+        dev = num.device if num is not None else codes.device
+        kind, src, level, shift, scale = self.device_arrays(dev)
+        if num is not None and num.shape[1] == 0:
+            num = None
+        if codes is not None and codes.shape[1] == 0:
+            codes = None
+        X, seen = engine.design(num, codes, kind, src, level, shift, scale, dtype=dtype, out=out)
+        seen = seen.cpu().numpy()
+        missing = [self.names[j] for j in self.dummy_cols if not seen[j]]
+        return X, missing
+
+
+def design_matrix(num, codes, spec, dtype=torch.float64):
+    """Tensor fast path: device-resident raw columns -> dense design matrix (see DesignSpec.build)."""
+    return spec.build(num, codes, dtype=dtype)

@@ -76,6 +76,31 @@ def synth(seed, row0, n, p, kind=SYNTH_UNIFORM, ones_col=False, labels=True, dty
     return X, y
 
 
+def design(num, codes, kind, src, level, shift, scale, dtype=torch.float64, out=None):
+    """Dense design matrix from raw numeric columns + integer level codes (models.py:56-104,121-122).
+    num [n,q] (dtype) or None, codes [n,f] int32 or None; kind/src/level int32 [p], shift/scale fp64 [p]
+    (device).  Returns (X [n,p], seen int32 [p]: 1 where the column has a non-zero entry)."""
+    lib = _lib.load()
+    _require_gpu(num, codes, kind, src, level, shift, scale, out)
+    p = kind.numel()
+    n = num.shape[0] if num is not None else codes.shape[0]
+    q = num.shape[1] if num is not None else 0
+    f = codes.shape[1] if codes is not None else 0
+    if num is not None and num.dtype != dtype:
+        raise ValueError("num must have the output dtype")
+    if codes is not None and codes.dtype != torch.int32:
+        raise ValueError("codes must be int32")
+    dev = kind.device
+    X = out if out is not None else torch.empty((n, p), dtype=dtype, device=dev)
+    seen = torch.empty((p,), dtype=torch.int32, device=dev)
+    fn = lib.dlsa_design_f64 if dtype == torch.float64 else lib.dlsa_design_f32
+    check(fn(_ptr(num), _rowmajor(num) if num is not None else 0, q,
+             _ptr(codes), _rowmajor(codes) if codes is not None else 0, f, n,
+             _ptr(kind), _ptr(src), _ptr(level), _ptr(shift), _ptr(scale), p, _ptr(X), _rowmajor(X), _ptr(seen),
+             _stream()))
+    return X, seen
+
+
 def gram(X, w=None, out=None, accumulate=False):
     """H = X' diag(w) X (dlsa/models.py:130) on the MFMA Gram kernel.  X [n,p] fp64/fp32."""
     lib = _lib.load()

@@ -17,6 +17,7 @@ import pandas as pd
 import torch
 
 from . import engine
+from .design import DesignSpec
 
 
 class MappedBlocks:
@@ -65,55 +66,25 @@ def simulate_logistic(sample_size, p, partition_method, partition_num, seed=2026
     return pd.DataFrame(data_np, columns=["partition_id"] + ["label"] + ["x" + str(x) for x in range(p)])
 
 
-def _design_frame(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info, for_eval=False):
-    """models.py:50-108 (and :159-206 for eval): column bookkeeping of the design matrix.
-    Returns (x_train DataFrame or None when the chunk must be skipped, usecols_full)."""
-    col_intercept_name = ["intercept"] if fit_intercept else []
-    if len(dummy_info) > 0:
-        convert_dummies = list(dummy_info["factor_selected"].keys())
-        # fold the dropped levels into one key (models.py:60)
-        sample_df = sample_df.replace({k: v for k, v in dummy_info["factor_dropped"].items() if len(v) > 0},
-                                      "000_OTHERS")
-        X_with_dummies = pd.get_dummies(data=sample_df, drop_first=False, columns=convert_dummies, dtype=float)
-        drop = ["partition_id", Y_name] + (list(dummy_factors_baseline) if not for_eval else list(dummy_factors_baseline))
-        x_train = X_with_dummies.drop([c for c in drop if c in X_with_dummies.columns], axis=1)
-        usecols_x0 = sorted(list(set(sample_df.columns.drop(["partition_id", Y_name])) - set(convert_dummies)))
-        usecols_x = usecols_x0.copy()
-        for i in convert_dummies:
-            for j in sorted(dummy_info["factor_selected_names"][i]):
-                usecols_x.append(j)
-        usecols_x = [i for i in usecols_x if i not in dummy_factors_baseline]
-        usecols_full = ["par_id", "coef", "Sig_invMcoef"] + col_intercept_name + usecols_x
-        if set(x_train.columns) != set(usecols_x):
-            missing = set(usecols_x) - set(x_train.columns)
-            if not for_eval:
-                warnings.warn("Dummies:" + str(missing) + "missing in this data chunk " + str(x_train.shape)
-                              + "Skip modeling this part of data.")
-                return None, usecols_full, usecols_x0
-            warnings.warn("Dummies:" + str(missing) + "missing in this data chunk " + str(x_train.shape))
-            for c in missing:                    # models.py:196-198: absent levels count as zeros
-                x_train[c] = 0.0
-    else:
-        drop = ["partition_id", Y_name] + ([] if for_eval else list(dummy_factors_baseline))
-        x_train = sample_df.drop(drop, axis=1)
-        usecols_x0 = list(x_train.columns)
-        usecols_x = usecols_x0
-        usecols_full = ["par_id", "coef", "Sig_invMcoef"] + col_intercept_name + list(usecols_x)
-    x_train = x_train.copy()
-    if len(data_info) > 0:                        # models.py:99-101: rows 1,2 of describe() = mean, stddev
-        for i in usecols_x0:
-            x_train[i] = (x_train[i] - float(data_info[i][1])) / float(data_info[i][2])
-    x_train = x_train.reindex(columns=usecols_x)  # models.py:104
-    return x_train, usecols_full, usecols_x0
-
-
-def _to_device_design(x_train, fit_intercept):
-    """Numeric frame -> row-major fp64 device matrix; the intercept is a leading ones column
-    (models.py:121-122)."""
-    xn = np.ascontiguousarray(x_train.to_numpy(dtype=np.float64))
-    if fit_intercept:
-        xn = np.concatenate([np.ones((xn.shape[0], 1)), xn], axis=1)
-    return torch.from_numpy(xn).cuda()
+def _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info, for_eval=False):
+    """models.py:50-108,121-122 (and :159-206 for eval): the chunk's design matrix, built ON THE DEVICE.
+    The host only does the column bookkeeping and turns categorical strings into level codes
+    (design.DesignSpec); get_dummies / baseline drop / standardise / reindex / ones column are one
+    dlsa_design_f64 launch.  Returns (X device tensor or None when the chunk must be skipped,
+    names = [intercept,] usecols_x)."""
+    spec = DesignSpec.from_reference(list(sample_df.columns), Y_name, fit_intercept, dummy_info,
+                                     ([] if (for_eval and len(dummy_info) == 0) else dummy_factors_baseline), data_info)
+    num, codes, unknown = spec.encode(sample_df, dummy_info)
+    dev = torch.device("cuda")
+    X, missing = spec.build(torch.from_numpy(num).to(dev), torch.from_numpy(codes).to(dev))
+    if missing or unknown:          # models.py:80-91 / :187-194
+        shape = (len(sample_df), len(spec.names) - (1 if fit_intercept else 0) - len(missing))
+        if not for_eval:
+            warnings.warn("Dummies:" + str(set(missing)) + "missing in this data chunk " + str(shape)
+                          + "Skip modeling this part of data.")
+            return None, spec.names
+        warnings.warn("Dummies:" + str(set(missing)) + "missing in this data chunk " + str(shape))
+    return X, spec.names
 
 
 def logistic_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[],
@@ -122,12 +93,9 @@ def logistic_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_
     UDF does (models.py:42-147).  Returns the p x (3+p) frame `par_id, coef, Sig_invMcoef,
     [intercept,] <features>`; a chunk that lacks an expected dummy level returns the all-zero
     block with a warning (models.py:84-91)."""
-    x_train, usecols_full, _ = _design_frame(sample_df, Y_name, fit_intercept, dummy_info,
-                                             dummy_factors_baseline, data_info)
-    if x_train is None:
-        return pd.DataFrame(0, index=np.arange(len(usecols_full) - 3), columns=usecols_full)
-    names = (["intercept"] if fit_intercept else []) + list(x_train.columns)
-    Xd = _to_device_design(x_train, fit_intercept)
+    Xd, names = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
+    if Xd is None:
+        return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
     yd = torch.from_numpy(np.ascontiguousarray(sample_df[Y_name].to_numpy(dtype=np.float64))).cuda()
     r = engine.irls_fit(Xd, yd, [0, Xd.shape[0]])
     st = r["status"][0]
@@ -177,9 +145,8 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
 def logistic_model_eval(sample_df, Y_name, par, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[],
                         data_info=[]):
     """Log-likelihood of every estimator column of `par` on one partition (models.py:151-225)."""
-    x_train, _, _ = _design_frame(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline,
-                                  data_info, for_eval=True)
-    Xd = _to_device_design(x_train, fit_intercept)
+    Xd, _ = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info,
+                           for_eval=True)
     yd = torch.from_numpy(np.ascontiguousarray(sample_df[Y_name].to_numpy(dtype=np.float64))).cuda()
     pard = torch.from_numpy(np.ascontiguousarray(np.asarray(par, dtype=np.float64))).cuda()
     ll = engine.loglik(Xd, yd, pard).cpu().numpy()
@@ -249,13 +216,11 @@ def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_inter
 def linear_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[], data_info=[]):
     """Frame-level sibling of logistic_model for a linear response: same arguments, same
     p x (3+p) output frame `par_id, coef, Sig_invMcoef, [intercept,] <features>`."""
-    x_train, usecols_full, _ = _design_frame(sample_df, Y_name, fit_intercept, dummy_info,
-                                             dummy_factors_baseline, data_info)
-    if x_train is None:
-        return pd.DataFrame(0, index=np.arange(len(usecols_full) - 3), columns=usecols_full)
-    Xd = torch.from_numpy(np.ascontiguousarray(x_train.to_numpy(dtype=np.float64))).cuda()
+    Xd, names = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
+    if Xd is None:
+        return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
     yd = torch.from_numpy(np.ascontiguousarray(sample_df[Y_name].to_numpy(dtype=np.float64))).cuda()
-    mb = fit_linear_partitions(Xd, yd, fit_intercept=fit_intercept, names=list(x_train.columns))
+    mb = fit_linear_partitions(Xd, yd, fit_intercept=False, names=names)      # the ones column is already in Xd
     out = mb.block_frame(0)
     if out.isna().values.any():
         warnings.warn("NAs appear in the final output")

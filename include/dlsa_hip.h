@@ -137,6 +137,25 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
                       double* beta_path, double* beta0, double* aic, double* bic,
                       int* n_steps_host, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- design matrix (N2) ----
+ * Replaces pd.get_dummies + drop(baselines) + standardise + reindex (dlsa/models.py:56-104) and the
+ * leading ones column (models.py:121-122) for one chunk whose categorical columns arrive as integer
+ * level codes.  Device inputs: num [n x q] raw numeric columns (row-major, ldn), codes [n x f] int32
+ * (row-major, ldc).  Output column j < p is described by device arrays kind/src/level/shift/scale:
+ *   kind 0: the constant 1;  kind 1: (num[:, src[j]] - shift[j]) / scale[j];
+ *   kind 2: 1.0 where codes[:, src[j]] == level[j], else 0.0.
+ * seen (device int32[p], nullable) is set to 1 for every column with a non-zero entry: a dummy column
+ * with seen == 0 is the reference's "level missing in this data chunk" case (models.py:80-91).
+ * p <= 2048. */
+int dlsa_design_f64(const double* num, int64_t ldn, int q, const int32_t* codes, int64_t ldc, int f,
+                    int64_t n, const int32_t* kind, const int32_t* src, const int32_t* level,
+                    const double* shift, const double* scale, int p, double* X, int64_t ldx,
+                    int32_t* seen, void* stream);
+int dlsa_design_f32(const float* num, int64_t ldn, int q, const int32_t* codes, int64_t ldc, int f,
+                    int64_t n, const int32_t* kind, const int32_t* src, const int32_t* level,
+                    const double* shift, const double* scale, int p, float* X, int64_t ldx,
+                    int32_t* seen, void* stream);
+
 /* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
  * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */
 int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles);

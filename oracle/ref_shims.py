@@ -54,6 +54,7 @@ def load_reference(tol=None):
     import dlsa.models as ref_models
     import dlsa.lsa as ref_lsa
     import dlsa.dlsa as ref_dlsa
+    import dlsa.dummies as ref_dummies
     from sklearn.linear_model import LogisticRegression as _LR
 
     class _ShimLR(_LR):
@@ -75,7 +76,7 @@ def load_reference(tol=None):
 
     ref_models.LogisticRegression = _ShimLR
     ref_models.pd = _PdProxy()
-    return types.SimpleNamespace(models=ref_models, lsa=ref_lsa, dlsa=ref_dlsa)
+    return types.SimpleNamespace(models=ref_models, lsa=ref_lsa, dlsa=ref_dlsa, dummies=ref_dummies)
 
 
 class FakeSparkDF:

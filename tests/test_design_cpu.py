@@ -1,0 +1,82 @@
+"""CPU: the design-matrix column plan (dlsa_amd.design.DesignSpec, host logic) and the oracle's
+design_matrix restatement, pinned to the reference's own dummy / standardise path (fixture F4)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import dlsa_oracle as orc
+from f4_fixture import load_f4
+
+TOL_MLE = 1e-10
+
+
+def rel_inf(a, b):
+    return np.max(np.abs(np.asarray(a, float) - np.asarray(b, float))) / max(1e-300, np.max(np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def f4():
+    return load_f4()
+
+
+def test_column_plan_matches_reference(f4):
+    from dlsa_amd.design import DesignSpec
+    z, df, dummy_info, baseline, data_info = f4
+    spec = DesignSpec.from_reference(list(df.columns), "label", True, dummy_info, baseline, data_info)
+    assert ["par_id", "coef", "Sig_invMcoef"] + spec.names == list(z["columns"])
+    assert spec.numeric_cols == ["dep", "dist"] and spec.factors == ["carrier", "dow"]
+    assert spec.levels["carrier"][0] == "000_OTHERS" and "ZZ" not in spec.levels["carrier"]
+    assert spec.kind.tolist() == [0, 1, 1, 2, 2, 2, 2, 2, 2]
+
+
+def test_encode_folds_dropped_levels_and_flags_unknown(f4):
+    from dlsa_amd.design import DesignSpec
+    z, df, dummy_info, baseline, data_info = f4
+    spec = DesignSpec.from_reference(list(df.columns), "label", True, dummy_info, baseline, data_info)
+    num, codes, unknown = spec.encode(df, dummy_info)
+    assert not unknown and num.shape == (len(df), 2) and codes.shape == (len(df), 2) and codes.dtype == np.int32
+    folded = df["carrier"].isin(["ZZ", "YY"]).to_numpy()
+    assert (codes[folded, 0] == 0).all() and (codes[~folded, 0] > 0).all()
+    df2 = df.copy()
+    df2.loc[3, "carrier"] = "QQ"                        # neither selected nor dropped
+    assert spec.encode(df2, dummy_info)[2]
+
+
+def test_oracle_design_and_fit_match_reference_dummy_path(f4):
+    """reference logistic_model on the dummy path == oracle design_matrix + oracle fit (exact-MLE tier)."""
+    from dlsa_amd.design import DesignSpec
+    z, df, dummy_info, baseline, data_info = f4
+    spec = DesignSpec.from_reference(list(df.columns), "label", True, dummy_info, baseline, data_info)
+    num, codes, _ = spec.encode(df, dummy_info)
+    X, seen = orc.design_matrix(num, codes, spec.kind, spec.src, spec.level, spec.shift, spec.scale)
+    assert seen.all()
+    # independent pandas construction of the same matrix
+    Xp = np.column_stack([np.ones(len(df)), (df["dep"] - z["data_info_mean"][1]) / z["data_info_std"][1],
+                          (df["dist"] - z["data_info_mean"][0]) / z["data_info_std"][0]]
+                         + [df["carrier"] == c for c in ("AA", "BB", "CC", "DD")] + [df["dow"] == d for d in ("2", "3")])
+    assert np.array_equal(X, Xp.astype(float))
+    coef, smc, sig = orc.logistic_model_block(X[:, 1:], df["label"].to_numpy(), True)
+    assert rel_inf(coef, z["coef_mle"]) < TOL_MLE
+    assert rel_inf(sig, z["Sig_inv_mle"]) < TOL_MLE and rel_inf(smc, z["Sig_invMcoef_mle"]) < TOL_MLE
+    assert rel_inf(coef, z["coef_shipped"]) < 2e-2          # the reference as shipped stops early
+    ll = orc.logistic_loglik(X, df["label"].to_numpy(), np.column_stack([coef, 0.5 * coef, 0 * coef]))
+    assert rel_inf(ll, z["eval_loglik"]) < TOL_MLE
+
+
+def test_missing_level_is_detected_by_seen_flags(f4):
+    from dlsa_amd.design import DesignSpec
+    z, df, dummy_info, baseline, data_info = f4
+    spec = DesignSpec.from_reference(list(df.columns), "label", True, dummy_info, baseline, data_info)
+    sub = df[df["carrier"] != "CC"].reset_index(drop=True)
+    num, codes, unknown = spec.encode(sub, dummy_info)
+    _, seen = orc.design_matrix(num, codes, spec.kind, spec.src, spec.level, spec.shift, spec.scale)
+    missing = [spec.names[j] for j in spec.dummy_cols if not seen[j]]
+    assert missing == ["carrier_CC"] and not unknown
+    assert list(z["zero_columns"]) == ["par_id", "coef", "Sig_invMcoef"] + spec.names and float(z["zero_absmax"]) == 0.0
+
+
+def test_plain_frame_plan_keeps_frame_order():
+    from dlsa_amd.design import DesignSpec
+    spec = DesignSpec.from_reference(["partition_id", "label", "x2", "x0", "x1"], "label", False)
+    assert spec.names == ["x2", "x0", "x1"] and spec.kind.tolist() == [1, 1, 1] and spec.src.tolist() == [0, 1, 2]
+    assert spec.shift.tolist() == [0, 0, 0] and spec.scale.tolist() == [1, 1, 1]
