@@ -22,7 +22,11 @@ def timed(fn, reps=3):
 
 
 def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
-    X, y = Xy if Xy is not None else engine.synth(20260101, 0, n, p, kind=kind)
+    extra = {}
+    if Xy is not None:
+        X, y, extra = Xy
+    else:
+        X, y = engine.synth(20260101, 0, n, p, kind=kind)
     p = X.shape[1]
     offs = [int(n * k / K) for k in range(K + 1)]
     beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[: int(0.4 * p)] = 1.0
@@ -37,7 +41,7 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
     t_all, (mb, out, sel) = timed(whole, reps=2)
     t_fit, _ = timed(lambda: engine.irls_fit(X, y, offs), reps=2)
     fl = p * (p + 1) + p
-    return {"config": name, "n": n, "p": p, "K": K, "dtype": "f64",
+    return {**extra, "config": name, "n": n, "p": p, "K": K, "dtype": "f64",
             "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
             "gram_GBps_alg": n * 8 * (p + 1) / t_gram / 1e9,
             "logit_ms": t_logit * 1e3, "logit_GBps": n * 8 * (p + 2) / t_logit / 1e9,
@@ -45,22 +49,36 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
 
 
 def airline_shaped(n, seed=7):
-    """Config 4 surrogate: 7 standardised Gaussian columns + 5 Zipf factors one-hot to p~250."""
+    """Config 4 surrogate: 7 numeric columns (standardised on the fly) + 5 Zipf factors whose
+    integer level codes are one-hot encoded ON THE DEVICE by dlsa_design_f64 (baseline level dropped,
+    intercept column first) -> p = 1 + 7 + 10+5+19+109+109 = 260."""
     g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    cols = [torch.randn((n, 7), dtype=torch.float64, device="cuda", generator=g)]
-    for levels in (11, 6, 20, 110, 110):
-        pr = 1.0 / torch.arange(1, levels + 1, dtype=torch.float64, device="cuda")
-        codes = torch.multinomial(pr / pr.sum(), n, replacement=True, generator=g)
-        oh = torch.zeros((n, levels - 1), dtype=torch.float64, device="cuda")      # baseline level dropped
-        m = codes > 0
-        oh[m.nonzero().flatten(), codes[m] - 1] = 1.0
-        cols.append(oh)
-    X = torch.cat([torch.ones((n, 1), dtype=torch.float64, device="cuda")] + cols, 1)
-    if X.shape[1] % 2:
-        X = torch.cat([X, torch.randn((n, 1), dtype=torch.float64, device="cuda", generator=g)], 1)
-    beta = torch.randn(X.shape[1], dtype=torch.float64, device="cuda", generator=g) * 0.15
-    y = (torch.rand(n, dtype=torch.float64, device="cuda", generator=g) < torch.sigmoid(X @ beta)).double()
-    return X.contiguous(), y
+    num = torch.randn((n, 7), dtype=torch.float64, device="cuda", generator=g) * 3.0 + 1.5
+    levels = (11, 6, 20, 110, 110)
+    codes = torch.empty((n, len(levels)), dtype=torch.int32, device="cuda")
+    for fi, L in enumerate(levels):
+        pr = 1.0 / torch.arange(1, L + 1, dtype=torch.float64, device="cuda")
+        codes[:, fi] = torch.multinomial(pr / pr.sum(), n, replacement=True, generator=g).int()
+    kind, src, level, shift, scale = [0], [0], [0], [0.0], [1.0]
+    for j in range(7):
+        kind.append(1); src.append(j); level.append(0); shift.append(1.5); scale.append(3.0)
+    for fi, L in enumerate(levels):
+        for lv in range(1, L):                    # level 0 = baseline
+            kind.append(2); src.append(fi); level.append(lv); shift.append(0.0); scale.append(1.0)
+    d = lambda a, t: torch.tensor(a, dtype=t, device="cuda")
+    spec = (d(kind, torch.int32), d(src, torch.int32), d(level, torch.int32), d(shift, torch.float64), d(scale, torch.float64))
+    Xbuf = torch.empty((n, len(kind)), dtype=torch.float64, device="cuda")
+    t_design, (X, seen) = timed(lambda: engine.design(num, codes, *spec, out=Xbuf))
+    assert int(seen.sum()) == len(kind)
+    p = X.shape[1]
+    beta = torch.randn(p, dtype=torch.float64, device="cuda", generator=g) * 0.15
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    for r in range(0, n, 1_000_000):
+        y[r:r + 1_000_000] = (torch.rand(min(1_000_000, n - r), dtype=torch.float64, device="cuda", generator=g)
+                              < torch.sigmoid(X[r:r + 1_000_000] @ beta)).double()
+    info = {"design_ms": t_design * 1e3, "design_write_GBps": n * p * 8 / t_design / 1e9,
+            "design_input_bytes_per_row": 7 * 8 + 5 * 4, "design_output_bytes_per_row": p * 8}
+    return X, y, info
 
 
 def linear_config(name, n, p, K):
@@ -118,7 +136,7 @@ def main():
         rows.append(logistic_config("C3 shard n=2.5e7 p=500 K=25 (1e6 rows per partition)", 25_000_000, 500, 25))
     if "C4" in sel:
         n4 = 14_000_000
-        rows.append(logistic_config("C4 shard airline-shaped synthetic n=1.4e7 (113.9M/8) p~250 K=14", n4, 0, 14, Xy=airline_shaped(n4)))
+        rows.append(logistic_config("C4 shard airline-shaped synthetic n=1.4e7 (113.9M/8) p=260 (7 numeric + 5 factors one-hot on device) K=14", n4, 0, 14, Xy=airline_shaped(n4)))
     torch.cuda.empty_cache()
     if "C5" in sel:
         rows.append(linear_config("C5 shard (capped) linear n=2.4e7 p=2000 fp32 K=8", 24_000_000, 2000, 8))
