@@ -7,8 +7,10 @@
 // lives in one XCD's L2 (measured: 18 % hit rate, 15x the algorithmic bytes, MFMA pipe 69 % busy).  Here
 //   * a PANEL is 256 columns; a WORKGROUP of 8 waves owns a 256x256 block of H for one slab of rows
 //     (64 flop per staged byte -> 2.5 TB/s at peak, HBM can feed it even without L2 hits);
-//   * a WAVE owns 4x8 tiles of 16x16 (128 accumulator VGPRs): per 4-row k-step 4 A + 8 B fragment reads
-//     and 4 v_mul (w scales the A side) for 32 MFMAs;
+//   * a WAVE owns 64 rows x 128 columns of H as 4x8 MFMA tiles (128 accumulator VGPRs).  The tiles are
+//     INTERLEAVED: lane m of tile e of a 64-column group holds column 4m+e, so one ds_read_b128 of the
+//     natural row layout feeds four MFMAs -- 3 LDS reads (+ w) and 4 v_mul per k-step of 32 MFMAs (with
+//     contiguous 16-column tiles it was 6 ds_read2_b32); the epilogue undoes the interleave with 16-byte stores;
 //   * staging is global->LDS DMA (buffer_load_dwordx4 ... lds, one 1 KiB panel row per wave instruction),
 //     three 16-row stages (105 KB LDS, one workgroup per CU): chunk c+2 is in flight while c is consumed,
 //     one barrier per chunk;
@@ -26,9 +28,16 @@ namespace dlsa {
 
 constexpr int WTILE = 16;
 constexpr int WPANEL = 256;            // columns per panel = 16 tiles
-constexpr int WKC = 16;                // rows per stage
+#ifndef DLSA_WIDE_KC
+#define DLSA_WIDE_KC 16
+#endif
+#ifndef DLSA_WIDE_STAGES
+#define DLSA_WIDE_STAGES 3
+#endif
+constexpr int WKC = DLSA_WIDE_KC;      // rows per stage
 constexpr int WLDP = 272;              // LDS row pitch in floats: 272 mod 64 == 16 -> conflict-free fragments
-constexpr int WSTAGES = 3;
+constexpr int WSTAGES = DLSA_WIDE_STAGES;
+constexpr int WAHEAD = WSTAGES - 1;    // chunks in flight ahead of the one being consumed
 constexpr int WWAVES = 8;
 constexpr int WTHREADS = 64 * WWAVES;
 constexpr int WMR = 4, WNR = 8;        // tiles per wave block
@@ -38,7 +47,8 @@ constexpr int WBUF_ELEMS = 2 * WPANEL_ELEMS + WKC;     // two panels + the w chu
 struct WideBlock {
     unsigned char selA, ta0;           // A tiles: panel select (0 = panA, 1 = panB), first local tile (0, 4, 8, 12)
     unsigned char selB, tb0;           // B tiles: panel select, first local tile (0 or 8)
-    unsigned int mask;                 // bit i*8+j: tile (ta0+i, tb0+j) is stored; 0 = idle wave
+    unsigned int mask;                 // bit i*8+j: the 16x16 cell (ta0+i, tb0+j) holds entries on/above the diagonal inside p;
+                                       // 0 = idle wave (the kernel computes and stores the whole 64 x 128 block otherwise)
 };
 struct WideItem {
     int panA, panB;
@@ -48,10 +58,11 @@ struct WideItem {
 struct WideArgs {
     const float* X;
     const float* w;
-    float* partial;                    // [nslab][PP][PP]
+    float* partial;                    // [nslab][PP][PP], PP = panels x 256
     const WideItem* items;
     int64_t ldx, n, rows_per_slab;
     int p, PP, nitems, nslab, xcd_map;
+    int dbg;                           // DLSA_GRAM_DBG (timing experiments only): 1 = no DMA after the prologue, 16 = no barrier
 };
 
 typedef float wacc_t __attribute__((ext_vector_type(4)));
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
     const bool active = wb.mask != 0;                                  // wave-uniform
     const int offA = wb.selA * WPANEL_ELEMS + wb.ta0 * WTILE;
     const int offB = wb.selB * WPANEL_ELEMS + wb.tb0 * WTILE;
-    const int lane_off = (lane >> 4) * WLDP + (lane & 15);
+    const int lane_off4 = (lane >> 4) * WLDP + (lane & 15) * 4;      // a lane reads 4 consecutive columns per fragment read
 
     const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
     const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
@@ -105,12 +116,14 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
     const bool inB = panB * WPANEL + lane * 4 + 3 < a.p;
     const int lane_boff = lane * 16;
 
-    // every wave issues exactly 4 row DMAs per chunk (2 rows x 2 panels; wave 0 a fifth for w)
+    // every wave issues exactly WKC/4 row DMAs per chunk (WKC/8 rows x 2 panels; wave 0 one more for w)
+    constexpr int RPW = WKC / WWAVES;                  // rows per wave per chunk
+    constexpr int LPC = 2 * RPW;                       // loads per wave per chunk
     auto stage_dma = [&](int chunk, int stage) {
         float* base = lds + stage * WBUF_ELEMS;
 #pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const int row = wave * 2 + r2;
+        for (int r2 = 0; r2 < RPW; ++r2) {
+            const int row = wave * RPW + r2;
             const int64_t rowoff = ((int64_t)chunk * WKC + row) * a.ldx;
             const int soffA = (int)((rowoff + panA * WPANEL) * (int64_t)sizeof(float));
             const int soffB = (int)((rowoff + panB * WPANEL) * (int64_t)sizeof(float));
@@ -124,59 +137,72 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + 2 * WPANEL_ELEMS), 16, lane * 16,
                                                      chunk * WKC * (int)sizeof(float), 0, 0);
     };
-    // wait until only the newest chunk's DMAs of this wave may still be in flight
+    // wait until only the WAHEAD-1 newest chunks' DMAs of this wave may still be in flight
     auto wait_prev = [&]() {
-        if (HASW && wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (HASW && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WAHEAD - 1) * (LPC + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WAHEAD - 1) * LPC) : "memory");
     };
 
     __syncthreads();                                   // zero fill done before the first DMA lands
-    if (nchunks > 0) stage_dma(0, 0);
-    if (nchunks > 1) stage_dma(1, 1);
+#pragma unroll
+    for (int c0 = 0; c0 < WAHEAD; ++c0)
+        if (c0 < nchunks) stage_dma(c0, c0);
 
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) wait_prev();              // chunk c landed (c+1 may be in flight)
+        if (c + WAHEAD - 1 < nchunks) wait_prev();     // chunk c landed (the newer ones may be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0, i.e. wait for chunk c+1 as well
-        asm volatile("s_barrier" ::: "memory");        // chunk c landed for every wave; stage (c+2)%3 == (c-1)%3 is free
-        if (c + 2 < nchunks) stage_dma(c + 2, (c + 2) % WSTAGES);
+        if (!(a.dbg & 16)) asm volatile("s_barrier" ::: "memory");   // chunk c landed for every wave; stage (c-1)%S is free again
+        if (c + WAHEAD < nchunks && !(a.dbg & 1)) stage_dma(c + WAHEAD, (c + WAHEAD) % WSTAGES);
         if (active) {
             const float* base = lds + (c % WSTAGES) * WBUF_ELEMS;
+            // fragments of k-step ks+1 are fetched while the 32 MFMAs of k-step ks issue (register double buffer)
+            wacc_t a4[2], b4[2][2];
+            float wv[2];
+            auto fetch = [&](int ks, int slot) {
+                const float* kb = base + ks * 4 * WLDP + lane_off4;
+                a4[slot] = *reinterpret_cast<const wacc_t*>(kb + offA);
+                b4[slot][0] = *reinterpret_cast<const wacc_t*>(kb + offB);
+                b4[slot][1] = *reinterpret_cast<const wacc_t*>(kb + offB + 64);
+                if (HASW) wv[slot] = base[2 * WPANEL_ELEMS + ks * 4 + (lane >> 4)];
+            };
+            fetch(0, 0);
 #pragma unroll
             for (int ks = 0; ks < WKC / 4; ++ks) {
-                const float* kb = base + ks * 4 * WLDP + lane_off;
-                float av[WMR], bv[WNR];
-#pragma unroll
-                for (int i = 0; i < WMR; ++i) av[i] = kb[offA + i * WTILE];
-#pragma unroll
-                for (int j = 0; j < WNR; ++j) bv[j] = kb[offB + j * WTILE];
-                if (HASW) {
-                    const float wv = base[2 * WPANEL_ELEMS + ks * 4 + (lane >> 4)];
-#pragma unroll
-                    for (int i = 0; i < WMR; ++i) av[i] *= wv;
-                }
+                const int cur = ks & 1;
+                if (ks + 1 < WKC / 4) fetch(ks + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (the scheduler sinks it otherwise)
+                if (HASW) a4[cur] *= wv[cur];
 #pragma unroll
                 for (int i = 0; i < WMR; ++i)
 #pragma unroll
                     for (int j = 0; j < WNR; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[cur][i], b4[cur][j >> 2][j & 3], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
-    // epilogue: stored tiles -> this slab's partial buffer (fp32 C/D layout: row = 4*(lane>>4) + r, col = lane&15)
+    // epilogue: the whole 64 x 128 block -> this slab's partial buffer (leading dimension PP = panels x 256, so no
+    // bounds checks; entries below the diagonal or past p are never read by the reduce kernel).
+    // acc[i][4g+e][r] is H[row0 + 4*(4*(lane>>4) + r) + i][col0 + 64g + 4*(lane&15) + e]  (fp32 C/D layout:
+    // tile row = 4*(lane>>4) + r, tile column = lane&15; tile e of a group holds the columns 4m+e)
     float* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
-    const int r0b = ((wb.selA ? panB : panA) * 16 + wb.ta0) * WTILE;
-    const int c0b = ((wb.selB ? panB : panA) * 16 + wb.tb0) * WTILE;
+    if (active) {
+        const int row0 = (wb.selA ? panB : panA) * WPANEL + wb.ta0 * WTILE;
+        const int col0 = (wb.selB ? panB : panA) * WPANEL + wb.tb0 * WTILE;
 #pragma unroll
-    for (int i = 0; i < WMR; ++i)
+        for (int i = 0; i < WMR; ++i)
 #pragma unroll
-        for (int j = 0; j < WNR; ++j)
-            if ((wb.mask >> (i * WNR + j)) & 1) {
+            for (int r = 0; r < 4; ++r) {
+                float* dst = P + (int64_t)(row0 + 4 * (4 * (lane >> 4) + r) + i) * a.PP + col0 + 4 * (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    P[(int64_t)(r0b + i * WTILE + 4 * (lane >> 4) + r) * a.PP + c0b + j * WTILE + (lane & 15)] = acc[i][j][r];
+                for (int g = 0; g < 2; ++g) {
+                    wacc_t v = {acc[i][4 * g + 0][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]};
+                    *reinterpret_cast<wacc_t*>(dst + 64 * g) = v;
+                }
             }
+    }
 }
 
 template <typename T>
@@ -257,7 +283,7 @@ static int get_wide_plan(int p, WidePlan& out) {
     build_wide_items(p, items);
     WidePlan pl;
     pl.nitems = (int)items.size();
-    pl.PP = (p + WTILE - 1) / WTILE * WTILE;
+    pl.PP = (p + WPANEL - 1) / WPANEL * WPANEL;
     DLSA_HIP_CHECK(hipMalloc((void**)&pl.d_items, items.size() * sizeof(WideItem)));
     DLSA_HIP_CHECK(hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(WideItem), hipMemcpyHostToDevice));
     g_wide_plans[key] = pl;
@@ -309,7 +335,7 @@ size_t gram_wide_f32_ws_bytes(int64_t n, int p) {
     build_wide_items(p, items);
     int nslab; int64_t rps;
     choose_wide_slabs(n, p, (int)items.size(), nslab, rps);
-    const size_t PP = (size_t)(p + WTILE - 1) / WTILE * WTILE;
+    const size_t PP = (size_t)(p + WPANEL - 1) / WPANEL * WPANEL;
     return align_up((size_t)nslab * PP * PP * sizeof(float), 256);
 }
 
@@ -328,6 +354,8 @@ int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
     WideArgs a;
     a.X = X; a.w = w; a.partial = (float*)ws; a.items = pl.d_items; a.ldx = ldx; a.n = n; a.rows_per_slab = rps;
     a.p = p; a.PP = pl.PP; a.nitems = pl.nitems; a.nslab = nslab; a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
+    { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    if (a.dbg & 2) a.xcd_map = 0;
     const int blocks = pl.nitems * nslab;
     if (w) hipLaunchKernelGGL((gram_wide_f32_kernel<true>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
     else hipLaunchKernelGGL((gram_wide_f32_kernel<false>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
