@@ -21,8 +21,13 @@
 // MFMA operand layout (v_mfma_f64_16x16x4_f64): A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
 // C/D reg r of lane l = C[4r + (l>>4)][l&15]  (the fp64 C/D map differs from every other dtype).
 // With A[i][k] = X[r0+k][ca+i] and B[k][j] = w[r0+k] X[r0+k][cb+j] both fragments are the SAME
-// LDS read pattern "lane l <- chunk[4ks + (l>>4)][16t + (l&15)]", bank-conflict-free at a row
-// pitch of 144 elements.  fp32 uses v_mfma_f32_16x16x4_f32 with the same fragments.
+// LDS read pattern from row 4ks + (l>>4) of the chunk (row pitch 144 elements).  In the blocked mode the
+// MFMA tiles of a 64-column block are INTERLEAVED: tile e of 32-column group g holds the columns
+// 32g + 2m + e (m = lane&15), so ONE 16-byte LDS read of the natural row layout feeds two tiles:
+// 4 ds_read_b128 + the w read per 16 MFMAs instead of 8 ds_read_b64.  On this chip every LDS / VALU
+// instruction issued next to fp64 MFMAs costs MFMA cycles, so halving them matters;
+// the next k-step's fragments are also fetched before the current MFMA block (register double buffer).
+// The epilogue undoes the interleave.  fp32 uses v_mfma_f32_16x16x4_f32 with the same scheme.
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -37,11 +42,18 @@ constexpr int PANEL = 128;        // columns per panel = 8 tiles
 #ifndef DLSA_GRAM_KC
 #define DLSA_GRAM_KC 16
 #endif
+#ifndef DLSA_GRAM_PREFETCH
+#define DLSA_GRAM_PREFETCH 1
+#endif
 #ifndef DLSA_GRAM_OCC
 #define DLSA_GRAM_OCC 2
 #endif
 constexpr int KC = DLSA_GRAM_KC;  // rows per staged chunk = KC/4 MFMA k-steps
-constexpr int LDP = 144;          // LDS row pitch (elements): 144 mod 32 == 16 -> conflict-free frags
+// LDS row pitch in elements, chosen per fragment-read instruction (MI355X_MICROARCH.md, LDS lane groups):
+//   list mode, one element per read: rows of a lane group must sit 16 elements apart modulo 32 -> 144;
+//   blocked fp64, ds_read_b128 (groups of 16 lanes mixing two rows): 256-byte multiples -> 128, no padding;
+//   blocked fp32, ds_read_b64 (groups of 32 lanes = two rows): 128 bytes apart modulo 256 -> 160.
+constexpr int gram_ldp(int elem_bytes, bool list) { return list ? 144 : (elem_bytes == 8 ? 128 : 160); }
 constexpr int GRAM_WAVES = 4;
 constexpr int GRAM_THREADS = 64 * GRAM_WAVES;
 constexpr int MR = 4, NR = 4;     // tiles per wave block
@@ -72,7 +84,7 @@ struct GramArgs {
     int64_t n;
     int64_t rows_per_slab;
     int p;
-    int PP;              // padded dimension = ntile*16
+    int PP;              // padded dimension: ntile*16 rounded up to a multiple of 64
     int nitems;
     int nslab;
     int xcd_map;         // 1: XCD-aware block->(item,slab) mapping (needs nslab % 8 == 0)
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Vec2<T>::type vec2_t;
     constexpr int PASSES = KC / GRAM_WAVES;              // staging passes per panel
+    constexpr int LDP = gram_ldp((int)sizeof(T), LIST);
     constexpr int PANEL_ELEMS = KC * LDP;
     constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + KC;      // two panels + the w chunk
     __shared__ __attribute__((aligned(16))) T lds[2 * BUF_ELEMS];
@@ -175,13 +188,12 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
         }
     }
 
-    // LDS element offsets of the block's A and B fragment origins (wave-uniform)
-    int offA[MR], offB[NR];
-#pragma unroll
-    for (int i = 0; i < MR; ++i) offA[i] = ((wb.a[i] >> 3) & 1) * PANEL_ELEMS + (wb.a[i] & 7) * TILE;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) offB[j] = ((wb.b[j] >> 3) & 1) * PANEL_ELEMS + (wb.b[j] & 7) * TILE;
-    const int lane_off = (lane >> 4) * LDP + (lane & 15);
+    // LDS element offsets of the block's 64-column A and B origins (wave-uniform); a[0] / b[0] are the
+    // first tiles of 4-aligned tile groups, i.e. column 0 or 64 of their panel
+    const int offA0 = ((wb.a[0] >> 3) & 1) * PANEL_ELEMS + (wb.a[0] & 7) * TILE;
+    const int offB0 = ((wb.b[0] >> 3) & 1) * PANEL_ELEMS + (wb.b[0] & 7) * TILE;
+    const int lane_off = (lane >> 4) * LDP + (lane & 15);          // list mode: one element per fragment read
+    const int lane_off2 = (lane >> 4) * LDP + (lane & 15) * 2;     // blocked mode: two adjacent columns per read
 
     const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
     const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
@@ -303,10 +315,10 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
         }
         if (active) {
             const T* base = lds + (c & 1) * BUF_ELEMS;
+            if constexpr (LIST) {
 #pragma unroll
-            for (int ks = 0; ks < KC / 4; ++ks) {
-                const T* kb = base + ks * 4 * LDP + lane_off;
-                if constexpr (LIST) {
+                for (int ks = 0; ks < KC / 4; ++ks) {
+                    const T* kb = base + ks * 4 * LDP + lane_off;
                     T wv = T(1);
                     if (HASW) wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
 #pragma unroll
@@ -316,16 +328,42 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
                         if (HASW) bv *= wv;
                         accl[t] = Mfma<T>::run(av, bv, accl[t]);
                     }
-                } else {
+                }
+            } else {
+                vec2_t a2[2][2], b2[2][2];
+                T wv[2];
+                auto fetch = [&](int ks, int slot) {
+                    const T* kb = base + ks * 4 * LDP + lane_off2;
+                    // written as scalar loads on purpose: hipcc merges each pair into one 16-byte ds_read, whereas an
+                    // explicit vector load here makes it put "s_waitcnt vmcnt(0)" in front of the first read, i.e.
+                    // wait for the LDS-DMA of the NEXT chunk that was issued just above (serialising load and compute)
+                    a2[slot][0].x = kb[offA0]; a2[slot][0].y = kb[offA0 + 1];
+                    a2[slot][1].x = kb[offA0 + 32]; a2[slot][1].y = kb[offA0 + 33];
+                    b2[slot][0].x = kb[offB0]; b2[slot][0].y = kb[offB0 + 1];
+                    b2[slot][1].x = kb[offB0 + 32]; b2[slot][1].y = kb[offB0 + 33];
+                    if (HASW) wv[slot] = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
+                };
+#if DLSA_GRAM_PREFETCH
+                fetch(0, 0);
+#endif
+#pragma unroll
+                for (int ks = 0; ks < KC / 4; ++ks) {
+                    const int cur = ks & 1;
+#if DLSA_GRAM_PREFETCH
+                    if (ks + 1 < KC / 4) fetch(ks + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block
+#else
+                    fetch(ks, cur);
+#endif
                     T av[MR], bv[NR];
 #pragma unroll
-                    for (int i = 0; i < MR; ++i) av[i] = kb[offA[i]];
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) bv[j] = kb[offB[j]];
+                    for (int g = 0; g < 2; ++g) {
+                        av[2 * g] = a2[cur][g].x; av[2 * g + 1] = a2[cur][g].y;
+                        bv[2 * g] = b2[cur][g].x; bv[2 * g + 1] = b2[cur][g].y;
+                    }
                     if (HASW) {
-                        const T wv = base[2 * PANEL_ELEMS + ks * 4 + (lane >> 4)];
 #pragma unroll
-                        for (int j = 0; j < NR; ++j) bv[j] *= wv;
+                        for (int j = 0; j < NR; ++j) bv[j] *= wv[cur];
                     }
 #pragma unroll
                     for (int i = 0; i < MR; ++i)
@@ -337,6 +375,9 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
 #pragma unroll
                             for (int j = 0; j < i; ++j) acc[i][j] = Mfma<T>::run(av[i], bv[j], acc[i][j]);
                     }
+#if DLSA_GRAM_PREFETCH
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
         }
@@ -362,19 +403,45 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
                     P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = accl[t][r];
             }
         }
-    } else {
+    } else if (active) {
+        // Interleaved tiles: acc[i][j][r] = H[row0 + 32(i>>1) + 2*tr + (i&1)][col0 + 32(j>>1) + 2*tc + (j&1)] with
+        // tr = crow(lane, r), tc = lane&15.  PP is a multiple of 64, so the whole 64x64 block lies inside the
+        // partial buffer; entries below the diagonal or past p are never read by the reduce kernel.
+        const int row0 = ((((wb.a[0] >> 3) & 1) ? panB : panA) * 8 + (wb.a[0] & 7)) * TILE;
+        const int col0 = ((((wb.b[0] >> 3) & 1) ? panB : panA) * 8 + (wb.b[0] & 7)) * TILE;
+        const int tc = lane & 15;
+        if (!tri) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int r0 = ((((wb.a[i] >> 3) & 1) ? panB : panA) * 8 + (wb.a[i] & 7)) * TILE;
+            for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                if ((wb.mask >> (i * NR + j)) & 1) {
-                    const int c0 = ((((wb.b[j] >> 3) & 1) ? panB : panA) * 8 + (wb.b[j] & 7)) * TILE;
+                for (int r = 0; r < 4; ++r) {
+                    const int R = row0 + 32 * (i >> 1) + 2 * Mfma<T>::crow(lane, r) + (i & 1);
+                    T* dst = P + (int64_t)R * a.PP + col0 + 2 * tc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        P[(int64_t)(r0 + Mfma<T>::crow(lane, r)) * a.PP + c0 + (lane & 15)] = acc[i][j][r];
+                    for (int g = 0; g < 2; ++g) {
+                        vec2_t v;
+                        v.x = acc[i][2 * g][r]; v.y = acc[i][2 * g + 1][r];
+                        *reinterpret_cast<vec2_t*>(dst + 32 * g) = v;
+                    }
                 }
-            }
+        } else {
+            // diagonal block: only tiles j >= i were computed.  Inside a diagonal 32x32 group the skipped tile
+            // (2g+1, 2g) is the transpose of tile (2g, 2g+1), whose lower half is therefore stored mirrored;
+            // every entry on/above the diagonal is written exactly once (deterministic).
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = i; j < NR; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tr = Mfma<T>::crow(lane, r);
+                        const int R = row0 + 32 * (i >> 1) + 2 * tr + (i & 1);
+                        const int C = col0 + 32 * (j >> 1) + 2 * tc + (j & 1);
+                        const T v = acc[i][j][r];
+                        if ((i >> 1) != (j >> 1)) P[(int64_t)R * a.PP + C] = v;
+                        else if (tr <= tc) P[(int64_t)R * a.PP + C] = v;
+                        else if (i != j) P[(int64_t)C * a.PP + R] = v;
+                    }
         }
     }
 }
@@ -603,7 +670,7 @@ static int get_plan(int p, GramPlan& out) {
     pl.p = p;
     pl.ntile = (p + TILE - 1) / TILE;
     pl.npan = (p + PANEL - 1) / PANEL;
-    pl.PP = pl.ntile * TILE;
+    pl.PP = (pl.ntile * TILE + 63) / 64 * 64;      // blocked mode stores whole 64x64 blocks
     std::vector<GramItem> items, listed;
     build_plan_items(p, items, listed, pl.nt_list);
     pl.nitems = (int)items.size();
@@ -655,7 +722,7 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     int nslab, nslab2 = 0; int64_t rps;
     choose_slabs(n, (int)items.size(), nslab, rps);
     if (nt_list) choose_slabs(n, (int)listed.size(), nslab2, rps);
-    const size_t PP = (size_t)ntile * TILE;
+    const size_t PP = ((size_t)ntile * TILE + 63) / 64 * 64;
     size_t bytes = align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
     if (elem_bytes == 4 && gram_wide_f32_shape_ok(n, p)) bytes = std::max(bytes, gram_wide_f32_ws_bytes(n, p));
     return bytes;

@@ -35,7 +35,7 @@ constexpr int WPANEL = 256;            // columns per panel = 16 tiles
 #define DLSA_WIDE_STAGES 3
 #endif
 constexpr int WKC = DLSA_WIDE_KC;      // rows per stage
-constexpr int WLDP = 272;              // LDS row pitch in floats: 272 mod 64 == 16 -> conflict-free fragments
+constexpr int WLDP = 256;              // LDS row pitch in floats: ds_read_b128 lane groups mix two rows -> 256-byte multiples, no padding
 constexpr int WSTAGES = DLSA_WIDE_STAGES;
 constexpr int WAHEAD = WSTAGES - 1;    // chunks in flight ahead of the one being consumed
 constexpr int WWAVES = 8;
