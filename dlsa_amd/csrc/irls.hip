@@ -63,11 +63,16 @@ struct IrlsBuffers {
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
 // `H` receives every fresh Hessian.  On return with DLSA_PART_OK, *fresh says whether H was evaluated
 // at the final beta.  Returns a HIP/argument error code (0 = fine) and sets *status.
+// inherit_scale > 0: b.L already holds the Cholesky factor of a Hessian H0 with  H(beta) ~= inherit_scale * H0
+// (the same model on a row subsample, or on the previous partition): the iterations start as quasi-Newton steps
+// delta = H0^-1 (g / inherit_scale) -- logit passes and triangular solves only -- and a fresh Gram pass is taken
+// only if those steps stop contracting.  The fixed point is the same MLE; only the path changes.
 static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, int p, double tol, int max_iter,
                       double freeze_at, double* H, const IrlsBuffers& b, hipStream_t s, int* status, int* iters,
-                      int* gram_passes, double* loglik, bool* fresh) {
+                      int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
     double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY;
-    bool have_prev = false, need_H = true, have_factor = false;
+    bool have_prev = false, need_H = !(inherit_scale > 0.0), have_factor = inherit_scale > 0.0;
+    double gscale = inherit_scale > 0.0 ? 1.0 / inherit_scale : 1.0;
     int halvings = 0;
     *status = DLSA_PART_NOT_CONVERGED;
     *fresh = false;
@@ -80,6 +85,10 @@ static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, 
             rc = gram_impl_f64(X, ldx, b.w, n, p, H, p, 0, b.ws_gram, b.ws_gram_bytes, s);
             if (rc) return rc;
             ++*gram_passes;
+            gscale = 1.0;
+        } else if (gscale != 1.0) {
+            rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
+            if (rc) return rc;
         }
         rc = launch_chol_solve(H, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, fresh_now ? 0 : 1);
         if (rc) return rc;
@@ -170,7 +179,13 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
 
     const char* env_warm = getenv("DLSA_IRLS_WARM");
     const bool warm_ok = env_warm ? atoi(env_warm) != 0 : true;   // 0 disables partition-to-partition warm starts
+    const char* env_inh = getenv("DLSA_IRLS_INHERIT");
+    // Starting from an inherited Cholesky factor trades one Gram pass (~n p^2 flops) for a few more logit passes
+    // (~n p bytes each): worth it once the Gram pass costs several logit passes, i.e. for p of a few hundred
+    // (measured: 2.5e7 x 500 fit 0.41 -> 0.33 s; at p = 100 the extra iterations cost more than the Gram they save).
+    const bool inherit_ok = env_inh ? atoi(env_inh) != 0 : (p >= 192);
     bool have_warm = false;
+    int64_t factor_rows = 0;             // rows behind the Hessian whose factor sits in b.L (0 = none usable)
     int overall = DLSA_OK;
     for (int k = 0; k < K; ++k) {
         const int64_t r0 = part_offsets_host[k];
@@ -198,8 +213,10 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
             bool warm = have_warm;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 st = DLSA_PART_OK; iters = 0; grams = 0;
+                double inherit = (warm && inherit_ok && factor_rows > 0) ? (double)nk / (double)factor_rows : 0.0;
                 if (!warm) {
                     DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
+                    factor_rows = 0;
                     // cold start of a large partition: solve its leading 1/sub_div rows first
                     const int64_t nsub = sub_div > 1 ? nk / sub_div : 0;
                     if (nsub >= 200 * (int64_t)p && nsub >= 50000) {
@@ -208,15 +225,30 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                         rc = newton_run(Xk, ldx, yk, nsub, p, 1e-6, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub,
                                         &gr_sub, &ll_sub, &fresh);
                         if (rc) return rc;
-                        if (st_sub != DLSA_PART_OK)     // degenerate subsample: plain cold start
+                        if (st_sub != DLSA_PART_OK) {   // degenerate subsample: plain cold start
                             DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
+                        } else if (inherit_ok) {
+                            // factor the subsample Hessian AT the subsample MLE (b.w are the weights of the last logit
+                            // pass, which ran at exactly this beta): nk/nsub times it stands in for the full Hessian
+                            if (!fresh) {
+                                rc = gram_impl_f64(Xk, ldx, b.w, nsub, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+                                if (rc) return rc;
+                            }
+                            rc = launch_chol_solve(Hk, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
+                            if (rc) return rc;
+                            inherit = (double)nk / (double)nsub;
+                        }
                     }
                 }
-                rc = newton_run(Xk, ldx, yk, nk, p, tol, max_iter, freeze_at, Hk, b, s, &st, &iters, &grams, &ll, &fresh);
+                rc = newton_run(Xk, ldx, yk, nk, p, tol, max_iter, freeze_at, Hk, b, s, &st, &iters, &grams, &ll, &fresh,
+                                inherit);
                 if (rc) return rc;
+                if (grams > 0) factor_rows = nk;         // b.L now factors a Hessian of this partition
+                else if (inherit > 0.0 && factor_rows == 0) factor_rows = nk / std::max(1, sub_div);
                 if (st == DLSA_PART_OK || !warm) break;
                 warm = false;                            // warm start failed: repeat from zero
             }
+            if (st != DLSA_PART_OK) factor_rows = 0;
             have_warm = (st == DLSA_PART_OK) && warm_ok;
             if (st == DLSA_PART_OK && !fresh) {
                 // Sig_inv must be the Hessian AT the returned coef: b.w holds the weights of the last
