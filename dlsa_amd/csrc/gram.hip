@@ -731,7 +731,7 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
 template <typename T>
 int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64_t ldh,
               int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
-    DLSA_REQUIRE(X && H, "gram: null X or H");
+    DLSA_REQUIRE((X || n == 0) && H, "gram: null X or H");      // an empty row block (n == 0) gives H = 0
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p && ldh >= p, "gram: bad shape n=%lld p=%d ldx=%lld ldh=%lld",
                  (long long)n, p, (long long)ldx, (long long)ldh);
     if constexpr (sizeof(T) == 4) {
