@@ -62,6 +62,74 @@ __host__ __device__ constexpr int rep_mask() {   // lane bits that must be zero 
     return 63 & ~used;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lean fp64 transcendentals for the logistic terms.  The library exp / log1p / division cost ~130 extra
+// VGPRs in this kernel (175 VGPRs at NC=1 -> two waves per SIMD, latency-bound at small p); these keep the
+// same accuracy class (<= 2 ulp on e, mu, w; softplus to ~1e-16 absolute) in ~60 instructions:
+//   e = exp(-|eta|):  k = rint(|eta| log2 e), r = k ln2 - |eta| (two-part ln2, |r| <= 0.347), degree-13
+//       polynomial, ldexp;
+//   1/(1+e), 1/den: v_rcp_f64 seed + two Newton steps;
+//   log1p(e) = log t, t = 1+e in (1,2]: halve t above sqrt 2, s = (t-1)/(t+1) (|s| <= 0.172), 2 atanh(s)
+//       as an odd polynomial with 10 terms, + ln2 if halved.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+
+__device__ __forceinline__ double exp_neg(double a) {      // exp(-a), a >= 0
+    a = fmin(a, 745.2);
+    const double kf = rint(a * 1.4426950408889634);
+    double r = fma(kf, 6.93147180369123816490e-01, -a);
+    r = fma(kf, 1.90821492927058770002e-10, r);
+    double q = 1.6059043836821613e-10;                      // 1/13!
+    q = fma(q, r, 2.08767569878681e-09);
+    q = fma(q, r, 2.505210838544172e-08);
+    q = fma(q, r, 2.755731922398589e-07);
+    q = fma(q, r, 2.7557319223985893e-06);
+    q = fma(q, r, 2.48015873015873e-05);
+    q = fma(q, r, 1.984126984126984e-04);
+    q = fma(q, r, 1.388888888888889e-03);
+    q = fma(q, r, 8.333333333333333e-03);
+    q = fma(q, r, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, -(int)kf);
+}
+
+// e = exp(-|eta|) -> mu = sigmoid(eta), wgt = mu(1-mu) = e/(1+e)^2, softplus(eta) = max(eta,0) + log1p(e)
+template <bool WANT_MU>
+__device__ __forceinline__ void logistic_terms(double eta, double& mu, double& wgt, double& softplus) {
+    const double e = exp_neg(fabs(eta));
+    if (WANT_MU) {
+        const double inv = rcp_newton(1.0 + e);
+        mu = eta >= 0.0 ? inv : e * inv;
+        wgt = e * inv * inv;
+    }
+    const bool big = e > 0.41421356237309503;               // t = 1 + e > sqrt(2)
+    const double num = big ? fma(0.5, e, -0.5) : e;         // t' - 1 with t' = t/2 or t
+    const double den = big ? fma(0.5, e, 1.5) : 2.0 + e;    // t' + 1
+    const double sv = num * rcp_newton(den);
+    const double z = sv * sv;
+    double q = 1.0 / 21.0;
+    q = fma(q, z, 1.0 / 19.0);
+    q = fma(q, z, 1.0 / 17.0);
+    q = fma(q, z, 1.0 / 15.0);
+    q = fma(q, z, 1.0 / 13.0);
+    q = fma(q, z, 1.0 / 11.0);
+    q = fma(q, z, 1.0 / 9.0);
+    q = fma(q, z, 1.0 / 7.0);
+    q = fma(q, z, 1.0 / 5.0);
+    q = fma(q, z, 1.0 / 3.0);
+    q = fma(q, z, 1.0);
+    const double l1p = fma(2.0 * sv, q, big ? 6.931471805599453094e-01 : 0.0);
+    softplus = fmax(eta, 0.0) + l1p;
+}
+
 struct LogitArgs {
     const double* X;
     const double* y;
@@ -95,28 +163,40 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
 
     const int64_t nbatch = (a.n + RB - 1) / RB;
     const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
-    for (int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave; bt < nbatch; bt += stride) {
+
+    // (the label of the lane's own row travels with the batch: a load issued later would make its s_waitcnt
+    //  drain the prefetch of the next batch as well -- vmcnt retires in order)
+    auto load_batch = [&](int64_t bt, double2 (&x)[RB][NC], double& yv) {
+        // Branch-free: rows past n and columns past p are CLAMPED to a valid address and zeroed by a select
+        // afterwards, so every load is unconditional straight-line code.  (With the loads inside per-row / per-column
+        // branches hipcc can no longer count them and falls back to s_waitcnt vmcnt(0), which drains the prefetch.)
         const int64_t row0 = bt * RB;
-        double2 x[RB][NC];
+        const int64_t ry = min(row0 + myrow, a.n - 1);
+        const double ytmp = a.y[ry];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int64_t r = row0 + i;
-            const double* src = a.X + r * a.ldx + 2 * lane;
+            const int64_t r = min(row0 + i, a.n - 1);
+            const double* rowp = a.X + r * a.ldx;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int col = c * 128 + 2 * lane;
-                double2 v; v.x = 0.0; v.y = 0.0;
-                if (r < a.n) {
-                    if (col + 1 < a.p) {
-                        if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
-                        else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
-                    } else if (col < a.p) {
-                        v.x = src[c * 128];
-                    }
+                const int c0 = col < a.p ? col : 0;                   // clamped first column
+                if (VEC) {                                            // VEC implies p even: a pair never straddles p
+                    x[i][c] = *reinterpret_cast<const double2*>(rowp + c0);
+                } else {
+                    x[i][c].x = rowp[c0];
+                    x[i][c].y = rowp[col + 1 < a.p ? col + 1 : 0];
                 }
-                x[i][c] = v;
             }
         }
+        yv = ytmp;      // masked in process(): touching the loaded values here would wait for them right away
+    };
+    auto process = [&](int64_t bt, const double2 (&xraw)[RB][NC], const double yraw) {
+        const int64_t row0 = bt * RB;
+        // No masking of x needed: a clamped column meets beta = 0 in the dot product and only pollutes entries
+        // of g beyond p, which nobody reads; a clamped row (past n) gets residual 0 below.
+        const double2 (&x)[RB][NC] = xraw;
+        const double yv = (row0 + myrow < a.n) ? yraw : 0.0;
         double dot[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -128,17 +208,14 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
         const double eta = merged_reduce<RB>(dot, lane);
         const int64_t r = row0 + myrow;
         const bool valid = r < a.n;
-        const double yv = valid ? a.y[r] : 0.0;
         // e = exp(-|eta|);  mu = sigmoid(eta);  w = mu(1-mu) = e/(1+e)^2
-        const double e = exp(-fabs(eta));
-        const double inv = 1.0 / (1.0 + e);
-        const double mu = eta >= 0.0 ? inv : e * inv;
-        const double wgt = e * inv * inv;
+        double mu, wgt, sp;
+        logistic_terms<true>(eta, mu, wgt, sp);
         const double resid = valid ? (yv - mu) : 0.0;
         if (valid && rep) {
             if (a.w_out) a.w_out[r] = wgt;
             // y log mu + (1-y) log(1-mu) = y*eta - softplus(eta)
-            ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
+            ll += yv * eta - sp;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -148,6 +225,34 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
                 g[c].x = fma(ri, x[i][c].x, g[c].x);
                 g[c].y = fma(ri, x[i][c].y, g[c].y);
             }
+        }
+    };
+
+    int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave;
+    if constexpr (NC == 1) {
+        // Narrow rows (p <= 128; at NC = 2 the second register set drops the kernel to one wave per SIMD: slower): a batch is only RB*8p bytes, so the serial chain load -> butterfly ->
+        // transcendentals -> rank-1 update leaves HBM idle at the two waves per SIMD this kernel gets.  The next
+        // batch is therefore loaded into a second register set before the current one is processed.
+        double2 xa[RB][NC], xb[RB][NC];
+        double ya = 0.0, yb = 0.0;
+        // the prefetch is UNCONDITIONAL (a batch past the end re-reads row n-1 and is never processed): a load
+        // inside "if (next < nbatch)" makes the wait counts conservative again
+        if (a.n > 0) {
+            load_batch(bt, xa, ya);
+            for (; bt < nbatch; bt += 2 * stride) {
+                const int64_t b1 = bt + stride, b2 = bt + 2 * stride;
+                load_batch(b1, xb, yb);
+                process(bt, xa, ya);
+                load_batch(b2, xa, ya);
+                if (b1 < nbatch) process(b1, xb, yb);
+            }
+        }
+    } else {
+        for (; bt < nbatch; bt += stride) {
+            double2 x[RB][NC];
+            double yv;
+            load_batch(bt, x, yv);
+            process(bt, x, yv);
         }
     }
 
@@ -248,7 +353,7 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p;
     a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
     a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
-    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {
         case 1: blocks = logit_blocks(n, 8); launch_logit<1, 8>(a, vec, blocks, stream); break;
@@ -304,20 +409,16 @@ __global__ __launch_bounds__(LOGIT_THREADS) void loglik_kernel(LoglikArgs a) {
         double dot[RB * C];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int64_t r = row0 + i;
-            const double* src = a.X + r * a.ldx + 2 * lane;
+            // branch-free clamped loads (see logit_kernel): clamped columns meet par = 0, clamped rows are dropped below
+            const int64_t r = min(row0 + i, a.n - 1);
+            const double* rowp = a.X + r * a.ldx;
             double2 x[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int col = c * 128 + 2 * lane;
-                double2 v; v.x = 0.0; v.y = 0.0;
-                if (r < a.n) {
-                    if (col + 1 < a.p) {
-                        if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
-                        else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
-                    } else if (col < a.p) v.x = src[c * 128];
-                }
-                x[c] = v;
+                const int c0 = col < a.p ? col : 0;
+                if (VEC) x[c] = *reinterpret_cast<const double2*>(rowp + c0);
+                else { x[c].x = rowp[c0]; x[c].y = rowp[col + 1 < a.p ? col + 1 : 0]; }
             }
 #pragma unroll
             for (int j = 0; j < C; ++j) {
@@ -331,7 +432,9 @@ __global__ __launch_bounds__(LOGIT_THREADS) void loglik_kernel(LoglikArgs a) {
         const int64_t r = row0 + myrow;
         if (rep && r < a.n && mycol < a.c) {
             const double yv = a.y[r];
-            ll += yv * eta - (fmax(eta, 0.0) + log1p(exp(-fabs(eta))));
+            double mu_unused, w_unused, sp;
+            logistic_terms<false>(eta, mu_unused, w_unused, sp);
+            ll += yv * eta - sp;
         }
     }
 #pragma unroll
@@ -376,21 +479,25 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
         const int64_t row0 = bt * RB;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int64_t r = row0 + i;
-            if (r >= a.n) continue;
-            const double yv = a.y[r];
-            const double* src = a.X + r * a.ldx + 2 * lane;
-            if (lane == 0) vv = fma(yv, yv, vv);
+            // branch-free clamped loads (see logit_kernel): a row past n gets weight 0, columns past p land in
+            // entries of g that nobody reads
+            const int64_t r = min(row0 + i, a.n - 1);
+            const double yraw = a.y[r];
+            const double* rowp = a.X + r * a.ldx;
+            double2 v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int col = c * 128 + 2 * lane;
-                double2 v; v.x = 0.0; v.y = 0.0;
-                if (col + 1 < a.p) {
-                    if (VEC) v = *reinterpret_cast<const double2*>(src + c * 128);
-                    else { v.x = src[c * 128]; v.y = src[c * 128 + 1]; }
-                } else if (col < a.p) v.x = src[c * 128];
-                g[c].x = fma(yv, v.x, g[c].x);
-                g[c].y = fma(yv, v.y, g[c].y);
+                const int c0 = col < a.p ? col : 0;
+                if (VEC) v[c] = *reinterpret_cast<const double2*>(rowp + c0);
+                else { v[c].x = rowp[c0]; v[c].y = rowp[col + 1 < a.p ? col + 1 : 0]; }
+            }
+            const double yv = (row0 + i < a.n) ? yraw : 0.0;
+            if (lane == 0) vv = fma(yv, yv, vv);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                g[c].x = fma(yv, v[c].x, g[c].x);
+                g[c].y = fma(yv, v[c].y, g[c].y);
             }
         }
     }
@@ -535,7 +642,7 @@ int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, in
     hipStream_t s = (hipStream_t)stream;
     LoglikArgs a;
     a.X = X; a.y = y; a.par = par; a.llpart = (double*)ws; a.ldx = ldx; a.ldpar = ldpar; a.n = n; a.p = p; a.c = c;
-    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     const int nc = logit_nc(p);
     int blocks;
     // RB*C = 16 values per merged butterfly (8 for the widest rows)
@@ -584,7 +691,7 @@ int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p
     a.X = X; a.y = v; a.beta = nullptr; a.w_out = nullptr; a.ldx = ldx; a.n = n; a.p = p;
     a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
     a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
-    const bool vec = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0);
+    const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {
         case 1: blocks = logit_blocks(n, 8); launch_xtv<1, 8>(a, vec, blocks, s); break;
