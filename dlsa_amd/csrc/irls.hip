@@ -11,6 +11,9 @@
 //   * frozen Hessian: once |delta|_inf <= 1e-1*max(1,|beta|_inf) the factor of the last Hessian is
 //     reused and only logit passes + triangular solves run (linear convergence at a rate
 //     ~|beta - beta*|; a stalled frozen iteration (step shrinking by < 4x) refreshes the Hessian).
+//   * inherited factor + secant correction: for p >= 192 the full-data iterations start from the factor of a stand-in
+//     Hessian (a quarter of the rows at the subsample MLE, or the previous partition's) and every reused factor is
+//     corrected with the L-BFGS two-loop recursion on the exact curvature pairs the iterations produce.
 // Stop when |delta|_inf <= tol*max(1,|beta|_inf).  The Hessian written to Sig_inv[k] is ALWAYS a
 // fresh Gram pass at the returned coef, exactly as the reference evaluates it after the fit
 // (models.py:114,130); Sig_invMcoef = Sig_inv . coef (models.py:131).  One D2H copy of 4 doubles
@@ -33,8 +36,10 @@ int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const doubl
 int launch_matvec(const double* A, int64_t lda, const double* x, int p, double* y, hipStream_t s);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
 
+constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
+
 struct IrlsLayout {
-    size_t w, g, beta, beta_prev, delta, stats, L, gram, logit, total;
+    size_t w, g, beta, beta_prev, delta, stats, L, gram, logit, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
 };
 
 static IrlsLayout irls_layout(int64_t max_rows, int p) {
@@ -50,12 +55,111 @@ static IrlsLayout irls_layout(int64_t max_rows, int p) {
     l.L = take((size_t)p * p * sizeof(double));
     l.gram = take(gram_workspace_bytes_impl(max_rows, p, 8));
     l.logit = take(logit_workspace_bytes_impl(max_rows, p));
+    l.qn_s = take((size_t)QN_PAIRS * p * sizeof(double));
+    l.qn_y = take((size_t)QN_PAIRS * p * sizeof(double));
+    l.qn_rho = take(QN_PAIRS * sizeof(double));
+    l.qn_alpha = take(QN_PAIRS * sizeof(double));
+    l.qn_q = take((size_t)p * sizeof(double));
+    l.qn_gprev = take((size_t)p * sizeof(double));
     l.total = align_up(off, 256);
     return l;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Secant (L-BFGS) correction of the frozen / inherited Hessian.  While the Cholesky factor of an approximate
+// Hessian H0 is reused, the iteration delta = H0^-1 g contracts only linearly (rate ~ |I - H0^-1 H|: 0.04-0.08
+// with a subsample Hessian at p = 500, i.e. nine to ten full logit passes to 1e-13).  Every iteration also yields
+// an exact curvature pair (s = beta_k - beta_k-1, y = g_k-1 - g_k = H s), and the two-loop recursion around the
+// triangular solve turns the contraction superlinear for a few tiny single-workgroup kernels per iteration.
+// The fixed point is unchanged (g = 0): only the path to the MLE gets shorter.
+// ---------------------------------------------------------------------------------------------
+struct QnOrder { int idx[QN_PAIRS]; int m; };     // ring slots, oldest first
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];       // fixed order
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void qn_push_kernel(const double* __restrict__ beta, const double* __restrict__ prev,
+                                                       const double* __restrict__ gprev, const double* __restrict__ g, int p,
+                                                       double* __restrict__ S, double* __restrict__ Y, double* __restrict__ rho) {
+    __shared__ double red[16];
+    double sy = 0.0;
+    for (int i = threadIdx.x; i < p; i += blockDim.x) {
+        const double sv = beta[i] - prev[i], yv = gprev[i] - g[i];
+        S[i] = sv; Y[i] = yv;
+        sy = fma(sv, yv, sy);
+    }
+    sy = block_sum(sy, red);
+    if (threadIdx.x == 0) *rho = (sy > 0.0 && isfinite(sy)) ? 1.0 / sy : 0.0;      // rho = 0: pair ignored
+}
+
+// first loop: q = (g - sum alpha_i y_i) * gscale, newest pair first
+__global__ __launch_bounds__(1024) void qn_pre_kernel(const double* __restrict__ g, const double* __restrict__ S,
+                                                      const double* __restrict__ Y, const double* __restrict__ rho,
+                                                      QnOrder ord, int p, double gscale, double* __restrict__ q,
+                                                      double* __restrict__ alpha) {
+    extern __shared__ double sm[];
+    double* qv = sm;                 // p
+    double* red = sm + p;            // 16
+    for (int i = threadIdx.x; i < p; i += blockDim.x) qv[i] = g[i];
+    __syncthreads();
+    for (int k = ord.m - 1; k >= 0; --k) {
+        const int slot = ord.idx[k];
+        const double* s = S + (int64_t)slot * p;
+        const double* y = Y + (int64_t)slot * p;
+        double d = 0.0;
+        for (int i = threadIdx.x; i < p; i += blockDim.x) d = fma(s[i], qv[i], d);
+        const double a = rho[slot] * block_sum(d, red);
+        if (threadIdx.x == 0) alpha[slot] = a;
+        for (int i = threadIdx.x; i < p; i += blockDim.x) qv[i] = fma(-a, y[i], qv[i]);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < p; i += blockDim.x) q[i] = qv[i] * gscale;
+}
+
+// second loop on r = H0^-1 q (in place), oldest pair first; then stats[0] = |r|_inf
+__global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, const double* __restrict__ S,
+                                                       const double* __restrict__ Y, const double* __restrict__ rho,
+                                                       const double* __restrict__ alpha, QnOrder ord, int p,
+                                                       double* __restrict__ stats) {
+    extern __shared__ double sm[];
+    double* rv = sm;
+    double* red = sm + p;
+    for (int i = threadIdx.x; i < p; i += blockDim.x) rv[i] = r[i];
+    __syncthreads();
+    for (int k = 0; k < ord.m; ++k) {
+        const int slot = ord.idx[k];
+        const double* s = S + (int64_t)slot * p;
+        const double* y = Y + (int64_t)slot * p;
+        double d = 0.0;
+        for (int i = threadIdx.x; i < p; i += blockDim.x) d = fma(y[i], rv[i], d);
+        const double bcoef = rho[slot] * block_sum(d, red);
+        const double c = alpha[slot] - bcoef;
+        for (int i = threadIdx.x; i < p; i += blockDim.x) rv[i] = fma(c, s[i], rv[i]);
+        __syncthreads();
+    }
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < p; i += blockDim.x) { r[i] = rv[i]; mx = fmax(mx, fabs(rv[i])); }
+    for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) a = fmax(a, red[k]);
+        stats[0] = a;
+    }
+}
+
 struct IrlsBuffers {
     double *w, *g, *beta, *prev, *delta, *stats, *L;
+    double *qn_s, *qn_y, *qn_rho, *qn_alpha, *qn_q, *qn_gprev;
     void* ws_gram; size_t ws_gram_bytes;
     void* ws_logit; size_t ws_logit_bytes;
 };
@@ -63,6 +167,11 @@ struct IrlsBuffers {
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
 // `H` receives every fresh Hessian.  On return with DLSA_PART_OK, *fresh says whether H was evaluated
 // at the final beta.  Returns a HIP/argument error code (0 = fine) and sets *status.
+static bool qn_enabled() {
+    const char* e = getenv("DLSA_IRLS_SECANT");
+    return e ? atoi(e) != 0 : true;
+}
+
 // inherit_scale > 0: b.L already holds the Cholesky factor of a Hessian H0 with  H(beta) ~= inherit_scale * H0
 // (the same model on a row subsample, or on the previous partition): the iterations start as quasi-Newton steps
 // delta = H0^-1 (g / inherit_scale) -- logit passes and triangular solves only -- and a fresh Gram pass is taken
@@ -74,6 +183,12 @@ static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, 
     bool have_prev = false, need_H = !(inherit_scale > 0.0), have_factor = inherit_scale > 0.0;
     double gscale = inherit_scale > 0.0 ? 1.0 / inherit_scale : 1.0;
     int halvings = 0;
+    // secant pairs (quasi-Newton correction of the reused factor): ring of QN_PAIRS slots
+    const bool qn_on = qn_enabled();
+    QnOrder ord; ord.m = 0;
+    int qn_next = 0;
+    bool qn_have_gprev = false;      // b.qn_gprev holds the gradient at b.prev
+    const size_t qn_shm = ((size_t)p + 16) * sizeof(double);
     *status = DLSA_PART_NOT_CONVERGED;
     *fresh = false;
     for (int it = 1; it <= max_iter; ++it) {
@@ -86,23 +201,51 @@ static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, 
             if (rc) return rc;
             ++*gram_passes;
             gscale = 1.0;
-        } else if (gscale != 1.0) {
+            ord.m = 0;                               // a new H0: the old pairs go
+        }
+        const bool qn_now = qn_on && !fresh_now;
+        if (qn_now && qn_have_gprev) {               // the accepted step prev -> beta gives a curvature pair
+            const int slot = qn_next;
+            qn_next = (qn_next + 1) % QN_PAIRS;
+            hipLaunchKernelGGL(qn_push_kernel, dim3(1), dim3(1024), 0, s, (const double*)b.beta, (const double*)b.prev,
+                               (const double*)b.qn_gprev, (const double*)b.g, p, b.qn_s + (int64_t)slot * p,
+                               b.qn_y + (int64_t)slot * p, b.qn_rho + slot);
+            if (ord.m < QN_PAIRS) ord.idx[ord.m++] = slot;
+            else { for (int k = 0; k + 1 < QN_PAIRS; ++k) ord.idx[k] = ord.idx[k + 1]; ord.idx[QN_PAIRS - 1] = slot; }
+        }
+        if (qn_on) {                                  // remember the gradient at this beta for the next pair
+            DLSA_HIP_CHECK(hipMemcpyAsync(b.qn_gprev, b.g, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
+            qn_have_gprev = true;
+        }
+        const double* rhs = b.g;
+        if (qn_now && ord.m > 0) {
+            hipLaunchKernelGGL(qn_pre_kernel, dim3(1), dim3(1024), qn_shm, s, (const double*)b.g, (const double*)b.qn_s,
+                               (const double*)b.qn_y, (const double*)b.qn_rho, ord, p, gscale, b.qn_q, b.qn_alpha);
+            rhs = b.qn_q;
+        } else if (!fresh_now && gscale != 1.0) {
             rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
             if (rc) return rc;
         }
-        rc = launch_chol_solve(H, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, fresh_now ? 0 : 1);
+        rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, fresh_now ? 0 : 1);
         if (rc) return rc;
+        if (qn_now && ord.m > 0) {
+            hipLaunchKernelGGL(qn_post_kernel, dim3(1), dim3(1024), qn_shm, s, b.delta, (const double*)b.qn_s,
+                               (const double*)b.qn_y, (const double*)b.qn_rho, (const double*)b.qn_alpha, ord, p, b.stats);
+            DLSA_HIP_CHECK(hipGetLastError());
+        }
         have_factor = true;
         double h[4];
         DLSA_HIP_CHECK(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
         ll = h[3];
         *loglik = ll;
+        if (getenv("DLSA_IRLS_TRACE")) fprintf(stderr, "[irls] n=%lld it=%d fresh=%d step=%.3e |beta|=%.3e ll=%.10e\n", (long long)n, it, (int)fresh_now, h[0], h[1], ll);
         if (h[2] == 1.0) { *status = DLSA_PART_NOT_SPD; return DLSA_OK; }
         if (h[2] == 2.0 || !isfinite(ll)) { *status = DLSA_PART_NAN; return DLSA_OK; }
         // safeguard: the previous step overshot (log-likelihood dropped) -> halve it, refresh H
         if (have_prev && ll < ll_prev - 1e-12 * fabs(ll_prev) && halvings < 30) {
             ++halvings;
+            ord.m = 0; qn_have_gprev = false;                            // the rejected step gives no valid pair
             rc = launch_axpby(b.beta, b.prev, -1.0, p, b.delta, s);      // delta = beta - prev
             if (rc) return rc;
             rc = launch_axpby(b.prev, b.delta, 0.5, p, b.beta, s);       // beta = prev + delta/2
@@ -167,6 +310,8 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     b.delta = (double*)(base + l.delta);
     b.stats = (double*)(base + l.stats);   // [0..2] solver stats, [3] loglik
     b.L = (double*)(base + l.L);
+    b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
+    b.qn_alpha = (double*)(base + l.qn_alpha); b.qn_q = (double*)(base + l.qn_q); b.qn_gprev = (double*)(base + l.qn_gprev);
     b.ws_gram = base + l.gram;
     b.ws_gram_bytes = gram_workspace_bytes_impl(max_rows, p, 8);
     b.ws_logit = base + l.logit;
@@ -186,6 +331,9 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     const bool inherit_ok = env_inh ? atoi(env_inh) != 0 : (p >= 192);
     bool have_warm = false;
     int64_t factor_rows = 0;             // rows behind the Hessian whose factor sits in b.L (0 = none usable)
+    int64_t factor_rows_sub = 0;
+    const char* env_fd = getenv("DLSA_IRLS_FACTOR_DIV");
+    const int fac_div = env_fd ? atoi(env_fd) : 4;              // rows / fac_div feed the stand-in Hessian (0/1: the subsample's)
     int overall = DLSA_OK;
     for (int k = 0; k < K; ++k) {
         const int64_t r0 = part_offsets_host[k];
@@ -228,15 +376,23 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                         if (st_sub != DLSA_PART_OK) {   // degenerate subsample: plain cold start
                             DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
                         } else if (inherit_ok) {
-                            // factor the subsample Hessian AT the subsample MLE (b.w are the weights of the last logit
-                            // pass, which ran at exactly this beta): nk/nsub times it stands in for the full Hessian
-                            if (!fresh) {
-                                rc = gram_impl_f64(Xk, ldx, b.w, nsub, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+                            // Factor a Hessian AT the subsample MLE that will stand in for the full one.  The quasi-Newton
+                            // contraction rate is the relative sampling error of that Hessian, ~2 sqrt(p / rows): on the
+                            // 1/16 subsample that is 0.08 at p = 500 (ten full logit passes to 1e-13); one Gram pass over
+                            // a quarter of the rows (a quarter of a full pass) brings it to 0.02 (six passes).
+                            const int64_t nfac = fac_div > 1 ? std::max<int64_t>(nsub, nk / fac_div) : nsub;
+                            if (nfac > nsub) {
+                                rc = logit_pass_impl(Xk, ldx, yk, b.beta, nfac, p, b.w, nullptr, nullptr, b.ws_logit, b.ws_logit_bytes, s);
+                                if (rc) return rc;
+                            }
+                            if (nfac > nsub || !fresh) {     // (b.w of the subsample run are the weights at exactly this beta)
+                                rc = gram_impl_f64(Xk, ldx, b.w, nfac, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
                                 if (rc) return rc;
                             }
                             rc = launch_chol_solve(Hk, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
                             if (rc) return rc;
-                            inherit = (double)nk / (double)nsub;
+                            inherit = (double)nk / (double)nfac;
+                            factor_rows_sub = nfac;
                         }
                     }
                 }
@@ -244,7 +400,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                                 inherit);
                 if (rc) return rc;
                 if (grams > 0) factor_rows = nk;         // b.L now factors a Hessian of this partition
-                else if (inherit > 0.0 && factor_rows == 0) factor_rows = nk / std::max(1, sub_div);
+                else if (inherit > 0.0 && factor_rows == 0) factor_rows = factor_rows_sub;
                 if (st == DLSA_PART_OK || !warm) break;
                 warm = false;                            // warm start failed: repeat from zero
             }

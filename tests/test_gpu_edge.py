@@ -93,14 +93,14 @@ def test_logit_pass_p_limit_and_invalid_arguments(eng):
 
 
 def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
-    """Subsample warm start, frozen / inherited Cholesky factors and partition warm starts only change the
+    """Subsample warm start, frozen / inherited Cholesky factors, secant corrections and partition warm starts only change the
     path of the iteration: the MLE and the Hessian at the MLE must agree to the solver tolerance."""
     n, p = 240_000, 200                                     # p >= 192: factor inheritance is active
     X, y = eng.synth(99, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
     offs = [0, 60_000, 120_000, n]                          # last partition large enough for the subsample start
     base = eng.irls_fit(X, y, offs)
     assert base["status"] == [0, 0, 0]
-    keys = ("DLSA_IRLS_SUBSAMPLE", "DLSA_IRLS_FREEZE", "DLSA_IRLS_WARM", "DLSA_IRLS_INHERIT")
+    keys = ("DLSA_IRLS_SUBSAMPLE", "DLSA_IRLS_FREEZE", "DLSA_IRLS_WARM", "DLSA_IRLS_INHERIT", "DLSA_IRLS_SECANT")
     try:
         for k in keys:
             os.environ[k] = "0"
@@ -109,7 +109,7 @@ def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
         for k in keys:
             os.environ.pop(k, None)
     assert plain["status"] == [0, 0, 0]
-    assert sum(base["n_iter"]) != sum(plain["n_iter"])      # the switches really changed the path
+    assert base["n_iter"] != plain["n_iter"]                # the switches really changed the path
     assert rel_inf(base["coef"].cpu().numpy(), plain["coef"].cpu().numpy()) < 1e-11
     assert rel_inf(base["Sig_inv"].cpu().numpy(), plain["Sig_inv"].cpu().numpy()) < 1e-11
     # and both are the oracle's MLE on the first partition
