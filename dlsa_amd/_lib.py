@@ -44,6 +44,16 @@ SIGNATURES = {
                                 c_vp, c_i64, c_vp, c_vp]),
     "dlsa_design_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                 c_vp, c_i64, c_vp, c_vp]),
+    "dlsa_onehot_plan_create": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "dlsa_onehot_plan_destroy": (None, [c_vp]),
+    "dlsa_onehot_plan_roles": (c_int, [c_vp]),
+    "dlsa_onehot_workspace_bytes": (c_sz, [c_vp, c_i64]),
+    "dlsa_onehot_logit_pass_f64": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_onehot_gram_f64": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dlsa_onehot_irls_workspace_bytes": (c_sz, [c_vp, c_i64]),
+    "dlsa_onehot_irls_fit_f64": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_int, c_dbl, c_int,
+                                         c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                         ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
     "dlsa_gram_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dlsa_gram_wide_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
 }

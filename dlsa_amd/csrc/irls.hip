@@ -22,6 +22,7 @@
 #include <math.h>
 #include <algorithm>
 #include <stdlib.h>
+#include <functional>
 
 namespace dlsa {
 int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
@@ -34,15 +35,26 @@ int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const doubl
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor);
 int launch_matvec(const double* A, int64_t lda, const double* x, int p, double* y, hipStream_t s);
+}  // namespace dlsa
+struct dlsa_onehot_plan;
+namespace dlsa {
+size_t onehot_workspace_bytes_impl(const dlsa_onehot_plan* pl, int64_t n);
+int onehot_plan_p(const dlsa_onehot_plan* pl);
+int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                           const double* y, const double* beta, int64_t n, double* w_out, double* g, double* loglik,
+                           void* ws, size_t ws_bytes, hipStream_t s);
+int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
 
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
 
 struct IrlsLayout {
-    size_t w, g, beta, beta_prev, delta, stats, L, gram, logit, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
+    size_t w, g, beta, beta_prev, delta, stats, L, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
 };
 
-static IrlsLayout irls_layout(int64_t max_rows, int p) {
+// pass_bytes: scratch of the data source's logit / Gram passes (they never run concurrently)
+static IrlsLayout irls_layout(int64_t max_rows, int p, size_t pass_bytes) {
     IrlsLayout l;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = align_up(off, 256); off = o + bytes; return o; };
@@ -53,8 +65,8 @@ static IrlsLayout irls_layout(int64_t max_rows, int p) {
     l.delta = take((size_t)p * sizeof(double));
     l.stats = take(8 * sizeof(double));
     l.L = take((size_t)p * p * sizeof(double));
-    l.gram = take(gram_workspace_bytes_impl(max_rows, p, 8));
-    l.logit = take(logit_workspace_bytes_impl(max_rows, p));
+    l.pass_bytes = pass_bytes;
+    l.pass = take(pass_bytes);
     l.qn_s = take((size_t)QN_PAIRS * p * sizeof(double));
     l.qn_y = take((size_t)QN_PAIRS * p * sizeof(double));
     l.qn_rho = take(QN_PAIRS * sizeof(double));
@@ -160,8 +172,14 @@ __global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, c
 struct IrlsBuffers {
     double *w, *g, *beta, *prev, *delta, *stats, *L;
     double *qn_s, *qn_y, *qn_rho, *qn_alpha, *qn_q, *qn_gprev;
-    void* ws_gram; size_t ws_gram_bytes;
-    void* ws_logit; size_t ws_logit_bytes;
+    void* ws_pass; size_t ws_pass_bytes;
+};
+
+// The rows of one partition, whatever their representation (dense matrix, or raw numerics + level codes): the two
+// passes of a Newton iteration over the leading `nrows` rows.
+struct IrlsData {
+    std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s)> logit;
+    std::function<int(const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s)> gram;
 };
 
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
@@ -176,7 +194,7 @@ static bool qn_enabled() {
 // (the same model on a row subsample, or on the previous partition): the iterations start as quasi-Newton steps
 // delta = H0^-1 (g / inherit_scale) -- logit passes and triangular solves only -- and a fresh Gram pass is taken
 // only if those steps stop contracting.  The fixed point is the same MLE; only the path changes.
-static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, int p, double tol, int max_iter,
+static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_iter,
                       double freeze_at, double* H, const IrlsBuffers& b, hipStream_t s, int* status, int* iters,
                       int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
     double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY;
@@ -193,11 +211,11 @@ static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, 
     *fresh = false;
     for (int it = 1; it <= max_iter; ++it) {
         ++*iters;
-        int rc = logit_pass_impl(X, ldx, y, b.beta, n, p, b.w, b.g, b.stats + 3, b.ws_logit, b.ws_logit_bytes, s);
+        int rc = d.logit(b.beta, n, b.w, b.g, b.stats + 3, b, s);
         if (rc) return rc;
         const bool fresh_now = need_H || !have_factor;
         if (fresh_now) {
-            rc = gram_impl_f64(X, ldx, b.w, n, p, H, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+            rc = d.gram(b.w, n, H, b, s);
             if (rc) return rc;
             ++*gram_passes;
             gscale = 1.0;
@@ -273,29 +291,18 @@ static int newton_run(const double* X, int64_t ldx, const double* y, int64_t n, 
     return DLSA_OK;
 }
 
-}  // namespace dlsa
-
-extern "C" {
-
-size_t dlsa_irls_workspace_bytes(int64_t max_rows_per_partition, int p) {
-    if (p <= 0 || p > 2048 || max_rows_per_partition < 0) return 0;
-    return dlsa::irls_layout(max_rows_per_partition, p).total;
-}
-
-int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_offsets_host,
-                      int K, int p, double tol, int max_iter, double* coef, double* Sig_inv,
-                      double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
-                      void* ws, size_t ws_bytes, void* stream) {
-    using namespace dlsa;
-    DLSA_REQUIRE(X && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "irls_fit: null argument");
-    DLSA_REQUIRE(K > 0 && p > 0 && p <= 2048 && ldx >= p, "irls_fit: bad shape K=%d p=%d ldx=%lld", K, p, (long long)ldx);
-    DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit: bad tol/max_iter");
+// The partition loop shared by every data representation.  make_data(r0) gives the passes over the rows that start
+// at row r0; pass_bytes(rows) the scratch those passes need.
+static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, const std::function<size_t(int64_t)>& pass_bytes,
+                         const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
+                         double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
+                         void* ws, size_t ws_bytes, void* stream) {
     int64_t max_rows = 0;
     for (int k = 0; k < K; ++k) {
         DLSA_REQUIRE(part_offsets_host[k + 1] >= part_offsets_host[k], "irls_fit: part_offsets not monotone");
         max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
     }
-    const IrlsLayout l = irls_layout(max_rows, p);
+    const IrlsLayout l = irls_layout(max_rows, p, pass_bytes(max_rows));
     if (!ws || ws_bytes < l.total || ((uintptr_t)ws & 255)) {
         set_error("irls_fit: workspace %zu bytes needed (256-aligned), got %zu", l.total, ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -312,10 +319,8 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     b.L = (double*)(base + l.L);
     b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
     b.qn_alpha = (double*)(base + l.qn_alpha); b.qn_q = (double*)(base + l.qn_q); b.qn_gprev = (double*)(base + l.qn_gprev);
-    b.ws_gram = base + l.gram;
-    b.ws_gram_bytes = gram_workspace_bytes_impl(max_rows, p, 8);
-    b.ws_logit = base + l.logit;
-    b.ws_logit_bytes = logit_workspace_bytes_impl(max_rows, p);
+    b.ws_pass = base + l.pass;
+    b.ws_pass_bytes = l.pass_bytes;
     // tuning knobs for experiments (defaults are the production policy)
     const char* env_sub = getenv("DLSA_IRLS_SUBSAMPLE");
     const char* env_frz = getenv("DLSA_IRLS_FREEZE");
@@ -338,8 +343,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     for (int k = 0; k < K; ++k) {
         const int64_t r0 = part_offsets_host[k];
         const int64_t nk = part_offsets_host[k + 1] - r0;
-        const double* Xk = X + r0 * ldx;
-        const double* yk = y + r0;
+        const IrlsData d = make_data(r0);
         double* Hk = Sig_inv + (int64_t)k * p * p;
         double* ck = coef + (int64_t)k * p;
         double* sk = Sig_invMcoef + (int64_t)k * p;
@@ -370,7 +374,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                     if (nsub >= 200 * (int64_t)p && nsub >= 50000) {
                         int st_sub = 0, it_sub = 0, gr_sub = 0;
                         double ll_sub = 0.0;
-                        rc = newton_run(Xk, ldx, yk, nsub, p, 1e-6, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub,
+                        rc = newton_run(d, nsub, p, 1e-6, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub,
                                         &gr_sub, &ll_sub, &fresh);
                         if (rc) return rc;
                         if (st_sub != DLSA_PART_OK) {   // degenerate subsample: plain cold start
@@ -382,11 +386,11 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                             // a quarter of the rows (a quarter of a full pass) brings it to 0.02 (six passes).
                             const int64_t nfac = fac_div > 1 ? std::max<int64_t>(nsub, nk / fac_div) : nsub;
                             if (nfac > nsub) {
-                                rc = logit_pass_impl(Xk, ldx, yk, b.beta, nfac, p, b.w, nullptr, nullptr, b.ws_logit, b.ws_logit_bytes, s);
+                                rc = d.logit(b.beta, nfac, b.w, nullptr, nullptr, b, s);
                                 if (rc) return rc;
                             }
                             if (nfac > nsub || !fresh) {     // (b.w of the subsample run are the weights at exactly this beta)
-                                rc = gram_impl_f64(Xk, ldx, b.w, nfac, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+                                rc = d.gram(b.w, nfac, Hk, b, s);
                                 if (rc) return rc;
                             }
                             rc = launch_chol_solve(Hk, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
@@ -396,7 +400,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
                         }
                     }
                 }
-                rc = newton_run(Xk, ldx, yk, nk, p, tol, max_iter, freeze_at, Hk, b, s, &st, &iters, &grams, &ll, &fresh,
+                rc = newton_run(d, nk, p, tol, max_iter, freeze_at, Hk, b, s, &st, &iters, &grams, &ll, &fresh,
                                 inherit);
                 if (rc) return rc;
                 if (grams > 0) factor_rows = nk;         // b.L now factors a Hessian of this partition
@@ -409,13 +413,13 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
             if (st == DLSA_PART_OK && !fresh) {
                 // Sig_inv must be the Hessian AT the returned coef: b.w holds the weights of the last
                 // logit pass, which ran at exactly this beta
-                rc = gram_impl_f64(Xk, ldx, b.w, nk, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+                rc = d.gram(b.w, nk, Hk, b, s);
                 if (rc) return rc;
             } else if (st == DLSA_PART_NOT_CONVERGED) {
                 // report the Hessian at the last iterate
-                rc = logit_pass_impl(Xk, ldx, yk, b.beta, nk, p, b.w, nullptr, nullptr, b.ws_logit, b.ws_logit_bytes, s);
+                rc = d.logit(b.beta, nk, b.w, nullptr, nullptr, b, s);
                 if (rc) return rc;
-                rc = gram_impl_f64(Xk, ldx, b.w, nk, p, Hk, p, 0, b.ws_gram, b.ws_gram_bytes, s);
+                rc = d.gram(b.w, nk, Hk, b, s);
                 if (rc) return rc;
             }
             DLSA_HIP_CHECK(hipMemcpyAsync(ck, b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -434,6 +438,75 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     if (overall == DLSA_ERR_NOT_SPD) set_error("irls_fit: a partition's Hessian is not positive definite");
     if (overall == DLSA_ERR_NAN) set_error("irls_fit: NaN/Inf in a partition's fit");
     return overall;
+}
+
+static size_t dense_pass_bytes(int64_t rows, int p) {
+    return std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p));
+}
+
+}  // namespace dlsa
+
+extern "C" {
+
+size_t dlsa_irls_workspace_bytes(int64_t max_rows_per_partition, int p) {
+    if (p <= 0 || p > 2048 || max_rows_per_partition < 0) return 0;
+    return dlsa::irls_layout(max_rows_per_partition, p, dlsa::dense_pass_bytes(max_rows_per_partition, p)).total;
+}
+
+int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_offsets_host,
+                      int K, int p, double tol, int max_iter, double* coef, double* Sig_inv,
+                      double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
+                      void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(X && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "irls_fit: null argument");
+    DLSA_REQUIRE(K > 0 && p > 0 && p <= 2048 && ldx >= p, "irls_fit: bad shape K=%d p=%d ldx=%lld", K, p, (long long)ldx);
+    DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit: bad tol/max_iter");
+    auto make_data = [=](int64_t r0) {
+        const double* Xk = X + r0 * ldx;
+        const double* yk = y + r0;
+        IrlsData d;
+        d.logit = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s) {
+            return logit_pass_impl(Xk, ldx, yk, beta, nrows, p, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
+            return gram_impl_f64(Xk, ldx, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        return d;
+    };
+    return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, part_offsets_host, K, p, tol,
+                         max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
+}
+
+// One-hot designs: the same fit on raw numerics + level codes (onehot.hip), never materialising the dense matrix.
+size_t dlsa_onehot_irls_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition) {
+    if (!plan || max_rows_per_partition < 0) return 0;
+    return dlsa::irls_layout(max_rows_per_partition, dlsa::onehot_plan_p(plan),
+                             dlsa::onehot_workspace_bytes_impl(plan, max_rows_per_partition)).total;
+}
+
+int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                             const double* y, const int64_t* part_offsets_host, int K, double tol, int max_iter,
+                             double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+                             double* loglik_host, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(plan && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "onehot irls_fit: null argument");
+    DLSA_REQUIRE(K > 0 && max_iter > 0 && tol > 0, "onehot irls_fit: bad K/tol/max_iter");
+    const int p = onehot_plan_p(plan);
+    auto make_data = [=](int64_t r0) {
+        const double* numk = num ? num + r0 * ldn : nullptr;
+        const int32_t* codesk = codes ? codes + r0 * ldc : nullptr;
+        const double* yk = y + r0;
+        IrlsData d;
+        d.logit = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s) {
+            return onehot_logit_pass_impl(plan, numk, ldn, codesk, ldc, yk, beta, nrows, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
+            return onehot_gram_impl(plan, numk, ldn, codesk, ldc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        return d;
+    };
+    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, part_offsets_host, K,
+                         p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,475 @@
+// Structured passes for one-hot designs (reference: the dummy path of logistic_model,
+// dlsa/models.py:56-131, where the design matrix is [intercept | standardised numerics | one-hot factor levels]).
+//
+// With f factors a row of the p-column design has only D + f non-zeros (D = intercept + numeric columns), so
+//   eta_i = d_i . beta_D + sum_t beta[col(t, code_it)]                       is a GATHER,
+//   g     = X'r:  g_D = sum r_i d_i,  g[col(t, l)] = sum_{code_it = l} r_i   is a HISTOGRAM,
+//   H     = X'WX: H_DD (D x D, dense), H[a][col(t,l)] = sum_{code_it=l} w_i d_ia  (vector histogram per level),
+//                 H[col(t,l)][col(t',l')] = sum_{code_it=l, code_it'=l'} w_i      (weighted co-occurrence counts)
+// and both passes read the 8q + 4f raw bytes of a row (76 B for the airline-shaped config 4) instead of the 8p
+// bytes of the dense row (2080 B): HBM-bound on a 27x smaller stream, no MFMA work at all.  The p x p result is
+// the same matrix the dense Gram kernel produces (to rounding), so Cholesky / WLS / LARS are unchanged.
+//
+// One thread owns one row (64 distinct rows per wave: the transcendentals are not replicated).  Histograms are
+// accumulated with LDS atomics in per-workgroup tables and flushed to per-workgroup partials that a second kernel
+// sums in a fixed order; the order of the LDS atomic adds inside a workgroup is not fixed, so -- unlike the dense
+// kernels -- results can differ in the last bits from run to run.  The factor-pair tables of the Gram are dealt to
+// workgroup ROLES so that each role's tables fit in LDS (every role streams all rows; they are cheap).
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <string.h>
+
+namespace dlsa {
+
+constexpr int OH_MAXD = 8;            // dense columns (intercept + numerics) handled in registers
+constexpr int OH_MAXF = 8;            // factors
+constexpr int OH_THREADS = 256;
+constexpr int OH_LDS_BUDGET = 120 * 1024;     // bytes of histogram tables per workgroup role
+constexpr int OH_MAX_BLOCKS = 1024;
+
+struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
+    int t, u;                         // factor indices
+    int lds_off;                      // offset (doubles) of its L_t x L_u (or L_t) cells in the role's LDS image
+};
+
+struct OhRole {
+    int ntab;
+    OhTable tab[OH_MAXF * (OH_MAXF + 1) / 2];
+    int with_dense;                   // this role also accumulates H_DD and H_D,dummy
+    int dense_off;                    // offset of the D x nlev_total block (H_D,dummy), if with_dense
+    int cells;                        // doubles in the LDS image
+};
+
+struct OhDesc {                       // device-visible description of the design
+    int p, D, f;
+    int dense_kind[OH_MAXD];          // 0: constant 1, 1: numeric column dense_src
+    int dense_src[OH_MAXD];
+    double dense_shift[OH_MAXD], dense_scale[OH_MAXD];
+    int dense_col[OH_MAXD];           // output column of dense column a
+    int lvl_off[OH_MAXF + 1];         // factor t's levels occupy [lvl_off[t], lvl_off[t+1]) of level_col
+    int nlev_total;
+};
+
+}  // namespace dlsa
+
+struct dlsa_onehot_plan {
+    dlsa::OhDesc desc;
+    int32_t* d_level_col;             // device: column of every (factor, level), -1 = no column (baseline / dropped)
+    std::vector<int32_t> h_level_col;
+    std::vector<dlsa::OhRole> roles;
+    dlsa::OhRole* d_roles;
+    bool needs_num;                   // some dense column is numeric
+};
+
+namespace dlsa {
+
+// standardised dense vector of row i (d[a], a < D)
+__device__ __forceinline__ void oh_dense_row(const OhDesc& ds, const double* __restrict__ num, int64_t ldn, int64_t i,
+                                             double (&d)[OH_MAXD]) {
+#pragma unroll
+    for (int a = 0; a < OH_MAXD; ++a) {
+        d[a] = 0.0;
+        if (a < ds.D) d[a] = ds.dense_kind[a] == 0 ? 1.0 : (num[i * ldn + ds.dense_src[a]] - ds.dense_shift[a]) / ds.dense_scale[a];
+    }
+}
+
+__device__ __forceinline__ double oh_exp_neg(double a) {      // exp(-a), a >= 0 (as logit.hip)
+    a = fmin(a, 745.2);
+    const double kf = rint(a * 1.4426950408889634);
+    double r = fma(kf, 6.93147180369123816490e-01, -a);
+    r = fma(kf, 1.90821492927058770002e-10, r);
+    double q = 1.6059043836821613e-10;
+    q = fma(q, r, 2.08767569878681e-09);
+    q = fma(q, r, 2.505210838544172e-08);
+    q = fma(q, r, 2.755731922398589e-07);
+    q = fma(q, r, 2.7557319223985893e-06);
+    q = fma(q, r, 2.48015873015873e-05);
+    q = fma(q, r, 1.984126984126984e-04);
+    q = fma(q, r, 1.388888888888889e-03);
+    q = fma(q, r, 8.333333333333333e-03);
+    q = fma(q, r, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, -(int)kf);
+}
+
+__device__ __forceinline__ double oh_block_sum(double v, double* red) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// logit pass: w, per-workgroup partial of g (p doubles) and loglik
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const int32_t* __restrict__ level_col,
+                                                              const double* __restrict__ num, int64_t ldn,
+                                                              const int32_t* __restrict__ codes, int64_t ldc,
+                                                              const double* __restrict__ y, const double* __restrict__ beta,
+                                                              int64_t n, double* __restrict__ w_out,
+                                                              double* __restrict__ gpart, double* __restrict__ llpart) {
+    extern __shared__ double sm[];
+    double* sbeta = sm;                           // p
+    double* sg = sm + ds.p;                       // p   (histogram of residuals)
+    int* scol = reinterpret_cast<int*>(sm + 2 * ds.p);     // nlev_total
+    double* red = reinterpret_cast<double*>(scol + ((ds.nlev_total + 1) & ~1));
+    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) { sbeta[j] = beta[j]; sg[j] = 0.0; }
+    for (int j = threadIdx.x; j < ds.nlev_total; j += blockDim.x) scol[j] = level_col[j];
+    __syncthreads();
+    double gd[OH_MAXD];
+#pragma unroll
+    for (int a = 0; a < OH_MAXD; ++a) gd[a] = 0.0;
+    double ll = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double d[OH_MAXD];
+        oh_dense_row(ds, num, ldn, i, d);
+        double eta = 0.0;
+#pragma unroll
+        for (int a = 0; a < OH_MAXD; ++a)
+            if (a < ds.D) eta = fma(d[a], sbeta[ds.dense_col[a]], eta);
+        int cols[OH_MAXF];
+#pragma unroll
+        for (int t = 0; t < OH_MAXF; ++t) {
+            cols[t] = -1;
+            if (t < ds.f) {
+                const int code = codes[i * ldc + t];
+                const int nl = ds.lvl_off[t + 1] - ds.lvl_off[t];
+                if (code >= 0 && code < nl) cols[t] = scol[ds.lvl_off[t] + code];
+                if (cols[t] >= 0) eta += sbeta[cols[t]];
+            }
+        }
+        const double yv = y[i];
+        const double e = oh_exp_neg(fabs(eta));
+        double inv = __builtin_amdgcn_rcp(1.0 + e);
+        inv = fma(fma(-(1.0 + e), inv, 1.0), inv, inv);
+        inv = fma(fma(-(1.0 + e), inv, 1.0), inv, inv);
+        const double mu = eta >= 0.0 ? inv : e * inv;
+        if (w_out) w_out[i] = e * inv * inv;
+        const double r = yv - mu;
+        ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
+#pragma unroll
+        for (int a = 0; a < OH_MAXD; ++a) gd[a] = fma(r, d[a], gd[a]);
+#pragma unroll
+        for (int t = 0; t < OH_MAXF; ++t)
+            if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg[cols[t]], r);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < OH_MAXD; ++a) {
+        const double sgd = oh_block_sum(gd[a], red);
+        if (threadIdx.x == 0 && a < ds.D) sg[ds.dense_col[a]] += sgd;
+    }
+    const double sll = oh_block_sum(ll, red);
+    __syncthreads();
+    double* gp = gpart + (int64_t)blockIdx.x * ds.p;
+    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) gp[j] = sg[j];
+    if (threadIdx.x == 0) llpart[blockIdx.x] = sll;
+}
+
+// g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b]   (fixed order)
+__global__ __launch_bounds__(256) void oh_logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart,
+                                                              int nblocks, int p, double* __restrict__ g, double* __restrict__ loglik) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g && j < p) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += gpart[(int64_t)b * p + j];
+        g[j] = s;
+    }
+    if (loglik && blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += llpart[b];
+        *loglik = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OH_THREADS) void oh_gram_kernel(OhDesc ds, const OhRole* __restrict__ roles, int nroles,
+                                                             int blocks_per_role, const double* __restrict__ num, int64_t ldn,
+                                                             const int32_t* __restrict__ codes, int64_t ldc,
+                                                             const double* __restrict__ w, int64_t n,
+                                                             double* __restrict__ partial, int64_t role_stride) {
+    extern __shared__ double sm[];
+    const int role_id = blockIdx.x / blocks_per_role;
+    const int bl = blockIdx.x % blocks_per_role;
+    const OhRole& role = roles[role_id];
+    double* tab = sm;                              // role.cells
+    double* red = sm + role.cells;                 // 16
+    for (int j = threadIdx.x; j < role.cells; j += blockDim.x) tab[j] = 0.0;
+    __syncthreads();
+    double hdd[OH_MAXD * (OH_MAXD + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < OH_MAXD * (OH_MAXD + 1) / 2; ++k) hdd[k] = 0.0;
+    const bool dense = role.with_dense != 0;
+    for (int64_t i = (int64_t)bl * blockDim.x + threadIdx.x; i < n; i += (int64_t)blocks_per_role * blockDim.x) {
+        const double wi = w ? w[i] : 1.0;
+        int lv[OH_MAXF];
+#pragma unroll
+        for (int t = 0; t < OH_MAXF; ++t) {
+            lv[t] = -1;
+            if (t < ds.f) {
+                const int code = codes[i * ldc + t];
+                if (code >= 0 && code < ds.lvl_off[t + 1] - ds.lvl_off[t]) lv[t] = code;
+            }
+        }
+        if (dense) {
+            double d[OH_MAXD];
+            oh_dense_row(ds, num, ldn, i, d);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < OH_MAXD; ++a)
+#pragma unroll
+                for (int b = a; b < OH_MAXD; ++b, ++k) hdd[k] = fma(wi * d[a], d[b], hdd[k]);
+#pragma unroll
+            for (int t = 0; t < OH_MAXF; ++t)
+                if (t < ds.f && lv[t] >= 0) {
+                    double* dst = tab + role.dense_off + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
+#pragma unroll
+                    for (int a = 0; a < OH_MAXD; ++a)
+                        if (a < ds.D) unsafeAtomicAdd(dst + a, wi * d[a]);
+                }
+        }
+        for (int q = 0; q < role.ntab; ++q) {
+            const OhTable tb = role.tab[q];
+            const int lt = lv[tb.t], lu = lv[tb.u];
+            if (lt < 0 || lu < 0) continue;
+            if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
+            else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
+        }
+    }
+    __syncthreads();
+    double* out = partial + (int64_t)role_id * role_stride + (int64_t)bl * (role.cells + OH_MAXD * (OH_MAXD + 1) / 2);
+    for (int j = threadIdx.x; j < role.cells; j += blockDim.x) out[j] = tab[j];
+    if (dense) {
+#pragma unroll
+        for (int k = 0; k < OH_MAXD * (OH_MAXD + 1) / 2; ++k) {
+            const double s = oh_block_sum(hdd[k], red);
+            if (threadIdx.x == 0) out[role.cells + k] = s;
+        }
+    }
+}
+
+// one thread per cell of a role image: sums the role's workgroup partials in a fixed order and scatters the value to
+// H (both triangles); cells whose (factor, level) has no column are dropped
+__global__ __launch_bounds__(256) void oh_gram_finish_kernel(OhDesc ds, const OhRole* __restrict__ roles, int role_id,
+                                                             int blocks_per_role, const int32_t* __restrict__ level_col,
+                                                             const double* __restrict__ partial, int64_t role_stride,
+                                                             double* __restrict__ H, int64_t ldh) {
+    const OhRole& role = roles[role_id];
+    constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
+    const int per = role.cells + NDD;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= per) return;
+    const double* src = partial + (int64_t)role_id * role_stride + c;
+    double s = 0.0;
+    for (int b = 0; b < blocks_per_role; ++b) s += src[(int64_t)b * per];
+    int r0 = -1, c0 = -1;
+    if (c >= role.cells) {                                   // H_DD, upper triangle order
+        if (!role.with_dense) return;
+        int k = c - role.cells, a = 0;
+        while (k >= OH_MAXD - a) { k -= OH_MAXD - a; ++a; }
+        const int b = a + k;
+        if (a < ds.D && b < ds.D) { r0 = ds.dense_col[a]; c0 = ds.dense_col[b]; }
+    } else if (role.with_dense && c >= role.dense_off && c < role.dense_off + ds.nlev_total * OH_MAXD) {     // H_D,dummy: [level][a]
+        const int k = c - role.dense_off, lvl = k / OH_MAXD, a = k % OH_MAXD;
+        if (a < ds.D && lvl < ds.nlev_total) { r0 = ds.dense_col[a]; c0 = level_col[lvl]; }
+    } else {
+        for (int q = 0; q < role.ntab; ++q) {
+            const OhTable tb = role.tab[q];
+            const int Lt = ds.lvl_off[tb.t + 1] - ds.lvl_off[tb.t], Lu = ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u];
+            const int sz = tb.t == tb.u ? Lt : Lt * Lu;
+            if (c >= tb.lds_off && c < tb.lds_off + sz) {
+                const int k = c - tb.lds_off;
+                const int lt = tb.t == tb.u ? k : k / Lu, lu = tb.t == tb.u ? k : k % Lu;
+                r0 = level_col[ds.lvl_off[tb.t] + lt];
+                c0 = level_col[ds.lvl_off[tb.u] + lu];
+                break;
+            }
+        }
+    }
+    if (r0 < 0 || c0 < 0) return;
+    H[(int64_t)r0 * ldh + c0] = s;
+    H[(int64_t)c0 * ldh + r0] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------
+static int oh_blocks(int64_t n) {
+    const int64_t want = (n + OH_THREADS * 4 - 1) / (OH_THREADS * 4);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, OH_MAX_BLOCKS));
+}
+
+int onehot_plan_p(const dlsa_onehot_plan* pl) { return pl->desc.p; }
+
+size_t onehot_workspace_bytes_impl(const dlsa_onehot_plan* pl, int64_t n) {
+    const int nb = oh_blocks(n);
+    size_t logit = align_up((size_t)nb * pl->desc.p * sizeof(double), 256) + align_up((size_t)nb * sizeof(double), 256);
+    size_t gram = 0;
+    constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
+    for (auto& r : pl->roles) gram = std::max(gram, (size_t)(r.cells + NDD));
+    gram = align_up(gram * nb * sizeof(double), 256) * pl->roles.size();
+    return std::max(logit, gram) + 256;
+}
+
+int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                           const double* y, const double* beta, int64_t n, double* w_out, double* g, double* loglik,
+                           void* ws, size_t ws_bytes, hipStream_t s) {
+    DLSA_REQUIRE(pl && y && beta && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
+                 "onehot logit pass: null argument");
+    const OhDesc& ds = pl->desc;
+    if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
+        set_error("onehot logit pass: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    const int nb = oh_blocks(n);
+    Arena ar(ws, ws_bytes);
+    double* gpart = (double*)ar.take((size_t)nb * ds.p * sizeof(double));
+    double* llpart = (double*)ar.take((size_t)nb * sizeof(double));
+    const size_t shm = (size_t)(2 * ds.p + 16) * sizeof(double) + (size_t)((ds.nlev_total + 1) & ~1) * sizeof(int);
+    hipLaunchKernelGGL(oh_logit_kernel, dim3(nb), dim3(OH_THREADS), shm, s, ds, (const int32_t*)pl->d_level_col, num, ldn, codes,
+                       ldc, y, beta, n, w_out, gpart, llpart);
+    DLSA_HIP_CHECK(hipGetLastError());
+    if (g || loglik) {
+        hipLaunchKernelGGL(oh_logit_finish_kernel, dim3((ds.p + 255) / 256), dim3(256), 0, s, (const double*)gpart,
+                           (const double*)llpart, nb, ds.p, g, loglik);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
+    return DLSA_OK;
+}
+
+int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s) {
+    DLSA_REQUIRE(pl && H && ldh >= pl->desc.p && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
+                 "onehot gram: null argument or ldh < p");
+    const OhDesc& ds = pl->desc;
+    if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
+        set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    const int nb = oh_blocks(n);
+    constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
+    size_t per_role = 0, max_cells = 0;
+    for (auto& r : pl->roles) { per_role = std::max(per_role, (size_t)(r.cells + NDD)); max_cells = std::max(max_cells, (size_t)r.cells); }
+    const int64_t role_stride = (int64_t)(align_up(per_role * nb * sizeof(double), 256) / sizeof(double));
+    const int nroles = (int)pl->roles.size();
+    DLSA_HIP_CHECK(hipMemset2DAsync(H, (size_t)ldh * sizeof(double), 0, (size_t)ds.p * sizeof(double), (size_t)ds.p, s));
+    const size_t shm = (max_cells + 16) * sizeof(double);
+    if (shm > 64 * 1024)
+        DLSA_HIP_CHECK(hipFuncSetAttribute((const void*)oh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(oh_gram_kernel, dim3(nb * nroles), dim3(OH_THREADS), shm, s, ds, (const OhRole*)pl->d_roles, nroles, nb,
+                       num, ldn, codes, ldc, w, n, (double*)ws, role_stride);
+    DLSA_HIP_CHECK(hipGetLastError());
+    for (int r = 0; r < nroles; ++r) {
+        const int per = pl->roles[r].cells + NDD;
+        hipLaunchKernelGGL(oh_gram_finish_kernel, dim3((per + 255) / 256), dim3(256), 0, s, ds, (const OhRole*)pl->d_roles, r, nb,
+                           (const int32_t*)pl->d_level_col, (const double*)ws, role_stride, H, ldh);
+    }
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+}  // namespace dlsa
+
+extern "C" {
+
+int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const int32_t* dense_src,
+                            const double* dense_shift, const double* dense_scale, const int32_t* dense_col,
+                            int nfactor, const int32_t* nlevels, const int32_t* level_col, dlsa_onehot_plan** out) {
+    using namespace dlsa;
+    DLSA_REQUIRE(out && p > 0 && p <= 2048, "onehot plan: bad p=%d", p);
+    DLSA_REQUIRE(ndense >= 0 && ndense <= OH_MAXD, "onehot plan: %d dense columns (intercept + numerics), at most %d", ndense, OH_MAXD);
+    DLSA_REQUIRE(nfactor >= 0 && nfactor <= OH_MAXF, "onehot plan: %d factors, at most %d", nfactor, OH_MAXF);
+    DLSA_REQUIRE(ndense == 0 || (dense_kind && dense_src && dense_shift && dense_scale && dense_col), "onehot plan: null dense descriptor");
+    DLSA_REQUIRE(nfactor == 0 || (nlevels && level_col), "onehot plan: null factor descriptor");
+    dlsa_onehot_plan* pl = new dlsa_onehot_plan();
+    OhDesc& ds = pl->desc;
+    memset(&ds, 0, sizeof(ds));
+    ds.p = p; ds.D = ndense; ds.f = nfactor;
+    pl->needs_num = false; pl->d_level_col = nullptr; pl->d_roles = nullptr;
+    for (int a = 0; a < ndense; ++a) pl->needs_num |= (dense_kind[a] == 1);
+    std::vector<char> used((size_t)p, 0);
+    auto fail = [&](const char* msg) { set_error("onehot plan: %s", msg); delete pl; return DLSA_ERR_INVALID; };
+    for (int a = 0; a < ndense; ++a) {
+        ds.dense_kind[a] = dense_kind[a]; ds.dense_src[a] = dense_src[a];
+        ds.dense_shift[a] = dense_shift[a]; ds.dense_scale[a] = dense_scale[a]; ds.dense_col[a] = dense_col[a];
+        if (dense_col[a] < 0 || dense_col[a] >= p || used[dense_col[a]]) return fail("dense column out of range or used twice");
+        used[dense_col[a]] = 1;
+    }
+    ds.lvl_off[0] = 0;
+    for (int t = 0; t < nfactor; ++t) {
+        if (nlevels[t] <= 0) return fail("a factor without levels");
+        ds.lvl_off[t + 1] = ds.lvl_off[t] + nlevels[t];
+    }
+    ds.nlev_total = ds.lvl_off[nfactor];
+    pl->h_level_col.assign(level_col, level_col + ds.nlev_total);
+    for (int c : pl->h_level_col) {
+        if (c < -1 || c >= p) return fail("level column out of range");
+        if (c >= 0) { if (used[c]) return fail("a column is produced twice"); used[c] = 1; }
+    }
+    for (int j = 0; j < p; ++j) if (!used[j]) return fail("a design column has no source");
+    // roles: the dense role (H_DD, H_D,dummy and as many pair tables as fit), then first-fit roles for the rest
+    auto tab_cells = [&](int t, int u) { return t == u ? nlevels[t] : nlevels[t] * nlevels[u]; };
+    struct Pend { int t, u, cells; };
+    std::vector<Pend> pend;
+    for (int t = 0; t < nfactor; ++t)
+        for (int u = t; u < nfactor; ++u) pend.push_back(Pend{t, u, tab_cells(t, u)});
+    std::sort(pend.begin(), pend.end(), [](const Pend& a, const Pend& b) { return a.cells > b.cells; });
+    const int budget = OH_LDS_BUDGET / (int)sizeof(double);
+    OhRole first; memset(&first, 0, sizeof(first));
+    first.with_dense = 1; first.dense_off = 0; first.cells = ds.nlev_total * OH_MAXD;
+    if (first.cells > budget) return fail("too many factor levels for the structured path");
+    pl->roles.push_back(first);
+    for (auto& pd : pend) {
+        if (pd.cells > budget) return fail("a factor-pair table exceeds the LDS budget: use the dense path");
+        OhRole* dst = nullptr;
+        for (auto& r : pl->roles) if (r.cells + pd.cells <= budget) { dst = &r; break; }
+        if (!dst) { OhRole nr; memset(&nr, 0, sizeof(nr)); pl->roles.push_back(nr); dst = &pl->roles.back(); }
+        dst->tab[dst->ntab++] = OhTable{pd.t, pd.u, dst->cells};
+        dst->cells += pd.cells;
+    }
+    if (hipMalloc((void**)&pl->d_level_col, std::max<size_t>(1, pl->h_level_col.size()) * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&pl->d_roles, pl->roles.size() * sizeof(OhRole)) != hipSuccess) {
+        set_error("onehot plan: hipMalloc failed"); delete pl; return DLSA_ERR_HIP;
+    }
+    if (!pl->h_level_col.empty())
+        DLSA_HIP_CHECK(hipMemcpy(pl->d_level_col, pl->h_level_col.data(), pl->h_level_col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    DLSA_HIP_CHECK(hipMemcpy(pl->d_roles, pl->roles.data(), pl->roles.size() * sizeof(OhRole), hipMemcpyHostToDevice));
+    *out = pl;
+    return DLSA_OK;
+}
+
+void dlsa_onehot_plan_destroy(dlsa_onehot_plan* pl) {
+    if (!pl) return;
+    if (pl->d_level_col) (void)hipFree(pl->d_level_col);
+    if (pl->d_roles) (void)hipFree(pl->d_roles);
+    delete pl;
+}
+
+int dlsa_onehot_plan_roles(const dlsa_onehot_plan* pl) { return pl ? (int)pl->roles.size() : 0; }
+
+size_t dlsa_onehot_workspace_bytes(const dlsa_onehot_plan* pl, int64_t n) {
+    if (!pl || n < 0) return 0;
+    return dlsa::onehot_workspace_bytes_impl(pl, n);
+}
+
+int dlsa_onehot_logit_pass_f64(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                               const double* y, const double* beta, int64_t n, double* w_out, double* g, double* loglik,
+                               void* ws, size_t ws_bytes, void* stream) {
+    return dlsa::onehot_logit_pass_impl(pl, num, ldn, codes, ldc, y, beta, n, w_out, g, loglik, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int dlsa_onehot_gram_f64(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                         const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, void* stream) {
+    return dlsa::onehot_gram_impl(pl, num, ldn, codes, ldc, w, n, H, ldh, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

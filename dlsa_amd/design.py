@@ -99,6 +99,39 @@ class DesignSpec:
             codes[:, fi] = c
         return num, codes, unknown
 
+    def onehot_plan(self):
+        """engine.OnehotPlan for the structured passes (gather / histogram instead of dense rows), or None when the
+        design does not qualify: more than 8 dense columns or 8 factors, or a factor-pair table too large for LDS."""
+        if getattr(self, "_oh_plan", False) is not False:
+            return self._oh_plan
+        self._oh_plan = None
+        dense = [j for j in range(self.p) if self.kind[j] in (0, 1)]
+        if len(dense) > 8 or len(self.factors) > 8 or len(self.factors) == 0:
+            return None
+        nlevels = [len(self.levels[f]) for f in self.factors]
+        level_col = []
+        for t, fct in enumerate(self.factors):
+            cols = [-1] * nlevels[t]
+            for j in self.dummy_cols:
+                if self.src[j] == t:
+                    cols[int(self.level[j])] = j
+            level_col += cols
+        try:
+            self._oh_plan = engine.OnehotPlan(self.p, [int(self.kind[j]) for j in dense], [int(self.src[j]) for j in dense],
+                                              [float(self.shift[j]) for j in dense], [float(self.scale[j]) for j in dense],
+                                              dense, nlevels, level_col)
+        except Exception:
+            self._oh_plan = None
+        return self._oh_plan
+
+    def missing_levels(self, codes):
+        """Names of the dummy columns whose level does not occur in `codes` (host array or device tensor [n, f])."""
+        if torch.is_tensor(codes):
+            present = [set(torch.unique(codes[:, t]).cpu().tolist()) for t in range(codes.shape[1])]
+        else:
+            present = [set(np.unique(codes[:, t]).tolist()) for t in range(codes.shape[1])]
+        return [self.names[j] for j in self.dummy_cols if int(self.level[j]) not in present[int(self.src[j])]]
+
     def device_arrays(self, device):
         key = str(device)
         if key not in self._dev:

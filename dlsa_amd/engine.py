@@ -246,3 +246,97 @@ def lars_path(Sigma0, b0, intercept, n, type="lar", eps=2.220446049250313e-16, m
                                 _ptr(ws), ws.numel(), _stream()))
     k = steps.value
     return {"AIC": aic[: k + 1], "BIC": bic[: k + 1], "beta": beta[: k + 1], "beta0": beta0[: k + 1]}
+
+
+class OnehotPlan:
+    """Handle of a structured one-hot design (include/dlsa_hip.h, dlsa_onehot_plan_create).  Host descriptor arrays:
+    dense_kind/src/col int32 [D], dense_shift/scale fp64 [D], nlevels int32 [f], level_col int32 [sum nlevels]."""
+
+    def __init__(self, p, dense_kind, dense_src, dense_shift, dense_scale, dense_col, nlevels, level_col):
+        import numpy as np
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("dlsa_amd runs on the GPU only (no CPU fallback)")
+        a = lambda v, t: np.ascontiguousarray(np.asarray(v, dtype=t))
+        dk, dsrc, dcol = a(dense_kind, np.int32), a(dense_src, np.int32), a(dense_col, np.int32)
+        dsh, dsc = a(dense_shift, np.float64), a(dense_scale, np.float64)
+        nl, lc = a(nlevels, np.int32), a(level_col, np.int32)
+        P = lambda x: ctypes.c_void_p(x.ctypes.data) if x.size else ctypes.c_void_p(0)
+        h = ctypes.c_void_p(0)
+        check(lib.dlsa_onehot_plan_create(int(p), int(dk.size), P(dk), P(dsrc), P(dsh), P(dsc), P(dcol), int(nl.size),
+                                          P(nl), P(lc), ctypes.byref(h)))
+        self._h, self._lib = h, lib
+        self.p, self.D, self.f = int(p), int(dk.size), int(nl.size)
+        self.roles = lib.dlsa_onehot_plan_roles(h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.dlsa_onehot_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _oh_args(plan, num, codes):
+    _require_gpu(num, codes)
+    if num is not None and num.dtype != torch.float64:
+        raise ValueError("num must be fp64")
+    if codes is not None and codes.dtype != torch.int32:
+        raise ValueError("codes must be int32")
+    return (_ptr(num), _rowmajor(num) if num is not None else 0, _ptr(codes), _rowmajor(codes) if codes is not None else 0)
+
+
+def onehot_logit_pass(plan, num, codes, y, beta, want_w=True, want_g=True, want_loglik=True):
+    """logit_pass on the raw representation of a one-hot design (num [n,q] fp64, codes [n,f] int32)."""
+    lib = _lib.load()
+    _require_gpu(y, beta)
+    n = y.numel()
+    dev = y.device
+    w = torch.empty((n,), dtype=torch.float64, device=dev) if want_w else None
+    g = torch.empty((plan.p,), dtype=torch.float64, device=dev) if want_g else None
+    ll = torch.empty((1,), dtype=torch.float64, device=dev) if want_loglik else None
+    ws = _workspace(lib.dlsa_onehot_workspace_bytes(plan._h, n), dev)
+    pn, ldn, pc, ldc = _oh_args(plan, num, codes)
+    check(lib.dlsa_onehot_logit_pass_f64(plan._h, pn, ldn, pc, ldc, _ptr(y), _ptr(beta), n, _ptr(w), _ptr(g), _ptr(ll),
+                                         _ptr(ws), ws.numel(), _stream()))
+    return w, g, ll
+
+
+def onehot_gram(plan, num, codes, w, n=None):
+    """X' diag(w) X of a one-hot design from its raw representation: the same p x p matrix as gram()."""
+    lib = _lib.load()
+    _require_gpu(w)
+    n = int(n if n is not None else (w.numel() if w is not None else (codes.shape[0] if codes is not None else num.shape[0])))
+    dev = (codes if codes is not None else num).device
+    H = torch.empty((plan.p, plan.p), dtype=torch.float64, device=dev)
+    ws = _workspace(lib.dlsa_onehot_workspace_bytes(plan._h, n), dev)
+    pn, ldn, pc, ldc = _oh_args(plan, num, codes)
+    check(lib.dlsa_onehot_gram_f64(plan._h, pn, ldn, pc, ldc, _ptr(w), n, _ptr(H), H.stride(0), _ptr(ws), ws.numel(), _stream()))
+    return H
+
+
+def onehot_irls_fit(plan, num, codes, y, part_offsets, tol=1e-13, max_iter=100):
+    """irls_fit on the raw representation of a one-hot design; same result dict."""
+    lib = _lib.load()
+    _require_gpu(y)
+    p = plan.p
+    offs = [int(v) for v in part_offsets]
+    K = len(offs) - 1
+    if offs[0] < 0 or offs[-1] > y.numel():
+        raise ValueError("part_offsets out of range")
+    dev = y.device
+    coef = torch.empty((K, p), dtype=torch.float64, device=dev)
+    smc = torch.empty((K, p), dtype=torch.float64, device=dev)
+    sig = torch.empty((K, p, p), dtype=torch.float64, device=dev)
+    max_rows = max(offs[k + 1] - offs[k] for k in range(K))
+    ws = _workspace(lib.dlsa_onehot_irls_workspace_bytes(plan._h, max_rows), dev)
+    c_offs = (ctypes.c_int64 * (K + 1))(*offs)
+    n_iter, status, ll = (ctypes.c_int * K)(), (ctypes.c_int * K)(), (ctypes.c_double * K)()
+    pn, ldn, pc, ldc = _oh_args(plan, num, codes)
+    rc = lib.dlsa_onehot_irls_fit_f64(plan._h, pn, ldn, pc, ldc, _ptr(y), c_offs, K, tol, max_iter, _ptr(coef), _ptr(sig),
+                                      _ptr(smc), n_iter, status, ll, _ptr(ws), ws.numel(), _stream())
+    if rc not in (0, 4, 5, 6):
+        check(rc)
+    return {"coef": coef, "Sig_invMcoef": smc, "Sig_inv": sig, "n_iter": list(n_iter), "status": list(status),
+            "loglik": list(ll), "rc": rc}

@@ -142,6 +142,41 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
                         sample_size=n)
 
 
+def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=None, structured=True, tol=1e-13,
+                        max_iter=100):
+    """Tensor fast path of the map step for a design given by its RAW columns: num [n, q] fp64 (columns in
+    spec.numeric_cols order) and codes [n, f] int32 level codes (DesignSpec.encode), both on the GPU.
+    With structured=True and a qualifying design (<= 8 dense columns, factor-pair tables that fit LDS) the fit runs on
+    the raw representation -- gather / histogram passes, the dense [n, p] matrix is never built (config 4: 76 B
+    instead of 2080 B per row and pass); otherwise the matrix is built once by the design kernel and the dense
+    kernels run.  Same MappedBlocks either way."""
+    if not y.is_cuda:
+        raise RuntimeError("fit_logistic_design runs on the GPU only (no CPU fallback)")
+    n = y.numel()
+    if part_offsets is None:
+        K = int(partition_num) if partition_num else 1
+        if K > 1:
+            idx = torch.arange(n, device=y.device)
+            order = torch.argsort(idx % K, stable=True)
+            num = num[order] if num is not None else None
+            codes = codes[order] if codes is not None else None
+            y = y[order]
+            counts = torch.bincount(idx % K, minlength=K).cpu().tolist()
+        else:
+            counts = [n]
+        part_offsets = np.concatenate([[0], np.cumsum(counts)])
+    plan = spec.onehot_plan() if structured else None
+    if plan is not None:
+        r = engine.onehot_irls_fit(plan, num.contiguous() if num is not None else None,
+                                   codes.contiguous() if codes is not None else None, y.contiguous(), part_offsets,
+                                   tol=tol, max_iter=max_iter)
+    else:
+        X, _ = spec.build(num, codes)
+        r = engine.irls_fit(X, y.contiguous(), part_offsets, tol=tol, max_iter=max_iter)
+    return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], spec.names, r["status"], r["n_iter"], r["loglik"],
+                        sample_size=n)
+
+
 def logistic_model_eval(sample_df, Y_name, par, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[],
                         data_info=[]):
     """Log-likelihood of every estimator column of `par` on one partition (models.py:151-225)."""

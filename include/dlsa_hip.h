@@ -156,6 +156,37 @@ int dlsa_design_f32(const float* num, int64_t ldn, int q, const int32_t* codes, 
                     const double* shift, const double* scale, int p, float* X, int64_t ldx,
                     int32_t* seen, void* stream);
 
+/* ---- structured passes for one-hot designs (N2) ----
+ * For a design [intercept | standardised numerics | one-hot factor levels] (the dummy path of logistic_model,
+ * dlsa/models.py:56-131) the logit pass is a gather, X'r a histogram and X'WX weighted co-occurrence counts: the
+ * passes below read the raw row (q doubles + f int32 codes) instead of the p-column dense row and produce the SAME
+ * w / g / loglik / p x p Hessian as dlsa_logit_pass_f64 / dlsa_gram_f64 on the matrix dlsa_design_f64 would build.
+ * A plan describes the design: `ndense` <= 8 dense columns (dense_kind 0 = the constant 1, 1 = numeric column
+ * dense_src standardised as (x - shift) / scale; dense_col = its output column) and `nfactor` <= 8 factors with
+ * nlevels[t] level codes each; level_col (concatenated over the factors) gives the output column of every level,
+ * -1 for a level without a column (baseline / dropped).  All descriptor arrays are HOST arrays.  Plan creation
+ * fails with DLSA_ERR_INVALID when a factor-pair table does not fit the per-workgroup LDS budget (use the dense
+ * path then).  Accumulation uses LDS atomics: results are not bit-reproducible run to run (last-bit differences). */
+typedef struct dlsa_onehot_plan dlsa_onehot_plan;
+int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const int32_t* dense_src,
+                            const double* dense_shift, const double* dense_scale, const int32_t* dense_col,
+                            int nfactor, const int32_t* nlevels, const int32_t* level_col, dlsa_onehot_plan** out);
+void dlsa_onehot_plan_destroy(dlsa_onehot_plan* plan);
+int dlsa_onehot_plan_roles(const dlsa_onehot_plan* plan);      /* workgroup roles of the Gram (each streams all rows) */
+size_t dlsa_onehot_workspace_bytes(const dlsa_onehot_plan* plan, int64_t n);
+int dlsa_onehot_logit_pass_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes,
+                               int64_t ldc, const double* y, const double* beta, int64_t n, double* w_out, double* g,
+                               double* loglik, void* ws, size_t ws_bytes, void* stream);
+int dlsa_onehot_gram_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes,
+                         int64_t ldc, const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes,
+                         void* stream);
+/* dlsa_irls_fit_f64 on the raw representation (same outputs, statuses and acceleration policy). */
+size_t dlsa_onehot_irls_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition);
+int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes,
+                             int64_t ldc, const double* y, const int64_t* part_offsets_host, int K, double tol,
+                             int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host,
+                             int* status_host, double* loglik_host, void* ws, size_t ws_bytes, void* stream);
+
 /* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
  * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */
 int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles);

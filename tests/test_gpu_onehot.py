@@ -1,0 +1,137 @@
+"""GPU: the structured one-hot passes (gather / histogram on raw numerics + level codes) must reproduce the dense
+kernels' results on the matrix the design kernel builds -- against the oracle, and against the reference's own
+dummy-path outputs (fixture F4)."""
+import numpy as np
+import pytest
+
+from f4_fixture import load_f4
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL_MLE = 1e-10
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def api():
+    assert torch.cuda.is_available()
+    import dlsa_amd
+    return dlsa_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _random_design(rng, n, q, nlevels, intercept=True, baseline=True):
+    """column plan: [1] + q numerics + every level of every factor except level 0 (the baseline)"""
+    kind, src, level, shift, scale = [], [], [], [], []
+    if intercept:
+        kind.append(0); src.append(0); level.append(0); shift.append(0.0); scale.append(1.0)
+    for a in range(q):
+        kind.append(1); src.append(a); level.append(0); shift.append(float(rng.normal())); scale.append(float(rng.uniform(0.5, 2)))
+    level_col, nl = [], []
+    for t, L in enumerate(nlevels):
+        nl.append(L)
+        for l in range(L):
+            if baseline and l == 0:
+                level_col.append(-1)
+            else:
+                level_col.append(len(kind))
+                kind.append(2); src.append(t); level.append(l); shift.append(0.0); scale.append(1.0)
+    p = len(kind)
+    num = rng.normal(size=(n, q)) * 2 + 0.5
+    codes = np.stack([rng.integers(0, L, n) for L in nlevels], 1).astype(np.int32) if nlevels else np.zeros((n, 0), np.int32)
+    arr = lambda v, t: np.asarray(v, dtype=t)
+    desc = (arr(kind, np.int32), arr(src, np.int32), arr(level, np.int32), arr(shift, np.float64), arr(scale, np.float64))
+    return p, num, codes, desc, nl, level_col
+
+
+def _plan(api, p, desc, nl, level_col):
+    from dlsa_amd import engine
+    kind, src, level, shift, scale = desc
+    dense = [j for j in range(p) if kind[j] in (0, 1)]
+    return engine.OnehotPlan(p, kind[dense], src[dense], shift[dense], scale[dense], dense, nl, level_col)
+
+
+@pytest.mark.parametrize("n,q,nlevels", [(5000, 7, (11, 6, 20)), (3001, 2, (3,)), (20000, 0, (5, 4)), (777, 7, (40, 40, 9, 2)),
+                                         (4000, 3, (110, 110, 20, 6)), (1, 1, (2,))])
+def test_onehot_passes_match_dense_oracle(api, orc, n, q, nlevels):
+    from dlsa_amd import engine
+    rng = np.random.default_rng(n + q)
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, q, nlevels)
+    codes[rng.integers(0, n, max(1, n // 50)), 0] = -1          # unknown level: no column
+    plan = _plan(api, p, desc, nl, level_col)
+    X, _ = orc.design_matrix(num, codes, *desc)
+    beta = rng.normal(size=p) * 0.4
+    y = (rng.random(n) < 0.5).astype(np.float64)
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    w, g, ll = engine.onehot_logit_pass(plan, dev(num) if q else None, dev(codes), dev(y), dev(beta))
+    assert rel_inf(w.cpu().numpy(), wo) < 1e-12
+    assert rel_inf(g.cpu().numpy(), go) < 1e-11 and abs(ll.item() - llo) < 1e-11 * abs(llo)
+    H = engine.onehot_gram(plan, dev(num) if q else None, dev(codes), dev(wo)).cpu().numpy()
+    Ho = orc.gram(X, wo)
+    assert np.max(np.abs(H - Ho)) < 1e-12 * np.max(np.abs(Ho))
+    assert np.array_equal(H, H.T)
+    if sum(nlevels) > 200:
+        assert plan.roles >= 2                                  # the 110 x 110 table gets a role of its own
+
+
+def test_onehot_plan_refuses_tables_beyond_lds(api):
+    from dlsa_amd import engine, _lib
+    rng = np.random.default_rng(0)
+    p, num, codes, desc, nl, level_col = _random_design(rng, 10, 1, (300, 300))
+    with pytest.raises(_lib.DlsaError, match="LDS budget"):
+        _plan(api, p, desc, nl, level_col)
+    p, num, codes, desc, nl, level_col = _random_design(rng, 10, 9, (3,))
+    with pytest.raises(_lib.DlsaError, match="dense columns"):
+        _plan(api, p, desc, nl, level_col)
+
+
+def test_structured_fit_matches_reference_dummy_path(api):
+    """fit_logistic_design on raw numerics + codes == the reference's logistic_model on the dummy path (F4)."""
+    z, df, dummy_info, baseline, data_info = load_f4()
+    spec = api.DesignSpec.from_reference(list(df.columns), "label", True, dummy_info, baseline, data_info)
+    assert spec.onehot_plan() is not None
+    num, codes, unknown = spec.encode(df, dummy_info)
+    assert not unknown and spec.missing_levels(codes) == []
+    y = dev(z["label"])
+    mb = api.fit_logistic_design(dev(num), dev(codes), y, spec)
+    assert ["par_id", "coef", "Sig_invMcoef"] + mb.names == list(z["columns"]) and mb.status == [0]
+    assert rel_inf(mb.coef[0].cpu().numpy(), z["coef_mle"]) < TOL_MLE
+    assert rel_inf(mb.Sig_inv[0].cpu().numpy(), z["Sig_inv_mle"]) < TOL_MLE
+    assert rel_inf(mb.Sig_invMcoef[0].cpu().numpy(), z["Sig_invMcoef_mle"]) < TOL_MLE
+    dense = api.fit_logistic_design(dev(num), dev(codes), y, spec, structured=False)
+    assert rel_inf(mb.coef[0].cpu().numpy(), dense.coef[0].cpu().numpy()) < 1e-11
+    sub = df[df["carrier"] != "CC"].reset_index(drop=True)
+    assert spec.missing_levels(spec.encode(sub, dummy_info)[1]) == ["carrier_CC"]
+
+
+def test_structured_fit_many_partitions_matches_dense(api, orc):
+    from dlsa_amd import engine
+    rng = np.random.default_rng(11)
+    n = 120_000
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, 4, (9, 5, 30))
+    plan = _plan(api, p, desc, nl, level_col)
+    X, _ = orc.design_matrix(num, codes, *desc)
+    beta = rng.normal(size=p) * 0.3
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(np.float64)
+    offs = [0, 30_000, 30_000, 75_000, n]                       # one empty partition
+    r = engine.onehot_irls_fit(plan, dev(num), dev(codes), dev(y), offs)
+    d = engine.irls_fit(dev(X), dev(y), offs)
+    assert r["status"] == d["status"] == [0, 4, 0, 0]
+    assert rel_inf(r["coef"].cpu().numpy(), d["coef"].cpu().numpy()) < 1e-10
+    assert rel_inf(r["Sig_inv"].cpu().numpy(), d["Sig_inv"].cpu().numpy()) < 1e-10
+    c, _, s = orc.logistic_model_block(X[:30_000], y[:30_000])
+    assert rel_inf(r["coef"][0].cpu().numpy(), c) < TOL_MLE and rel_inf(r["Sig_inv"][0].cpu().numpy(), s) < TOL_MLE
