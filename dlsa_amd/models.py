@@ -93,11 +93,29 @@ def logistic_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_
     UDF does (models.py:42-147).  Returns the p x (3+p) frame `par_id, coef, Sig_invMcoef,
     [intercept,] <features>`; a chunk that lacks an expected dummy level returns the all-zero
     block with a warning (models.py:84-91)."""
-    Xd, names = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
-    if Xd is None:
-        return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
     yd = torch.from_numpy(np.ascontiguousarray(sample_df[Y_name].to_numpy(dtype=np.float64))).cuda()
-    r = engine.irls_fit(Xd, yd, [0, Xd.shape[0]])
+    r = None
+    if len(dummy_info) > 0:
+        # dummy path: fit on the raw numerics + level codes when the design qualifies (structured passes, the dense
+        # one-hot matrix is never built); the missing-level check of models.py:80-91 runs on the codes
+        spec = DesignSpec.from_reference(list(sample_df.columns), Y_name, fit_intercept, dummy_info,
+                                         dummy_factors_baseline, data_info)
+        plan = spec.onehot_plan()
+        if plan is not None:
+            names = spec.names
+            num, codes, unknown = spec.encode(sample_df, dummy_info)
+            missing = spec.missing_levels(codes)
+            if missing or unknown:
+                shape = (len(sample_df), len(names) - (1 if fit_intercept else 0) - len(missing))
+                warnings.warn("Dummies:" + str(set(missing)) + "missing in this data chunk " + str(shape)
+                              + "Skip modeling this part of data.")
+                return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
+            r = engine.onehot_irls_fit(plan, torch.from_numpy(num).cuda(), torch.from_numpy(codes).cuda(), yd, [0, len(sample_df)])
+    if r is None:
+        Xd, names = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
+        if Xd is None:
+            return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
+        r = engine.irls_fit(Xd, yd, [0, Xd.shape[0]])
     st = r["status"][0]
     if st == 1:
         warnings.warn("logistic_model: Newton iterations did not converge (max_iter reached)")
