@@ -374,6 +374,16 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
                     if (nsub >= 200 * (int64_t)p && nsub >= 50000) {
                         int st_sub = 0, it_sub = 0, gr_sub = 0;
                         double ll_sub = 0.0;
+                        // ... and that subsample starts from ITS leading 1/sub_div (rows / 256): the first Newton
+                        // iterations from zero, the expensive ones, run on the smallest sample that still pins the MLE
+                        const int64_t nsub2 = nsub / sub_div;
+                        if (nsub2 >= 100 * (int64_t)p && nsub2 >= 20000) {
+                            rc = newton_run(d, nsub2, p, 1e-3, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub, &gr_sub,
+                                            &ll_sub, &fresh);
+                            if (rc) return rc;
+                            if (st_sub != DLSA_PART_OK) DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
+                            st_sub = 0; it_sub = 0; gr_sub = 0;
+                        }
                         rc = newton_run(d, nsub, p, 1e-6, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub,
                                         &gr_sub, &ll_sub, &fresh);
                         if (rc) return rc;
