@@ -26,7 +26,7 @@ constexpr int OH_MAXD = 8;            // dense columns (intercept + numerics) ha
 constexpr int OH_MAXF = 8;            // factors
 constexpr int OH_THREADS = 256;
 constexpr int OH_LDS_BUDGET = 120 * 1024;     // bytes of histogram tables per workgroup role
-constexpr int OH_MAX_BLOCKS = 1024;
+constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
 struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
     int t, u;                         // factor indices
@@ -173,21 +173,9 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
     if (threadIdx.x == 0) llpart[blockIdx.x] = sll;
 }
 
-// g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b]   (fixed order)
-__global__ __launch_bounds__(256) void oh_logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart,
-                                                              int nblocks, int p, double* __restrict__ g, double* __restrict__ loglik) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g && j < p) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += gpart[(int64_t)b * p + j];
-        g[j] = s;
-    }
-    if (loglik && blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += llpart[b];
-        *loglik = s;
-    }
-}
+// g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b] in a fixed order: the dense pass's finish kernel (logit.hip)
+__global__ void logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart, int nblocks,
+                                    int pitch, int p, double* __restrict__ g, double* __restrict__ loglik);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
@@ -257,20 +245,29 @@ __global__ __launch_bounds__(OH_THREADS) void oh_gram_kernel(OhDesc ds, const Oh
     }
 }
 
-// one thread per cell of a role image: sums the role's workgroup partials in a fixed order and scatters the value to
-// H (both triangles); cells whose (factor, level) has no column are dropped
+// 32 cells x 8 block groups per workgroup: group y sums the partials of blocks y, y+8, ... of its cell, the groups are
+// combined in a fixed order, and the value is scattered to H (both triangles); cells whose (factor, level) has no
+// column are dropped
 __global__ __launch_bounds__(256) void oh_gram_finish_kernel(OhDesc ds, const OhRole* __restrict__ roles, int role_id,
                                                              int blocks_per_role, const int32_t* __restrict__ level_col,
                                                              const double* __restrict__ partial, int64_t role_stride,
                                                              double* __restrict__ H, int64_t ldh) {
+    __shared__ double red[8][33];
     const OhRole& role = roles[role_id];
     constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
     const int per = role.cells + NDD;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= per) return;
-    const double* src = partial + (int64_t)role_id * role_stride + c;
+    const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double s = 0.0;
-    for (int b = 0; b < blocks_per_role; ++b) s += src[(int64_t)b * per];
+    if (c < per) {
+        const double* src = partial + (int64_t)role_id * role_stride + c;
+        for (int b = gy; b < blocks_per_role; b += 8) s += src[(int64_t)b * per];
+    }
+    red[gy][cx] = s;
+    __syncthreads();
+    if (gy != 0 || c >= per) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][cx];
     int r0 = -1, c0 = -1;
     if (c >= role.cells) {                                   // H_DD, upper triangle order
         if (!role.with_dense) return;
@@ -304,7 +301,7 @@ __global__ __launch_bounds__(256) void oh_gram_finish_kernel(OhDesc ds, const Oh
 // host
 // ---------------------------------------------------------------------------------------------------------------
 static int oh_blocks(int64_t n) {
-    const int64_t want = (n + OH_THREADS * 4 - 1) / (OH_THREADS * 4);
+    const int64_t want = (n + OH_THREADS * 16 - 1) / (OH_THREADS * 16);
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, OH_MAX_BLOCKS));
 }
 
@@ -339,8 +336,8 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
                        ldc, y, beta, n, w_out, gpart, llpart);
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        hipLaunchKernelGGL(oh_logit_finish_kernel, dim3((ds.p + 255) / 256), dim3(256), 0, s, (const double*)gpart,
-                           (const double*)llpart, nb, ds.p, g, loglik);
+        hipLaunchKernelGGL(logit_finish_kernel, dim3((ds.p + 63) / 64), dim3(1024), 0, s, (const double*)gpart,
+                           (const double*)llpart, nb, ds.p, ds.p, g, loglik);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;
@@ -370,7 +367,7 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
     DLSA_HIP_CHECK(hipGetLastError());
     for (int r = 0; r < nroles; ++r) {
         const int per = pl->roles[r].cells + NDD;
-        hipLaunchKernelGGL(oh_gram_finish_kernel, dim3((per + 255) / 256), dim3(256), 0, s, ds, (const OhRole*)pl->d_roles, r, nb,
+        hipLaunchKernelGGL(oh_gram_finish_kernel, dim3((per + 31) / 32), dim3(256), 0, s, ds, (const OhRole*)pl->d_roles, r, nb,
                            (const int32_t*)pl->d_level_col, (const double*)ws, role_stride, H, ldh);
     }
     DLSA_HIP_CHECK(hipGetLastError());
