@@ -196,6 +196,149 @@ __global__ __launch_bounds__(1024) void chol_tri_solve_kernel(const double* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Explicit inverse of the factor, for factors that are REUSED (frozen / inherited Hessians of the IRLS driver): the
+// triangular solves above are a chain of ~2p/32 dependent block steps in one workgroup (0.33 ms at p = 500, more than
+// a logit pass over 1e6 rows), whereas x = Linv' (Linv g) is two mat-vecs (~20 us).  Linv is built block row by
+// block row: Linv[i][i] = L_ii^-1,  Linv[i][j] = -L_ii^-1 sum_{k=j}^{i-1} L[i][k] Linv[k][j]  (one launch per block
+// row, one workgroup per block column).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tri_inverse_row_kernel(const double* __restrict__ L, int p, int bi,
+                                                              double* __restrict__ Linv) {
+    __shared__ double Dinv[NB][NB + 1];     // L_ii^-1
+    __shared__ double A[NB][NB + 1];        // L[i][k] block
+    __shared__ double B[NB][NB + 1];        // Linv[k][j] block
+    __shared__ double T[NB][NB + 1];        // accumulated sum
+    const int tid = threadIdx.x;
+    const int i0 = bi * NB, nbi = min(NB, p - i0);
+    const int bj = blockIdx.x;               // block column 0..bi
+    const int j0 = bj * NB;                  // (always a full block: j < i)
+    // inverse of the diagonal block: thread c < nbi builds column c by forward substitution (L_ii in A)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        A[r][c] = (r < nbi && c <= r) ? L[(int64_t)(i0 + r) * p + i0 + c] : 0.0;
+        Dinv[r][c] = 0.0;
+    }
+    __syncthreads();
+    if (tid < nbi) {
+        const int c = tid;
+        for (int r = c; r < nbi; ++r) {
+            double sacc = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) sacc -= A[r][k] * Dinv[k][c];
+            Dinv[r][c] = sacc / A[r][r];
+        }
+    }
+    __syncthreads();
+    if (bj == bi) {                          // the diagonal block of Linv (and zeros above it)
+        for (int e = tid; e < nbi * nbi; e += 256) Linv[(int64_t)(i0 + e / nbi) * p + i0 + e % nbi] = Dinv[e / nbi][e % nbi];
+        return;
+    }
+    const int r = tid / 8, cq = (tid % 8) * 4;            // thread: row r, columns cq..cq+3 of the 32 x 32 result
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int bk = bj; bk < bi; ++bk) {
+        const int k0 = bk * NB;
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int rr = e / NB, cc = e % NB;
+            A[rr][cc] = rr < nbi ? L[(int64_t)(i0 + rr) * p + k0 + cc] : 0.0;
+            B[rr][cc] = Linv[(int64_t)(k0 + rr) * p + j0 + cc];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+            const double a = A[r][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fma(a, B[k][cq + c], acc[c]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][cq + c] = acc[c];
+    __syncthreads();
+    if (r < nbi) {
+        double out[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k <= r; ++k) {
+            const double dv = Dinv[r][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = fma(dv, T[k][cq + c], out[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Linv[(int64_t)(i0 + r) * p + j0 + cq + c] = -out[c];
+    }
+}
+
+// x = Linv' (Linv rhs) in one workgroup; stats as chol_tri_solve_kernel
+__global__ __launch_bounds__(1024) void inv_apply_kernel(const double* __restrict__ Linv, int p,
+                                                         const double* __restrict__ rhs, const double* __restrict__ ref,
+                                                         double* __restrict__ xout, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* g = sm;              // p
+    double* y = sm + p;          // p
+    double* part = y + p;        // 2 * p (two row groups of phase 2)
+    double* red = part + 2 * p;  // 48
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    for (int i = tid; i < p; i += nth) g[i] = rhs[i];
+    __syncthreads();
+    for (int i = wave; i < p; i += nw) {                   // y_i = sum_{k<=i} Linv[i][k] g[k], a wave per row
+        const double* row = Linv + (int64_t)i * p;
+        double sacc = 0.0;
+        for (int k = lane; k <= i; k += 64) sacc = fma(row[k], g[k], sacc);
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) y[i] = sacc;
+    }
+    __syncthreads();
+    {                                                      // x_k = sum_{i>=k} Linv[i][k] y[i]: two row groups per column
+        const int half = nth / 2, grp = tid / half, t = tid % half;
+        for (int k = t; k < p; k += half) {
+            double sacc = 0.0;
+            for (int i = k + grp; i < p; i += 2) sacc = fma(Linv[(int64_t)i * p + k], y[i], sacc);
+            part[grp * p + k] = sacc;
+        }
+    }
+    __syncthreads();
+    double mx = 0.0, mr = 0.0;
+    int bad = 0;
+    for (int i = tid; i < p; i += nth) {
+        const double v = part[i] + part[p + i];
+        xout[i] = v;
+        mx = fmax(mx, fabs(v));
+        if (!isfinite(v)) bad = 1;
+        if (ref) mr = fmax(mr, fabs(ref[i]));
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, m, 64));
+        mr = fmax(mr, __shfl_xor(mr, m, 64));
+        bad |= __shfl_xor(bad, m, 64);
+    }
+    if (lane == 0) { red[wave] = mx; red[16 + wave] = mr; red[32 + wave] = (double)bad; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < nw; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); c = fmax(c, red[32 + k]); }
+        stats[0] = a;
+        stats[1] = b;
+        if (c != 0.0 && stats[2] == 0.0) stats[2] = 2.0;
+    }
+}
+
+int launch_tri_inverse(const double* L, int p, double* Linv, hipStream_t s) {
+    DLSA_HIP_CHECK(hipMemsetAsync(Linv, 0, (size_t)p * p * sizeof(double), s));
+    const int nblk = (p + NB - 1) / NB;
+    for (int bi = 0; bi < nblk; ++bi)
+        hipLaunchKernelGGL(tri_inverse_row_kernel, dim3(bi + 1), dim3(256), 0, s, L, p, bi, Linv);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+int launch_inv_apply(const double* Linv, int p, const double* rhs, const double* ref, double* xout, double* stats,
+                     hipStream_t s) {
+    const size_t shm = ((size_t)4 * p + 48) * sizeof(double);
+    DLSA_REQUIRE(shm <= 64 * 1024, "inverse apply: p=%d too large", p);
+    hipLaunchKernelGGL(inv_apply_kernel, dim3(1), dim3(p <= 64 ? 256 : 1024), shm, s, Linv, p, rhs, ref, xout, stats);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
 int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const double* rhs, int64_t stride_rhs,
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor) {

@@ -35,6 +35,8 @@ int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const doubl
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor);
 int launch_matvec(const double* A, int64_t lda, const double* x, int p, double* y, hipStream_t s);
+int launch_tri_inverse(const double* L, int p, double* Linv, hipStream_t s);
+int launch_inv_apply(const double* Linv, int p, const double* rhs, const double* ref, double* xout, double* stats, hipStream_t s);
 }  // namespace dlsa
 struct dlsa_onehot_plan;
 namespace dlsa {
@@ -50,7 +52,7 @@ int launch_axpby(const double* a, const double* b, double sc, int n, double* out
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
 
 struct IrlsLayout {
-    size_t w, g, beta, beta_prev, delta, stats, L, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
+    size_t w, g, beta, beta_prev, delta, stats, L, Linv, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
 };
 
 // pass_bytes: scratch of the data source's logit / Gram passes (they never run concurrently)
@@ -65,6 +67,7 @@ static IrlsLayout irls_layout(int64_t max_rows, int p, size_t pass_bytes) {
     l.delta = take((size_t)p * sizeof(double));
     l.stats = take(8 * sizeof(double));
     l.L = take((size_t)p * p * sizeof(double));
+    l.Linv = take((size_t)p * p * sizeof(double));
     l.pass_bytes = pass_bytes;
     l.pass = take(pass_bytes);
     l.qn_s = take((size_t)QN_PAIRS * p * sizeof(double));
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, c
 }
 
 struct IrlsBuffers {
-    double *w, *g, *beta, *prev, *delta, *stats, *L;
+    double *w, *g, *beta, *prev, *delta, *stats, *L, *Linv;
+    int* inv_valid;      // host flag: Linv is the inverse of the factor currently in L
     double *qn_s, *qn_y, *qn_rho, *qn_alpha, *qn_q, *qn_gprev;
     void* ws_pass; size_t ws_pass_bytes;
 };
@@ -185,6 +189,11 @@ struct IrlsData {
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
 // `H` receives every fresh Hessian.  On return with DLSA_PART_OK, *fresh says whether H was evaluated
 // at the final beta.  Returns a HIP/argument error code (0 = fine) and sets *status.
+static bool inv_enabled(int p) {
+    const char* e = getenv("DLSA_IRLS_INVERSE");
+    return (e ? atoi(e) != 0 : true) && ((size_t)4 * p + 48) * sizeof(double) <= 64 * 1024;
+}
+
 static bool qn_enabled() {
     const char* e = getenv("DLSA_IRLS_SECANT");
     return e ? atoi(e) != 0 : true;
@@ -244,7 +253,20 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
             if (rc) return rc;
         }
-        rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, fresh_now ? 0 : 1);
+        if (fresh_now) {
+            *b.inv_valid = 0;
+            rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
+        } else if (inv_enabled(p)) {
+            // a reused factor: invert it once, then every solve is two mat-vecs instead of 2p/32 dependent block steps
+            if (!*b.inv_valid) {
+                rc = launch_tri_inverse(b.L, p, b.Linv, s);
+                if (rc) return rc;
+                *b.inv_valid = 1;
+            }
+            rc = launch_inv_apply(b.Linv, p, rhs, b.beta, b.delta, b.stats, s);
+        } else {
+            rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 1);
+        }
         if (rc) return rc;
         if (qn_now && ord.m > 0) {
             hipLaunchKernelGGL(qn_post_kernel, dim3(1), dim3(1024), qn_shm, s, b.delta, (const double*)b.qn_s,
@@ -317,6 +339,9 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
     b.delta = (double*)(base + l.delta);
     b.stats = (double*)(base + l.stats);   // [0..2] solver stats, [3] loglik
     b.L = (double*)(base + l.L);
+    b.Linv = (double*)(base + l.Linv);
+    int inv_valid_flag = 0;
+    b.inv_valid = &inv_valid_flag;
     b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
     b.qn_alpha = (double*)(base + l.qn_alpha); b.qn_q = (double*)(base + l.qn_q); b.qn_gprev = (double*)(base + l.qn_gprev);
     b.ws_pass = base + l.pass;
@@ -405,6 +430,7 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
                             }
                             rc = launch_chol_solve(Hk, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
                             if (rc) return rc;
+                            *b.inv_valid = 0;
                             inherit = (double)nk / (double)nfac;
                             factor_rows_sub = nfac;
                         }

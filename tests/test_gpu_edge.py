@@ -100,7 +100,8 @@ def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
     offs = [0, 60_000, 120_000, n]                          # last partition large enough for the subsample start
     base = eng.irls_fit(X, y, offs)
     assert base["status"] == [0, 0, 0]
-    keys = ("DLSA_IRLS_SUBSAMPLE", "DLSA_IRLS_FREEZE", "DLSA_IRLS_WARM", "DLSA_IRLS_INHERIT", "DLSA_IRLS_SECANT")
+    keys = ("DLSA_IRLS_SUBSAMPLE", "DLSA_IRLS_FREEZE", "DLSA_IRLS_WARM", "DLSA_IRLS_INHERIT", "DLSA_IRLS_SECANT",
+            "DLSA_IRLS_INVERSE")
     try:
         for k in keys:
             os.environ[k] = "0"
