@@ -75,6 +75,28 @@ def test_wide_f32_plan_for_config5(lib):
     assert tiles.value / slots.value > 0.9
 
 
+def test_onehot_plan_validates_its_descriptor_without_a_gpu(lib):
+    """argument / capacity checks of the structured one-hot plan run before any HIP call"""
+    import numpy as np
+    from dlsa_amd import _lib
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    h = ctypes.c_void_p(0)
+    i32, f64 = np.int32, np.float64
+    # nine dense columns: over the limit of eight
+    k = np.ones(9, i32); z = np.zeros(9, f64); o = np.ones(9, f64); col = np.arange(9, dtype=i32)
+    rc = lib.dlsa_onehot_plan_create(9, 9, P(k), P(col), P(z), P(o), P(col), 0, None, None, ctypes.byref(h))
+    assert rc == 1 and "dense columns" in _lib.last_error()
+    # two 300-level factors: the 300 x 300 pair table does not fit the LDS budget
+    nl = np.array([300, 300], i32); lc = np.arange(600, dtype=i32)
+    rc = lib.dlsa_onehot_plan_create(600, 0, None, None, None, None, None, 2, P(nl), P(lc), ctypes.byref(h))
+    assert rc == 1 and "LDS budget" in _lib.last_error()
+    # a design column without a source
+    nl = np.array([3], i32); lc = np.array([-1, 0, 1], i32)
+    rc = lib.dlsa_onehot_plan_create(3, 0, None, None, None, None, None, 1, P(nl), P(lc), ctypes.byref(h))
+    assert rc == 1 and "no source" in _lib.last_error()
+    assert lib.dlsa_onehot_workspace_bytes(None, 10) == 0
+
+
 def test_engine_refuses_cpu_tensors():
     import torch
     from dlsa_amd import engine
