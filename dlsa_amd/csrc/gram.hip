@@ -446,15 +446,16 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
     }
 }
 
-// H[i][j] = (accumulate ? H[i][j] : 0) + sum_s partial[s][min(i,j)][max(i,j)]   (fixed order)
+// H[i][j] = H[j][i] = (accumulate ? H[i][j] : 0) + sum_s partial[s][i][j]  for i <= j  (fixed order).  Only the upper
+// triangle is read -- coalesced along j -- and each sum is written to both triangles (the mirrored write is the
+// uncoalesced one, but it is p^2/2 elements once instead of nslab strided reads per element).
 template <typename T>
 __global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int PP, int p,
                                    T* __restrict__ H, int64_t ldh, int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
-    if (j >= p) return;
-    const int r = min(i, j), c = max(i, j);
-    const T* src = partial + (int64_t)r * PP + c;
+    if (j >= p || j < i) return;
+    const T* src = partial + (int64_t)i * PP + j;
     T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
     const int64_t stride = (int64_t)PP * PP;
     int k = 0;
@@ -468,6 +469,10 @@ __global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int
     const T s = (s0 + s1) + (s2 + s3);
     T* dst = H + (int64_t)i * ldh + j;
     *dst = accumulate ? (*dst + s) : s;
+    if (i != j) {
+        T* mir = H + (int64_t)j * ldh + i;
+        *mir = accumulate ? (*mir + s) : s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
