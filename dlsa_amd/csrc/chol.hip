@@ -26,31 +26,41 @@ __global__ void chol_copy_lower_kernel(const double* __restrict__ A, int64_t lda
     L[e] = (k <= i) ? A[(int64_t)i * lda + k] : 0.0;
 }
 
-// factor the nb x nb diagonal block at (j0, j0) in place; one wave, lane = row
+// factor the nb x nb diagonal block at (j0, j0) in place; one wave, lane = row, the row lives in REGISTERS.
+// Per column j: the pivot is broadcast with a lane read, lane i > j forms l_ij, column j goes through a 32-entry
+// LDS buffer once (broadcast reads, no dependent read-modify-write chain) and every lane updates the rest of its
+// row: ~32 x (one divide + 31 FMAs).  (The first version kept the block in LDS and walked it with three barriers
+// per column: 36 us per block, more than half of a p = 500 factorisation and most of a p = 50 one.)
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ L, int p, int j0, int nb,
                                                        double* __restrict__ stats) {
-    __shared__ double S[NB][NB + 1];
+    __shared__ double col[2][NB];
     const int lane = threadIdx.x;
-    for (int e = lane; e < nb * nb; e += 64) S[e / nb][e % nb] = L[(int64_t)(j0 + e / nb) * p + j0 + e % nb];
-    __syncthreads();
+    double r[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        r[k] = (lane < nb && k <= lane) ? L[(int64_t)(j0 + lane) * p + j0 + k] : 0.0;
     int bad = 0;
-    for (int j = 0; j < nb; ++j) {
-        const double d = S[j][j];
-        double s;
-        if (!(d > 0.0) || !isfinite(d)) { bad = isfinite(d) ? 1 : 2; s = 1.0; }
-        else s = sqrt(d);
-        __syncthreads();
-        if (lane == j) S[j][j] = s;
-        if (lane > j && lane < nb) S[lane][j] /= s;
-        __syncthreads();
-        if (lane > j && lane < nb) {
-            const double lij = S[lane][j];
-            for (int k = j + 1; k <= lane; ++k) S[lane][k] -= lij * S[k][j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < nb) {                                        // wave-uniform
+            const double d = __shfl(r[j], j, 64);            // the pivot sits in lane j
+            double sq;
+            if (!(d > 0.0) || !isfinite(d)) { bad = isfinite(d) ? 1 : 2; sq = 1.0; }
+            else sq = sqrt(d);
+            const double lj = (lane == j) ? sq : r[j] / sq;  // l_ij for lane i >= j
+            if (lane >= j) r[j] = lj;
+            if (lane < NB) col[j & 1][lane] = (lane >= j && lane < nb) ? lj : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int k = j + 1; k < NB; ++k)
+                if (k <= lane) r[k] = fma(-lj, col[j & 1][k], r[k]);
         }
-        __syncthreads();
     }
-    for (int e = lane; e < nb * nb; e += 64)
-        if (e % nb <= e / nb) L[(int64_t)(j0 + e / nb) * p + j0 + e % nb] = S[e / nb][e % nb];
+    if (lane < nb) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (k <= lane) L[(int64_t)(j0 + lane) * p + j0 + k] = r[k];
+    }
     if (lane == 0 && bad) stats[2] = fmax(stats[2], (double)bad);
 }
 
