@@ -168,7 +168,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": R * bytes_row,
-                         "kernel": "dlsa::gram_kernel<double,true,2,0> (+gram_reduce_kernel, ~0.9 ms)", "kernel_ms": kern_ms,
+                         "kernel": "dlsa::gram_kernel<double,true,2,0> (+gram_reduce_kernel, ~0.1 ms)", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_row": flops_row, "algorithmic_bytes_per_row": bytes_row,
                          "hbm_GBps_algorithmic": R * bytes_row / (kern_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": R * bytes_row / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
