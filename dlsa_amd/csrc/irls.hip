@@ -172,6 +172,108 @@ __global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, c
     }
 }
 
+// One launch per quasi-Newton iteration: [push the new curvature pair] -> first loop -> x = Linv' (Linv q) -> second loop
+// -> delta and stats, all in one 1024-thread workgroup (the separate kernels above cost five launches and their gaps
+// per iteration, which is what small partitions are made of).
+__global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict__ beta, const double* __restrict__ prev,
+                                                       double* __restrict__ gprev, const double* __restrict__ g,
+                                                       double* __restrict__ S, double* __restrict__ Y, double* __restrict__ rho,
+                                                       QnOrder ord, int push_slot, int p, double gscale,
+                                                       const double* __restrict__ Linv, double* __restrict__ delta,
+                                                       double* __restrict__ stats) {
+    extern __shared__ double sm[];
+    double* qv = sm;                 // p
+    double* yv = sm + p;             // p
+    double* part = yv + p;           // 2p
+    double* red = part + 2 * p;      // 48
+    double* alpha = red + 48;        // QN_PAIRS
+    double* srho = alpha + QN_PAIRS; // QN_PAIRS
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    if (push_slot >= 0) {
+        double* s = S + (int64_t)push_slot * p;
+        double* y = Y + (int64_t)push_slot * p;
+        double sy = 0.0;
+        for (int i = tid; i < p; i += nth) {
+            const double sv = beta[i] - prev[i], yv2 = gprev[i] - g[i];
+            s[i] = sv; y[i] = yv2;
+            sy = fma(sv, yv2, sy);
+        }
+        sy = block_sum(sy, red);
+        if (tid == 0) rho[push_slot] = (sy > 0.0 && isfinite(sy)) ? 1.0 / sy : 0.0;
+        __threadfence_block();
+    }
+    for (int i = tid; i < p; i += nth) { const double gi = g[i]; qv[i] = gi; gprev[i] = gi; }
+    __syncthreads();
+    if (tid < QN_PAIRS) srho[tid] = rho[tid];
+    __syncthreads();
+    for (int k = ord.m - 1; k >= 0; --k) {
+        const int slot = ord.idx[k];
+        const double* s = S + (int64_t)slot * p;
+        const double* y = Y + (int64_t)slot * p;
+        double d = 0.0;
+        for (int i = tid; i < p; i += nth) d = fma(s[i], qv[i], d);
+        const double a = srho[slot] * block_sum(d, red);
+        if (tid == 0) alpha[slot] = a;
+        for (int i = tid; i < p; i += nth) qv[i] = fma(-a, y[i], qv[i]);
+        __syncthreads();
+    }
+    for (int i = tid; i < p; i += nth) qv[i] *= gscale;
+    __syncthreads();
+    for (int i = wave; i < p; i += nw) {                   // y_i = sum_{k<=i} Linv[i][k] q[k]
+        const double* row = Linv + (int64_t)i * p;
+        double sacc = 0.0;
+        for (int k = lane; k <= i; k += 64) sacc = fma(row[k], qv[k], sacc);
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) yv[i] = sacc;
+    }
+    __syncthreads();
+    {
+        const int half = nth / 2, grp = tid / half, t = tid % half;
+        for (int k = t; k < p; k += half) {
+            double sacc = 0.0;
+            for (int i = k + grp; i < p; i += 2) sacc = fma(Linv[(int64_t)i * p + k], yv[i], sacc);
+            part[grp * p + k] = sacc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p; i += nth) qv[i] = part[i] + part[p + i];     // r = H0^-1 q
+    __syncthreads();
+    for (int k = 0; k < ord.m; ++k) {
+        const int slot = ord.idx[k];
+        const double* s = S + (int64_t)slot * p;
+        const double* y = Y + (int64_t)slot * p;
+        double d = 0.0;
+        for (int i = tid; i < p; i += nth) d = fma(y[i], qv[i], d);
+        const double c = alpha[slot] - srho[slot] * block_sum(d, red);
+        for (int i = tid; i < p; i += nth) qv[i] = fma(c, s[i], qv[i]);
+        __syncthreads();
+    }
+    double mx = 0.0, mr = 0.0;
+    int bad = 0;
+    for (int i = tid; i < p; i += nth) {
+        const double v = qv[i];
+        delta[i] = v;
+        mx = fmax(mx, fabs(v));
+        if (!isfinite(v)) bad = 1;
+        mr = fmax(mr, fabs(beta[i]));
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, m, 64));
+        mr = fmax(mr, __shfl_xor(mr, m, 64));
+        bad |= __shfl_xor(bad, m, 64);
+    }
+    __syncthreads();
+    if (lane == 0) { red[wave] = mx; red[16 + wave] = mr; red[32 + wave] = (double)bad; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < nw; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); c = fmax(c, red[32 + k]); }
+        stats[0] = a;
+        stats[1] = b;
+        if (c != 0.0 && stats[2] == 0.0) stats[2] = 2.0;
+    }
+}
+
 struct IrlsBuffers {
     double *w, *g, *beta, *prev, *delta, *stats, *L, *Linv;
     int* inv_valid;      // host flag: Linv is the inverse of the factor currently in L
@@ -231,47 +333,65 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             ord.m = 0;                               // a new H0: the old pairs go
         }
         const bool qn_now = qn_on && !fresh_now;
+        int push_slot = -1;
         if (qn_now && qn_have_gprev) {               // the accepted step prev -> beta gives a curvature pair
-            const int slot = qn_next;
+            push_slot = qn_next;
             qn_next = (qn_next + 1) % QN_PAIRS;
-            hipLaunchKernelGGL(qn_push_kernel, dim3(1), dim3(1024), 0, s, (const double*)b.beta, (const double*)b.prev,
-                               (const double*)b.qn_gprev, (const double*)b.g, p, b.qn_s + (int64_t)slot * p,
-                               b.qn_y + (int64_t)slot * p, b.qn_rho + slot);
-            if (ord.m < QN_PAIRS) ord.idx[ord.m++] = slot;
-            else { for (int k = 0; k + 1 < QN_PAIRS; ++k) ord.idx[k] = ord.idx[k + 1]; ord.idx[QN_PAIRS - 1] = slot; }
+            if (ord.m < QN_PAIRS) ord.idx[ord.m++] = push_slot;
+            else { for (int k = 0; k + 1 < QN_PAIRS; ++k) ord.idx[k] = ord.idx[k + 1]; ord.idx[QN_PAIRS - 1] = push_slot; }
         }
-        if (qn_on) {                                  // remember the gradient at this beta for the next pair
-            DLSA_HIP_CHECK(hipMemcpyAsync(b.qn_gprev, b.g, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
-            qn_have_gprev = true;
-        }
-        const double* rhs = b.g;
-        if (qn_now && ord.m > 0) {
-            hipLaunchKernelGGL(qn_pre_kernel, dim3(1), dim3(1024), qn_shm, s, (const double*)b.g, (const double*)b.qn_s,
-                               (const double*)b.qn_y, (const double*)b.qn_rho, ord, p, gscale, b.qn_q, b.qn_alpha);
-            rhs = b.qn_q;
-        } else if (!fresh_now && gscale != 1.0) {
-            rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
-            if (rc) return rc;
-        }
-        if (fresh_now) {
-            *b.inv_valid = 0;
-            rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
-        } else if (inv_enabled(p)) {
-            // a reused factor: invert it once, then every solve is two mat-vecs instead of 2p/32 dependent block steps
+        const bool fused = qn_now && inv_enabled(p) && ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double) <= 64 * 1024;
+        if (fused) {
+            // reused factor, secant correction on: invert the factor once, then ONE launch per iteration
             if (!*b.inv_valid) {
                 rc = launch_tri_inverse(b.L, p, b.Linv, s);
                 if (rc) return rc;
                 *b.inv_valid = 1;
             }
-            rc = launch_inv_apply(b.Linv, p, rhs, b.beta, b.delta, b.stats, s);
-        } else {
-            rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 1);
-        }
-        if (rc) return rc;
-        if (qn_now && ord.m > 0) {
-            hipLaunchKernelGGL(qn_post_kernel, dim3(1), dim3(1024), qn_shm, s, b.delta, (const double*)b.qn_s,
-                               (const double*)b.qn_y, (const double*)b.qn_rho, (const double*)b.qn_alpha, ord, p, b.stats);
+            const size_t shm = ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double);
+            hipLaunchKernelGGL(qn_step_kernel, dim3(1), dim3(1024), shm, s, (const double*)b.beta, (const double*)b.prev,
+                               b.qn_gprev, (const double*)b.g, b.qn_s, b.qn_y, b.qn_rho, ord, push_slot, p, gscale,
+                               (const double*)b.Linv, b.delta, b.stats);
             DLSA_HIP_CHECK(hipGetLastError());
+            qn_have_gprev = true;
+        } else {
+            if (push_slot >= 0)
+                hipLaunchKernelGGL(qn_push_kernel, dim3(1), dim3(1024), 0, s, (const double*)b.beta, (const double*)b.prev,
+                                   (const double*)b.qn_gprev, (const double*)b.g, p, b.qn_s + (int64_t)push_slot * p,
+                                   b.qn_y + (int64_t)push_slot * p, b.qn_rho + push_slot);
+            if (qn_on) {                              // remember the gradient at this beta for the next pair
+                DLSA_HIP_CHECK(hipMemcpyAsync(b.qn_gprev, b.g, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
+                qn_have_gprev = true;
+            }
+            const double* rhs = b.g;
+            if (qn_now && ord.m > 0) {
+                hipLaunchKernelGGL(qn_pre_kernel, dim3(1), dim3(1024), qn_shm, s, (const double*)b.g, (const double*)b.qn_s,
+                                   (const double*)b.qn_y, (const double*)b.qn_rho, ord, p, gscale, b.qn_q, b.qn_alpha);
+                rhs = b.qn_q;
+            } else if (!fresh_now && gscale != 1.0) {
+                rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
+                if (rc) return rc;
+            }
+            if (fresh_now) {
+                *b.inv_valid = 0;
+                rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
+            } else if (inv_enabled(p)) {
+                // a reused factor: invert it once, then every solve is two mat-vecs instead of 2p/32 dependent block steps
+                if (!*b.inv_valid) {
+                    rc = launch_tri_inverse(b.L, p, b.Linv, s);
+                    if (rc) return rc;
+                    *b.inv_valid = 1;
+                }
+                rc = launch_inv_apply(b.Linv, p, rhs, b.beta, b.delta, b.stats, s);
+            } else {
+                rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 1);
+            }
+            if (rc) return rc;
+            if (qn_now && ord.m > 0) {
+                hipLaunchKernelGGL(qn_post_kernel, dim3(1), dim3(1024), qn_shm, s, b.delta, (const double*)b.qn_s,
+                                   (const double*)b.qn_y, (const double*)b.qn_rho, (const double*)b.qn_alpha, ord, p, b.stats);
+                DLSA_HIP_CHECK(hipGetLastError());
+            }
         }
         have_factor = true;
         double h[4];
