@@ -19,23 +19,82 @@ constexpr int LOGIT_THREADS = 256;
 constexpr int LOGIT_WAVES = LOGIT_THREADS / 64;
 constexpr int LOGIT_MAX_BLOCKS = 2048;
 
+// Cross-lane exchanges without LDS round trips (lane maps probed on the box, bench/probe_permlane.hip):
+//   xor 1, 2: DPP quad_perm;  xor 4: row_half_mirror then quad_perm [3,2,1,0];  xor 8: row_ror:8;
+//   xor 16 / 32: v_permlane16_swap / v_permlane32_swap (gfx950): swap(a, b) leaves in a' + b' exactly "the value I keep
+//   plus my partner's copy of it" for BOTH halves, so a halving step of the merged butterfly needs no select at all.
+// ds_bpermute costs an LDS round trip per exchange; the reduction is a chain of six dependent exchanges per batch.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+template <int M>
+__device__ __forceinline__ double dpp_xor_f64(double v) {      // value of lane ^ M, M in {1, 2, 4, 8}
+    if constexpr (M == 1) return dpp_mov_f64<0xB1>(v);
+    else if constexpr (M == 2) return dpp_mov_f64<0x4E>(v);
+    else if constexpr (M == 4) return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));
+    else return dpp_mov_f64<0x128>(v);
+}
+// (lane & M ? hi : lo) of this lane + the same quantity of lane ^ M
+template <int M>
+__device__ __forceinline__ double exch_add(double lo, double hi, int lane) {
+    if constexpr (M >= 16) {
+        const int alo = __double2loint(lo), ahi = __double2hiint(lo), blo = __double2loint(hi), bhi = __double2hiint(hi);
+        if constexpr (M == 32) {
+            const auto x = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+            return __hiloint2double(y[0], x[0]) + __hiloint2double(y[1], x[1]);
+        } else {
+            const auto x = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+            const auto y = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+            return __hiloint2double(y[0], x[0]) + __hiloint2double(y[1], x[1]);
+        }
+    } else {
+        const double s0 = lo + dpp_xor_f64<M>(lo), s1 = hi + dpp_xor_f64<M>(hi);
+        return (lane & M) ? s1 : s0;
+    }
+}
+template <int M>
+__device__ __forceinline__ double xor_add(double s) {           // s + s of lane ^ M
+    if constexpr (M >= 16) return exch_add<M>(s, s, 0);
+    else return s + dpp_xor_f64<M>(s);
+}
+template <int L>
+__device__ __forceinline__ double read_lane_f64(double v) {     // broadcast of lane L through SGPRs
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
+
 template <int RB>
 __device__ __forceinline__ double merged_reduce(double (&v)[RB], int lane) {
-    // after this, every lane holds the wave-sum of row rsel(lane)
-    int m = 32;
+    // after this, every lane holds the wave-sum of row rsel(lane): log2(RB) halving steps (masks 32, 16, ...), then
+    // plain xor-sums over the remaining masks
+    if constexpr (RB >= 2) {
 #pragma unroll
-    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) {
-        const int half = cnt / 2;
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const double mine = up ? v[i + half] : v[i];
-            const double other = up ? v[i] : v[i + half];
-            v[i] = mine + __shfl_xor(other, m, 64);
-        }
+        for (int i = 0; i < RB / 2; ++i) v[i] = exch_add<32>(v[i], v[i + RB / 2], lane);
     }
+    if constexpr (RB >= 4) {
+#pragma unroll
+        for (int i = 0; i < RB / 4; ++i) v[i] = exch_add<16>(v[i], v[i + RB / 4], lane);
+    }
+    if constexpr (RB >= 8) {
+#pragma unroll
+        for (int i = 0; i < RB / 8; ++i) v[i] = exch_add<8>(v[i], v[i + RB / 8], lane);
+    }
+    if constexpr (RB >= 16) {
+#pragma unroll
+        for (int i = 0; i < RB / 16; ++i) v[i] = exch_add<4>(v[i], v[i + RB / 16], lane);
+    }
+    if constexpr (RB >= 32) v[0] = exch_add<2>(v[0], v[1], lane);
+    static_assert(RB <= 32, "merged_reduce: at most 32 values");
     double s = v[0];
-    for (; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if constexpr (RB < 2) s = xor_add<32>(s);
+    if constexpr (RB < 4) s = xor_add<16>(s);
+    if constexpr (RB < 8) s = xor_add<8>(s);
+    if constexpr (RB < 16) s = xor_add<4>(s);
+    if constexpr (RB < 32) s = xor_add<2>(s);
+    s = xor_add<1>(s);
     return s;
 }
 
@@ -142,6 +201,20 @@ struct LogitArgs {
     int p;
 };
 
+// g += sum_i resid(row i) * x_i : the residual of row i sits in lane lane_of_row(i) and is broadcast through SGPRs
+template <int RB, int NC, int I>
+__device__ __forceinline__ void rank1_update(double resid, const double2 (&x)[RB][NC], double2 (&g)[NC]) {
+    if constexpr (I < RB) {
+        const double ri = read_lane_f64<lane_of_row<RB>(I)>(resid);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            g[c].x = fma(ri, x[I][c].x, g[c].x);
+            g[c].y = fma(ri, x[I][c].y, g[c].y);
+        }
+        rank1_update<RB, NC, I + 1>(resid, x, g);
+    }
+}
+
 template <int NC, int RB, bool VEC>
 __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     __shared__ double red[NC * 128 + 1];
@@ -217,15 +290,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
             // y log mu + (1-y) log(1-mu) = y*eta - softplus(eta)
             ll += yv * eta - sp;
         }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const double ri = __shfl(resid, lane_of_row<RB>(i), 64);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                g[c].x = fma(ri, x[i][c].x, g[c].x);
-                g[c].y = fma(ri, x[i][c].y, g[c].y);
-            }
-        }
+        rank1_update<RB, NC, 0>(resid, x, g);
     };
 
     int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave;
