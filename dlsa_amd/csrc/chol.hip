@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void inv_apply_kernel(const double* __restric
         const double* row = Linv + (int64_t)i * p;
         double sacc = 0.0;
         for (int k = lane; k <= i; k += 64) sacc = fma(row[k], g[k], sacc);
-        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        sacc = wave_allreduce_sum(sacc);
         if (lane == 0) y[i] = sacc;
     }
     __syncthreads();

@@ -44,6 +44,60 @@ struct Arena {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-wide fp64 exchanges and reductions WITHOUT LDS round trips (device code; lane maps probed on the box with
+// bench/probe_permlane.hip):  xor 1, 2: DPP quad_perm;  xor 4: row_half_mirror then quad_perm [3,2,1,0];
+// xor 8: row_ror:8;  xor 16 / 32: v_permlane16_swap / v_permlane32_swap (gfx950) -- swap(a, b) returns (a', b')
+// that hold, in both halves, {the value this lane keeps, its partner's copy of it}.  __shfl_xor compiles to
+// ds_bpermute: an LDS round trip per step, six dependent ones per reduction.
+// ---------------------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+template <int M>
+__device__ __forceinline__ double dpp_xor_f64(double v) {      // value of lane ^ M, M in {1, 2, 4, 8}
+    if constexpr (M == 1) return dpp_mov_f64<0xB1>(v);
+    else if constexpr (M == 2) return dpp_mov_f64<0x4E>(v);
+    else if constexpr (M == 4) return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));
+    else return dpp_mov_f64<0x128>(v);
+}
+// permlane swap of two doubles at distance M (16 or 32): a', b' as described above
+template <int M>
+__device__ __forceinline__ void swap_f64(double a, double b, double& a2, double& b2) {
+    const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    if constexpr (M == 32) {
+        const auto x = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        a2 = __hiloint2double(y[0], x[0]); b2 = __hiloint2double(y[1], x[1]);
+    } else {
+        const auto x = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto y = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        a2 = __hiloint2double(y[0], x[0]); b2 = __hiloint2double(y[1], x[1]);
+    }
+}
+struct WaveOpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct WaveOpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct WaveOpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+template <class Op>
+__device__ __forceinline__ double wave_allreduce(double s, Op op) {      // same pairing order as the xor butterfly 32..1
+    double a, b;
+    swap_f64<32>(s, s, a, b); s = op(a, b);
+    swap_f64<16>(s, s, a, b); s = op(a, b);
+    s = op(s, dpp_xor_f64<8>(s));
+    s = op(s, dpp_xor_f64<4>(s));
+    s = op(s, dpp_xor_f64<2>(s));
+    s = op(s, dpp_xor_f64<1>(s));
+    return s;
+}
+__device__ __forceinline__ double wave_allreduce_sum(double s) { return wave_allreduce(s, WaveOpSum()); }
+__device__ __forceinline__ double wave_allreduce_max(double s) { return wave_allreduce(s, WaveOpMax()); }
+__device__ __forceinline__ double wave_allreduce_min(double s) { return wave_allreduce(s, WaveOpMin()); }
+#endif
+
 constexpr int kNumXCD = 8;
 constexpr int kNumCU = 256;
 

@@ -91,7 +91,7 @@ static IrlsLayout irls_layout(int64_t max_rows, int p, size_t pass_bytes) {
 struct QnOrder { int idx[QN_PAIRS]; int m; };     // ring slots, oldest first
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = wave_allreduce_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
         const double* row = Linv + (int64_t)i * p;
         double sacc = 0.0;
         for (int k = lane; k <= i; k += 64) sacc = fma(row[k], qv[k], sacc);
-        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        sacc = wave_allreduce_sum(sacc);
         if (lane == 0) yv[i] = sacc;
     }
     __syncthreads();

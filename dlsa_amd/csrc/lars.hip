@@ -42,18 +42,10 @@ struct LarsArgs {
     int* n_steps;     // device scalar
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
-    return v;
-}
+// LDS-free wave reductions (common.h): this kernel is one long chain of dependent reductions
+__device__ __forceinline__ double wave_sum(double v) { return wave_allreduce_sum(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_allreduce_max(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_allreduce_min(v); }
 
 // block-wide reductions; `red` is LDS scratch of LARS_WAVES+1 doubles.  Result to all threads.
 __device__ double block_sum(double v, double* red) {

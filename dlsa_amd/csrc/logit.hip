@@ -19,38 +19,14 @@ constexpr int LOGIT_THREADS = 256;
 constexpr int LOGIT_WAVES = LOGIT_THREADS / 64;
 constexpr int LOGIT_MAX_BLOCKS = 2048;
 
-// Cross-lane exchanges without LDS round trips (lane maps probed on the box, bench/probe_permlane.hip):
-//   xor 1, 2: DPP quad_perm;  xor 4: row_half_mirror then quad_perm [3,2,1,0];  xor 8: row_ror:8;
-//   xor 16 / 32: v_permlane16_swap / v_permlane32_swap (gfx950): swap(a, b) leaves in a' + b' exactly "the value I keep
-//   plus my partner's copy of it" for BOTH halves, so a halving step of the merged butterfly needs no select at all.
-// ds_bpermute costs an LDS round trip per exchange; the reduction is a chain of six dependent exchanges per batch.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
-                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
-}
-template <int M>
-__device__ __forceinline__ double dpp_xor_f64(double v) {      // value of lane ^ M, M in {1, 2, 4, 8}
-    if constexpr (M == 1) return dpp_mov_f64<0xB1>(v);
-    else if constexpr (M == 2) return dpp_mov_f64<0x4E>(v);
-    else if constexpr (M == 4) return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));
-    else return dpp_mov_f64<0x128>(v);
-}
+// Cross-lane exchanges without LDS round trips: dpp_xor_f64 / swap_f64 of common.h.
 // (lane & M ? hi : lo) of this lane + the same quantity of lane ^ M
 template <int M>
 __device__ __forceinline__ double exch_add(double lo, double hi, int lane) {
     if constexpr (M >= 16) {
-        const int alo = __double2loint(lo), ahi = __double2hiint(lo), blo = __double2loint(hi), bhi = __double2hiint(hi);
-        if constexpr (M == 32) {
-            const auto x = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-            return __hiloint2double(y[0], x[0]) + __hiloint2double(y[1], x[1]);
-        } else {
-            const auto x = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-            const auto y = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-            return __hiloint2double(y[0], x[0]) + __hiloint2double(y[1], x[1]);
-        }
+        double a2, b2;
+        swap_f64<M>(lo, hi, a2, b2);        // no select: a2 + b2 is the kept value plus the partner's copy in both halves
+        return a2 + b2;
     } else {
         const double s0 = lo + dpp_xor_f64<M>(lo), s1 = hi + dpp_xor_f64<M>(hi);
         return (lane & M) ? s1 : s0;
