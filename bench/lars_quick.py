@@ -12,6 +12,9 @@ for p in (50, 200, 500, 1000):
     engine.lars_path(S, b, False, float(n)); torch.cuda.synchronize()
     ts = []
     for typ in ("lar", "lasso"):
-        t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
-        ts.append((typ, (time.perf_counter() - t) * 1e3, r["beta"].shape[0] - 1))
-    print("p=%d: " % p + "  ".join("%s %.2f ms (%d steps)" % t for t in ts))
+        reps = []
+        for _ in range(4):
+            t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t) * 1e3)
+        ts.append((typ, min(reps), max(reps), r["beta"].shape[0] - 1))
+    print("p=%d: " % p + "  ".join("%s %.2f ms (max %.2f; %d steps)" % t for t in ts))

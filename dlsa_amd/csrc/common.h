@@ -100,5 +100,6 @@ __device__ __forceinline__ double wave_allreduce_min(double s) { return wave_all
 
 constexpr int kNumXCD = 8;
 constexpr int kNumCU = 256;
+constexpr int kLdsBytes = 160 * 1024;     // LDS per CU (one workgroup may take all of it)
 
 }  // namespace dlsa

@@ -2,13 +2,17 @@
 // (reference: lars_lsa and its helpers, dlsa/lsa.py:8-212; selection by AIC/BIC, dlsa/dlsa.py:87-105).
 //
 // The path is strictly sequential over steps, so it runs as ONE persistent workgroup
-// (1024 threads = 16 waves on one CU) with the p x p matrices in HBM/L2 and all vectors in a
-// global scratch area; there are no host round trips inside the path.  Differences in
-// *method* (not in result) from the reference:
-//   * the reference keeps the Cholesky factor R of Sigma[active,active] and does two
-//     triangular solves per step (lsa.py:151); triangular solves are k dependent steps, so the
-//     kernel keeps R^{-1} instead (appending a column is two mat-vecs, lsa.py:12-32) and gets
-//     Gi1 = R^{-1} R^{-T} s from two mat-vecs;
+// (1024 threads = 16 waves on one CU) with the p x p matrices in HBM/L2, the short vectors of the inner
+// loops in LDS and no host round trips inside the path.  A step is a chain of dependent phases, each moving
+// only a few hundred KB, so what matters is the number of loads in flight per phase and the number of
+// phases, not bytes.  Differences in *method* (not in result) from the reference:
+//   * the reference keeps the Cholesky factor R of Sigma[active,active] and does two triangular solves per
+//     step (lsa.py:151); triangular solves are k dependent steps, so the kernel keeps R^{-1} (row-major, and
+//     its transpose, so both R^{-1}v and R^{-T}v read contiguous rows) and appends a column with two
+//     mat-vecs (lsa.py:12-32 updateR);
+//   * Gi1 = R^{-1} R^{-T} s (lsa.py:151-153) is carried along: appending column c = R^{-1}[:, k] with sign s_k
+//     adds one entry t_k = (s_k - r.t)/r_kk to t = R^{-T} s and the rank-one term c t_k to Gi1 -- O(k)
+//     per step instead of two O(k^2) mat-vecs;
 //   * a = w Sigma[active, inactive] (lsa.py:157-160) and Sigma[:,active] w (lsa.py:177) are the
 //     same vector u by symmetry and are computed once;
 //   * RSS_k = (b-beta_k)' Sigma (b-beta_k) (lsa.py:190-192) equals (b-beta_k).Cvec_k because
@@ -25,6 +29,12 @@ namespace dlsa {
 #endif
 constexpr int LARS_THREADS = DLSA_LARS_THREADS;
 constexpr int LARS_WAVES = LARS_THREADS / 64;
+constexpr int LARS_ROWGROUPS = LARS_THREADS / 16;
+#ifndef DLSA_LARS_TRIP
+#define DLSA_LARS_TRIP 2
+#endif
+constexpr int LARS_TRIP = DLSA_LARS_TRIP;      // loads per row, lane and trip in the triangular mat-vecs (four rows at a time)
+constexpr int LARS_SLACK = 16 * LARS_TRIP;     // zeroed elements after each factor matrix: the last rows' trips run into them
 
 struct LarsArgs {
     const double* Sigma0;   // p x p
@@ -33,8 +43,9 @@ struct LarsArgs {
     int p, intercept, type, max_steps;
     double n, eps;
     // workspace
-    double* S;        // m x m scaled Sigma
-    double* Rinv;     // m x m upper triangular inverse factor (active order)
+    double* S;        // m x ld scaled Sigma (ld = m rounded up to even; the pad column is zero)
+    double* Rinv;     // m x ld upper triangular inverse factor (active order), rows
+    double* RinvT;    // m x ld its transpose, rows
     double* vec;      // 12 vectors of length m (see kernel)
     int* ivec;        // 4 int vectors of length m
     // outputs
@@ -42,126 +53,264 @@ struct LarsArgs {
     int* n_steps;     // device scalar
 };
 
+// Optional phase timer (-DDLSA_LARS_PROF): thread 0 accumulates wall-clock ticks (100 MHz) per phase and prints them.
+#ifdef DLSA_LARS_PROF
+__shared__ long long lars_prof_t[16];
+__shared__ long long lars_prof_last;
+#define LARS_PROF_DECL do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) lars_prof_t[q_] = 0; lars_prof_last = wall_clock64(); } } while (0)
+#define LARS_TICK(i) do { if (threadIdx.x == 0) { const long long now_ = wall_clock64(); lars_prof_t[i] += now_ - lars_prof_last; lars_prof_last = now_; } } while (0)
+#else
+#define LARS_PROF_DECL
+#define LARS_TICK(i)
+#endif
+
 // LDS-free wave reductions (common.h): this kernel is one long chain of dependent reductions
 __device__ __forceinline__ double wave_sum(double v) { return wave_allreduce_sum(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_allreduce_max(v); }
 __device__ __forceinline__ double wave_min(double v) { return wave_allreduce_min(v); }
-
-// block-wide reductions; `red` is LDS scratch of LARS_WAVES+1 doubles.  Result to all threads.
-__device__ double block_sum(double v, double* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int k = 0; k < LARS_WAVES; ++k) s += red[k];
-    return s;
-}
-__device__ double block_max(double v, double* red) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = red[0];
-    for (int k = 1; k < LARS_WAVES; ++k) s = fmax(s, red[k]);
-    return s;
-}
-__device__ double block_min(double v, double* red) {
-    v = wave_min(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = red[0];
-    for (int k = 1; k < LARS_WAVES; ++k) s = fmin(s, red[k]);
+__device__ __forceinline__ double row16_sum(double s) {      // over the 16 lanes of one DPP row, result in all of them
+    s += dpp_xor_f64<8>(s);
+    s += dpp_xor_f64<4>(s);
+    s += dpp_xor_f64<2>(s);
+    s += dpp_xor_f64<1>(s);
     return s;
 }
 
-// Append variable `inew` to the factor (lsa.py:12-32 updateR, on R^{-1}).
-// Returns (to all threads) 1 if the rank grew, 0 if the column is machine-singular.
-__device__ int append_column(const double* __restrict__ S, double* __restrict__ Rinv, int m, int na,
-                             int inew, const int* __restrict__ active, double eps,
-                             double* __restrict__ xold, double* __restrict__ r, double* red) {
+// block-wide reductions of NV values at once; `red` is LDS scratch of 4*LARS_WAVES doubles.  Result to all threads.
+template <int NV, typename Op>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double* red, Op op) {
+    static_assert(NV <= 3, "red holds three values per wave");
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = wave_allreduce(v[q], op);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[q * LARS_WAVES + (threadIdx.x >> 6)] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = red[q * LARS_WAVES];
+        for (int k = 1; k < LARS_WAVES; ++k) s = op(s, red[q * LARS_WAVES + k]);
+        v[q] = s;
+    }
+}
+// two groups of values with different operators in one pass (NA + NB <= 4)
+template <int NA, typename OpA, int NB, typename OpB>
+__device__ __forceinline__ void block_reduce2(double (&va)[NA], OpA opa, double (&vb)[NB], OpB opb, double* red) {
+    static_assert(NA + NB <= 4, "red holds four values per wave");
+#pragma unroll
+    for (int q = 0; q < NA; ++q) va[q] = wave_allreduce(va[q], opa);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) vb[q] = wave_allreduce(vb[q], opb);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) red[q * LARS_WAVES + (threadIdx.x >> 6)] = va[q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) red[(NA + q) * LARS_WAVES + (threadIdx.x >> 6)] = vb[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        double s = red[q * LARS_WAVES];
+        for (int k = 1; k < LARS_WAVES; ++k) s = opa(s, red[q * LARS_WAVES + k]);
+        va[q] = s;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double s = red[(NA + q) * LARS_WAVES];
+        for (int k = 1; k < LARS_WAVES; ++k) s = opb(s, red[(NA + q) * LARS_WAVES + k]);
+        vb[q] = s;
+    }
+}
+__device__ double block_sum(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpSum()); return a[0]; }
+__device__ double block_max(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpMax()); return a[0]; }
+__device__ double block_min(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpMin()); return a[0]; }
+
+// y_i = sum_l M[i][l] x[l] over the stored part of row i of a triangular matrix: l in [0, i] (LOWER) or [i, n).
+// The other triangle of M is zero (and so are LARS_SLACK elements after the matrix), so nothing but x is masked:
+// a 16-lane group owns four consecutive rows at a time, forms four row pointers once and issues 4 x LARS_TRIP
+// loads per lane and trip at constant offsets from them.  x is in LDS and shared by the four rows;
+// emit(i, y_i) runs on one lane.
+template <bool LOWER, typename Emit>
+__device__ __forceinline__ void tri_matvec(const double* __restrict__ M, int ld, int n, const double* xs, Emit&& emit) {
+    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    for (int base = 4 * grp; base < n; base += 4 * LARS_ROWGROUPS) {
+        const int lo = (LOWER ? 0 : base) + l16, hi = LOWER ? min(base + 4, n) : n;
+        const double* __restrict__ r0 = M + (int64_t)base * ld + lo;
+        const double* __restrict__ r1 = M + (int64_t)min(base + 1, n - 1) * ld + lo;
+        const double* __restrict__ r2 = M + (int64_t)min(base + 2, n - 1) * ld + lo;
+        const double* __restrict__ r3 = M + (int64_t)min(base + 3, n - 1) * ld + lo;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int l = lo, o = 0; l < hi; l += 16 * LARS_TRIP, o += 16 * LARS_TRIP) {
+            double m0[LARS_TRIP], m1[LARS_TRIP], m2[LARS_TRIP], m3[LARS_TRIP];
+#pragma unroll
+            for (int c = 0; c < LARS_TRIP; ++c) {
+                m0[c] = r0[o + 16 * c]; m1[c] = r1[o + 16 * c]; m2[c] = r2[o + 16 * c]; m3[c] = r3[o + 16 * c];
+            }
+#pragma unroll
+            for (int c = 0; c < LARS_TRIP; ++c) {
+                const int lc = l + 16 * c;
+                const double x = lc < hi ? xs[min(lc, hi - 1)] : 0.0;
+                s0 = fma(m0[c], x, s0); s1 = fma(m1[c], x, s1); s2 = fma(m2[c], x, s2); s3 = fma(m3[c], x, s3);
+            }
+        }
+        s0 = row16_sum(s0); s1 = row16_sum(s1); s2 = row16_sum(s2); s3 = row16_sum(s3);
+        if (l16 == 0) {
+            emit(base, s0);
+            if (base + 1 < n) emit(base + 1, s1);
+            if (base + 2 < n) emit(base + 2, s2);
+            if (base + 3 < n) emit(base + 3, s3);
+        }
+    }
+}
+
+// out[j] = sum_{i<na} wv[i] S[act[i]][j] for all j < m (rows of the symmetric S, so this is S[:,act] wv).
+// A thread owns two adjacent columns (16-byte loads); the i range is split over G groups of JT2 threads with
+// eight independent loads in flight per thread; partial sums meet in LDS.
+__device__ void sym_matvec(const double* __restrict__ S, int ld, int m, int na, const double* wv, const int* act,
+                           double* __restrict__ out, double2* part, int JT2, int G) {
+    const int jx = threadIdx.x % JT2, g = threadIdx.x / JT2;
+    for (int j0 = 0; j0 < m; j0 += 2 * JT2) {
+        const int j = j0 + 2 * jx;
+        double2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+        if (j < m) {
+            const double* __restrict__ col = S + j;
+            int i = g;
+            for (; i + 7 * G < na; i += 8 * G) {
+                double2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const double2*>(col + (int64_t)act[i + q * G] * ld);
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    const double w0 = wv[i + q * G], w1 = wv[i + (q + 1) * G], w2 = wv[i + (q + 2) * G], w3 = wv[i + (q + 3) * G];
+                    a0.x = fma(w0, v[q].x, a0.x); a0.y = fma(w0, v[q].y, a0.y);
+                    a1.x = fma(w1, v[q + 1].x, a1.x); a1.y = fma(w1, v[q + 1].y, a1.y);
+                    a2.x = fma(w2, v[q + 2].x, a2.x); a2.y = fma(w2, v[q + 2].y, a2.y);
+                    a3.x = fma(w3, v[q + 3].x, a3.x); a3.y = fma(w3, v[q + 3].y, a3.y);
+                }
+            }
+            for (; i < na; i += G) {
+                const double2 v = *reinterpret_cast<const double2*>(col + (int64_t)act[i] * ld);
+                const double w0 = wv[i];
+                a0.x = fma(w0, v.x, a0.x); a0.y = fma(w0, v.y, a0.y);
+            }
+        }
+        part[g * JT2 + jx] = double2{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
+        __syncthreads();
+        if (g == 0 && j < m) {
+            double2 t = part[jx];
+            for (int q = 1; q < G; ++q) { t.x += part[q * JT2 + jx].x; t.y += part[q * JT2 + jx].y; }
+            out[j] = t.x;
+            if (j + 1 < m) out[j + 1] = t.y;
+        }
+        __syncthreads();
+    }
+}
+
+// State of the factor of Sigma[active,active] that the appends maintain.
+struct LarsFactor {
+    const double* __restrict__ S;
+    double* __restrict__ Rinv;
+    double* __restrict__ RinvT;
+    int ld;
+    int* active;  int* sh_act;         // active list (variable ids): global copy and LDS mirror
+    double* sgn;                       // sign of the correlation at entry, by active position
+    double* t;                         // R^{-T} sgn (LDS)
+    double* gi1;                       // R^{-1} R^{-T} sgn (LDS)
+    double* sh_x; double* sh_r;        // LDS scratch, m doubles each
+    double* red;
+};
+
+// Append variable `inew` with sign `sg` at position na (lsa.py:12-32 updateR, on R^{-1}) and extend t and Gi1;
+// tsq accumulates |t|^2 = sgn' Gi1 = 1/A^2.
+// Returns (to all threads) 1 if the rank grew, 0 if the column is machine-singular (nothing is modified then).
+__device__ int append_column(const LarsFactor& f, int na, int inew, double sg, double eps, double& tsq) {
     const int tid = threadIdx.x;
-    if (na == 0) {
-        __syncthreads();
-        const double d = S[(int64_t)inew * m + inew];
-        if (tid == 0) Rinv[0] = 1.0 / sqrt(d);
-        __syncthreads();
-        return 1;
-    }
-    for (int i = tid; i < na; i += LARS_THREADS) xold[i] = S[(int64_t)inew * m + active[i]];
+    const double* __restrict__ srow = f.S + (int64_t)inew * f.ld;
+    LARS_TICK(2);
+    for (int i = tid; i < na; i += LARS_THREADS) f.sh_x[i] = srow[f.sh_act[i]];
     __syncthreads();
-    // r = R^{-T} xold :  r[i] = sum_{l<=i} Rinv[l][i] xold[l]   (coalesced over i)
+    LARS_TICK(8);
+    // r = R^{-T} x
+    tri_matvec<true>(f.RinvT, f.ld, na, f.sh_x, [&](int i, double s) { f.sh_r[i] = s; });
+    __syncthreads();
+    LARS_TICK(9);
+    double acc[2] = {0.0, 0.0};
     for (int i = tid; i < na; i += LARS_THREADS) {
-        double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int l = 0;
-        for (; l + 3 <= i; l += 4) {
-            s = fma(Rinv[(int64_t)l * m + i], xold[l], s);
-            s1 = fma(Rinv[(int64_t)(l + 1) * m + i], xold[l + 1], s1);
-            s2 = fma(Rinv[(int64_t)(l + 2) * m + i], xold[l + 2], s2);
-            s3 = fma(Rinv[(int64_t)(l + 3) * m + i], xold[l + 3], s3);
-        }
-        for (; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], xold[l], s);
-        r[i] = (s + s1) + (s2 + s3);
+        const double ri = f.sh_r[i];
+        acc[0] = fma(ri, ri, acc[0]);
+        acc[1] = fma(ri, f.t[i], acc[1]);
     }
-    __syncthreads();
-    double part = 0.0;
-    for (int i = tid; i < na; i += LARS_THREADS) part += r[i] * r[i];
-    const double rr = block_sum(part, red);
-    double rpp = S[(int64_t)inew * m + inew] - rr;
-    if (rpp <= eps) return 0;            // rank did not grow: caller records an "ignore"
+    block_reduce(acc, f.red, WaveOpSum());
+    LARS_TICK(10);
+    double rpp = srow[inew] - acc[0];
+    if (na > 0 && rpp <= eps) return 0;  // rank did not grow: caller records an "ignore"
     rpp = sqrt(rpp);
-    // new column of R^{-1}: [-R^{-1} r / rpp ; 1/rpp]   (one wave per row, coalesced over l)
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int i = wave; i < na; i += LARS_WAVES) {
-        double s = 0.0, s1 = 0.0;
-        int l = i + lane;
-        for (; l + 64 < na; l += 128) {
-            s = fma(Rinv[(int64_t)i * m + l], r[l], s);
-            s1 = fma(Rinv[(int64_t)i * m + l + 64], r[l + 64], s1);
-        }
-        if (l < na) s = fma(Rinv[(int64_t)i * m + l], r[l], s);
-        s = wave_sum(s + s1);
-        if (lane == 0) Rinv[(int64_t)i * m + na] = -s / rpp;
+    const double tn = (sg - acc[1]) / rpp;      // new entry of R^{-T} sgn
+    tsq = fma(tn, tn, tsq);
+    // new column of R^{-1}: c = [-R^{-1} r / rpp ; 1/rpp];  Gi1 += c tn
+    double* __restrict__ Rinv = f.Rinv;
+    double* __restrict__ RinvT = f.RinvT;
+    const int ld = f.ld;
+    tri_matvec<false>(Rinv, ld, na, f.sh_r, [&](int i, double s) {
+        const double c = -s / rpp;
+        Rinv[(int64_t)i * ld + na] = c;
+        RinvT[(int64_t)na * ld + i] = c;
+        f.gi1[i] = fma(c, tn, f.gi1[i]);
+    });
+    LARS_TICK(11);
+    if (tid == 0) {
+        const double c = 1.0 / rpp;
+        Rinv[(int64_t)na * ld + na] = c;
+        RinvT[(int64_t)na * ld + na] = c;
+        f.gi1[na] = c * tn;
+        f.t[na] = tn;
+        f.sgn[na] = sg;
+        f.active[na] = inew;
+        f.sh_act[na] = inew;
     }
-    if (tid == 0) Rinv[(int64_t)na * m + na] = 1.0 / rpp;
     __syncthreads();
+    LARS_TICK(12);
     return 1;
 }
 
 __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
-    __shared__ double red[LARS_WAVES + 1];
+    __shared__ double red[4 * LARS_WAVES];
     __shared__ int sh_i[4];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];     // sh_w[m] | sh_part[LARS_THREADS] | sh_act[m]
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // sh_part[2*LARS_THREADS] | sh_w, sh_x, sh_r, sh_t, sh_gi1 [m] | sh_act[m]
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
     const int p = a.p;
     const int off = a.intercept ? 1 : 0;
     const int m = p - off;
+    const int ld = (m + 1) & ~1;
     const double eps = a.eps;
-    double* sh_w = dyn;
-    double* sh_part = dyn + m;
-    int* sh_act = reinterpret_cast<int*>(dyn + m + LARS_THREADS);
-    // thread groups for the mat-vec over the active set: JT threads along j, G groups along i
-    int JT = 64;
-    while (JT < m && JT < LARS_THREADS) JT *= 2;
-    const int G = LARS_THREADS / JT;
+    double2* sh_part = reinterpret_cast<double2*>(dyn);
+    double* sh_w = dyn + 2 * LARS_THREADS;
+    double* sh_x = sh_w + m;
+    double* sh_r = sh_x + m;
+    double* sh_t = sh_r + m;       // R^{-T} sgn
+    double* sh_gi1 = sh_t + m;     // R^{-1} R^{-T} sgn
+    int* sh_act = reinterpret_cast<int*>(sh_gi1 + m);
+    // thread groups for the mat-vec over the active set: JT2 threads along j (two columns each), G groups along i
+    int JT2 = 32;
+    while (2 * JT2 < m && JT2 < LARS_THREADS) JT2 *= 2;
+    const int G = LARS_THREADS / JT2;
     double* __restrict__ S = a.S;
-    double* __restrict__ Rinv = a.Rinv;
     double* b = a.vec + 0 * (int64_t)m;       // sign(b0)
     double* absb = a.vec + 1 * (int64_t)m;    // |b0|
     double* Cvec = a.vec + 2 * (int64_t)m;
     double* beta = a.vec + 3 * (int64_t)m;    // current (scaled) coefficients
     double* u = a.vec + 4 * (int64_t)m;       // Sigma[:,active] w
-    double* w = a.vec + 5 * (int64_t)m;       // by active position
+    double* zt = a.vec + 5 * (int64_t)m;      // lasso crossing distances, by active position
     double* sgn = a.vec + 6 * (int64_t)m;     // by active position
-    double* t1 = a.vec + 7 * (int64_t)m;
-    double* t2 = a.vec + 8 * (int64_t)m;
     double* a12 = a.vec + 9 * (int64_t)m;
     int* active = a.ivec + 0 * (int64_t)m;    // active list (variable ids)
     int* state = a.ivec + 1 * (int64_t)m;     // 0 inactive, 1 active, 2 ignored
     int* dropf = a.ivec + 2 * (int64_t)m;     // by active position
+    const LarsFactor fac{S, a.Rinv, a.RinvT, ld, active, sh_act, sgn, sh_t, sh_gi1, sh_x, sh_r, red};
 
+    LARS_PROF_DECL;
     // ---- prologue: intercept Schur complement (lsa.py:98-104) and rescaling (lsa.py:108-109)
     double a11 = 1.0, beta0c = 0.0;
     if (a.intercept) {
@@ -171,7 +320,10 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
     for (int j = tid; j < m; j += LARS_THREADS) {
         const double v = a.b0[j + off];
         absb[j] = fabs(v);
-        b[j] = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+        const double sb = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+        b[j] = sb;
+        sh_w[j] = sb;
+        sh_act[j] = j;
         beta[j] = 0.0;
         state[j] = 0;
     }
@@ -181,174 +333,115 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
         for (int j = tid; j < m; j += LARS_THREADS) part += a12[j] * a.b0[j + 1];
         beta0c = block_sum(part, red) / a11;
     }
-    for (int64_t e = tid; e < (int64_t)m * m; e += LARS_THREADS) {
-        const int i = (int)(e / m), j = (int)(e % m);
-        double v = a.Sigma0[(int64_t)(i + off) * a.lds0 + (j + off)];
-        if (a.intercept) v -= a12[i] * a12[j] / a11;
-        S[e] = absb[i] * v * absb[j];
+    for (int64_t e = tid; e < (int64_t)m * ld; e += LARS_THREADS) {
+        const int i = (int)(e / ld), j = (int)(e % ld);
+        double v = 0.0;
+        if (j < m) {
+            v = a.Sigma0[(int64_t)(i + off) * a.lds0 + (j + off)];
+            if (a.intercept) v -= a12[i] * a12[j] / a11;
+            v = absb[i] * v * absb[j];
+        }
+        S[e] = v;
     }
     __syncthreads();
-    // Cvec = b' Sigma  (lsa.py:114); one wave per column block would be strided, S is symmetric
-    // up to rounding, so use rows: Cvec[j] = sum_i b[i] S[i][j]
-    for (int j = tid; j < m; j += LARS_THREADS) {
-        double s = 0.0;
-        for (int i = 0; i < m; ++i) s = fma(b[i], S[(int64_t)i * m + j], s);
-        Cvec[j] = s;
-    }
-    __syncthreads();
+    // Cvec = b' Sigma  (lsa.py:114): S is symmetric up to rounding, so use rows: Cvec[j] = sum_i b[i] S[i][j]
+    sym_matvec(S, ld, m, m, sh_w, sh_act, Cvec, sh_part, JT2, G);
     int max_steps = a.max_steps > 0 ? a.max_steps : 8 * m;
-    // path row 0
+    // path row 0, and Cmax of the first step (lsa.py:128-129: max |Cvec| over the non-active variables)
+    double Cmax;
     {
-        double part = 0.0;
+        double rss[1] = {0.0}, cm[1] = {0.0};
         for (int j = tid; j < m; j += LARS_THREADS) {
             a.beta_path[j] = 0.0;
-            part += b[j] * Cvec[j];
+            const double c = Cvec[j];
+            rss[0] += b[j] * c;
+            cm[0] = fmax(cm[0], fabs(c));
         }
-        const double rss = block_sum(part, red);
+        if (tid == 0) { sh_i[0] = m; sh_i[2] = 0; }
+        block_reduce2(rss, WaveOpSum(), cm, WaveOpMax(), red);
+        Cmax = cm[0];
         if (tid == 0) {
-            a.aic[0] = rss; a.bic[0] = rss;
+            a.aic[0] = rss[0]; a.bic[0] = rss[0];
             a.beta0[0] = a.intercept ? beta0c : 0.0;
         }
     }
     int na = 0, k = 0;
     bool had_drops = false;
+    double tsq = 0.0;         // |R^{-T} sgn|^2 = sgn' Gi1 = 1/A^2, carried with the factor
+    LARS_TICK(0);
     while (k < max_steps && na < m) {
         ++k;
-        // ---- Cmax over the non-active variables (lsa.py:128-129)
-        double part = 0.0;
-        for (int j = tid; j < m; j += LARS_THREADS) if (state[j] != 1) part = fmax(part, fabs(Cvec[j]));
-        const double Cmax = block_max(part, red);
         if (!had_drops) {
-            // ---- new variables, in increasing index order (lsa.py:130-149)
+            // ---- new variables, in increasing index order (lsa.py:130-149).  One scan finds the first candidate
+            // and counts them all (sh_i[0] = m, sh_i[2] = 0 on entry); further scans only when there are ties.
             int start = 0;
             while (true) {
-                __syncthreads();
-                if (tid == 0) sh_i[0] = m;
-                __syncthreads();
-                int cand = m;
+                int cand = m, ncand = 0;
                 for (int j = start + tid; j < m; j += LARS_THREADS)
-                    if (state[j] == 0 && fabs(Cvec[j]) >= Cmax - eps) { cand = j; break; }
-                if (cand < m) atomicMin(&sh_i[0], cand);
+                    if (state[j] == 0 && fabs(Cvec[j]) >= Cmax - eps) { cand = min(cand, j); ++ncand; }
+                if (ncand > 0) { atomicMin(&sh_i[0], cand); atomicAdd(&sh_i[2], ncand); }
                 __syncthreads();
-                const int inew = sh_i[0];
+                const int inew = sh_i[0], left = sh_i[2] - 1;
                 if (inew >= m) break;
-                const int grew = append_column(S, Rinv, m, na, inew, active, eps, t1, t2, red);
+                const double c = Cvec[inew];
+                const int grew = append_column(fac, na, inew, (c > 0.0) ? 1.0 : ((c < 0.0) ? -1.0 : 0.0), eps, tsq);
                 if (tid == 0) {
-                    if (grew) {
-                        active[na] = inew;
-                        const double c = Cvec[inew];
-                        sgn[na] = (c > 0.0) ? 1.0 : ((c < 0.0) ? -1.0 : 0.0);
-                        state[inew] = 1;
-                    } else {
-                        state[inew] = 2;      // machine-singular: ignore (lsa.py:139-144)
-                    }
+                    state[inew] = grew ? 1 : 2;      // 2: machine-singular, ignored (lsa.py:139-144)
+                    sh_i[0] = m; sh_i[2] = 0;
                 }
                 if (grew) ++na;
                 start = inew + 1;
                 __syncthreads();
+                if (left <= 0) break;
             }
         }
         if (na == 0) break;   // nothing could enter (degenerate input)
-        // ---- equiangular direction: Gi1 = R^{-1} R^{-T} Sign (lsa.py:151-153)
-        for (int i = tid; i < na; i += LARS_THREADS) {
-            double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int l = 0;
-            for (; l + 3 <= i; l += 4) {
-                s = fma(Rinv[(int64_t)l * m + i], sgn[l], s);
-                s1 = fma(Rinv[(int64_t)(l + 1) * m + i], sgn[l + 1], s1);
-                s2 = fma(Rinv[(int64_t)(l + 2) * m + i], sgn[l + 2], s2);
-                s3 = fma(Rinv[(int64_t)(l + 3) * m + i], sgn[l + 3], s3);
-            }
-            for (; l <= i; ++l) s = fma(Rinv[(int64_t)l * m + i], sgn[l], s);
-            t1[i] = (s + s1) + (s2 + s3);
-        }
+        LARS_TICK(2);
+        // ---- equiangular direction from the carried Gi1 = R^{-1} R^{-T} Sign (lsa.py:151-153)
+        const double A = 1.0 / sqrt(tsq);
+        for (int i = tid; i < na; i += LARS_THREADS) sh_w[i] = A * sh_gi1[i];
         __syncthreads();
-        for (int i = wave; i < na; i += LARS_WAVES) {
-            double s = 0.0, s1 = 0.0;
-            int l = i + lane;
-            for (; l + 64 < na; l += 128) {
-                s = fma(Rinv[(int64_t)i * m + l], t1[l], s);
-                s1 = fma(Rinv[(int64_t)i * m + l + 64], t1[l + 64], s1);
-            }
-            if (l < na) s = fma(Rinv[(int64_t)i * m + l], t1[l], s);
-            s = wave_sum(s + s1);
-            if (lane == 0) t2[i] = s;
-        }
-        __syncthreads();
-        part = 0.0;
-        for (int i = tid; i < na; i += LARS_THREADS) part += t2[i] * sgn[i];
-        const double A = 1.0 / sqrt(block_sum(part, red));
-        for (int i = tid; i < na; i += LARS_THREADS) w[i] = A * t2[i];
-        __syncthreads();
-        // ---- u = Sigma[:,active] w  (rows of S, coalesced over j).  w and the active list are cached in
-        // LDS (no dependent global loads); the i range is split over G thread groups of JT threads.
-        for (int i = tid; i < na; i += LARS_THREADS) { sh_w[i] = w[i]; sh_act[i] = active[i]; }
-        __syncthreads();
-        {
-            const int jx = tid % JT, g = tid / JT;
-            for (int j0 = 0; j0 < m; j0 += JT) {
-                const int j = j0 + jx;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                if (j < m) {
-                    int i = g;
-                    for (; i + 3 * G < na; i += 4 * G) {
-                        s0 = fma(sh_w[i], S[(int64_t)sh_act[i] * m + j], s0);
-                        s1 = fma(sh_w[i + G], S[(int64_t)sh_act[i + G] * m + j], s1);
-                        s2 = fma(sh_w[i + 2 * G], S[(int64_t)sh_act[i + 2 * G] * m + j], s2);
-                        s3 = fma(sh_w[i + 3 * G], S[(int64_t)sh_act[i + 3 * G] * m + j], s3);
-                    }
-                    for (; i < na; i += G) s0 = fma(sh_w[i], S[(int64_t)sh_act[i] * m + j], s0);
-                }
-                sh_part[g * JT + jx] = (s0 + s1) + (s2 + s3);
-                __syncthreads();
-                if (g == 0 && j < m) {
-                    double t = sh_part[jx];
-                    for (int q = 1; q < G; ++q) t += sh_part[q * JT + jx];
-                    u[j] = t;
-                }
-                __syncthreads();
-            }
-        }
-        // ---- step length (lsa.py:154-162)
+        LARS_TICK(3);
+        // ---- u = Sigma[:,active] w
+        sym_matvec(S, ld, m, na, sh_w, sh_act, u, sh_part, JT2, G);
+        LARS_TICK(4);
+        // ---- step length (lsa.py:154-162) and lasso modification (lsa.py:164-173)
         double gamhat = Cmax / A;
+        double mins[2] = {INFINITY, INFINITY};
         if (na < m) {
-            double gm = INFINITY;
             for (int j = tid; j < m; j += LARS_THREADS) {
                 if (state[j] != 0) continue;
                 const double c = Cvec[j], aj = u[j];
                 const double g1 = (Cmax - c) / (A - aj);
                 const double g2 = (Cmax + c) / (A + aj);
-                if (g1 > eps) gm = fmin(gm, g1);
-                if (g2 > eps) gm = fmin(gm, g2);
+                if (g1 > eps) mins[0] = fmin(mins[0], g1);
+                if (g2 > eps) mins[0] = fmin(mins[0], g2);
             }
-            gm = block_min(gm, red);
-            gamhat = fmin(gm, gamhat);
         }
-        // ---- lasso modification (lsa.py:164-173)
-        had_drops = false;
         if (a.type == 1) {
-            double zm = INFINITY;
             for (int i = tid; i < na; i += LARS_THREADS) {
-                const double z = -beta[active[i]] / w[i];
-                t1[i] = z;
-                if (z > eps) zm = fmin(zm, z);
+                const double z = -beta[sh_act[i]] / sh_w[i];
+                zt[i] = z;
+                if (z > eps) mins[1] = fmin(mins[1], z);
             }
-            zm = block_min(zm, red);
-            if (zm < gamhat) {
-                gamhat = zm;
-                had_drops = true;
-                for (int i = tid; i < na; i += LARS_THREADS) dropf[i] = (t1[i] == zm) ? 1 : 0;
-            }
-            __syncthreads();
+        }
+        block_reduce(mins, red, WaveOpMin());
+        gamhat = fmin(mins[0], gamhat);
+        had_drops = false;
+        if (a.type == 1 && mins[1] < gamhat) {
+            gamhat = mins[1];
+            had_drops = true;
+            for (int i = tid; i < na; i += LARS_THREADS) dropf[i] = (zt[i] == gamhat) ? 1 : 0;
         }
         // ---- move (lsa.py:175-177)
-        for (int i = tid; i < na; i += LARS_THREADS) beta[active[i]] += gamhat * w[i];
+        for (int i = tid; i < na; i += LARS_THREADS) beta[sh_act[i]] += gamhat * sh_w[i];
         for (int j = tid; j < m; j += LARS_THREADS) Cvec[j] -= gamhat * u[j];
         __syncthreads();
+        LARS_TICK(5);
         // ---- drops (lsa.py:179-186)
         if (had_drops) {
             for (int i = tid; i < na; i += LARS_THREADS)
-                if (dropf[i]) { beta[active[i]] = 0.0; state[active[i]] = 0; }
+                if (dropf[i]) { beta[sh_act[i]] = 0.0; state[sh_act[i]] = 0; }
             __syncthreads();
             if (tid == 0) {
                 int q = 0;
@@ -358,36 +451,43 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
             }
             __syncthreads();
             const int keep = sh_i[1];
-            // rebuild R^{-1} for the remaining ordered active set
-            int nb = 0;
-            for (int i = 0; i < keep; ++i) {
-                append_column(S, Rinv, m, nb, active[i], active, 0.0, t1, t2, red);
-                ++nb;
-                __syncthreads();
-            }
+            // rebuild R^{-1}, t and Gi1 for the remaining ordered active set
+            tsq = 0.0;
+            for (int i = 0; i < keep; ++i) append_column(fac, i, active[i], sgn[i], 0.0, tsq);
             na = keep;
         }
+        LARS_TICK(6);
         // ---- record the path point: un-scaled beta (lsa.py:194-201), RSS, dof, AIC/BIC (:190-210)
-        double prss = 0.0, pdof = 0.0, pb0 = 0.0;
+        // and Cmax of the next step (lsa.py:128-129)
+        double rec[3] = {0.0, 0.0, 0.0}, cm[1] = {0.0};      // RSS, dof, a12 . beta
         for (int j = tid; j < m; j += LARS_THREADS) {
-            const double bj = beta[j];
+            const double bj = beta[j], cj = Cvec[j];
             const double ub = absb[j] * bj;
             a.beta_path[(int64_t)k * m + j] = ub;
-            prss += (b[j] - bj) * Cvec[j];
-            if (fabs(ub) > eps) pdof += 1.0;
-            if (a.intercept) pb0 += a12[j] * ub;
+            rec[0] += (b[j] - bj) * cj;
+            if (fabs(ub) > eps) rec[1] += 1.0;
+            if (a.intercept) rec[2] += a12[j] * ub;
+            if (state[j] != 1) cm[0] = fmax(cm[0], fabs(cj));
         }
-        const double rss = block_sum(prss, red);
-        const double dof = block_sum(pdof, red);
-        double b0k = 0.0;
-        if (a.intercept) b0k = beta0c - block_sum(pb0, red) / a11;
+        block_reduce2(rec, WaveOpSum(), cm, WaveOpMax(), red);
+        Cmax = cm[0];
         if (tid == 0) {
-            a.aic[k] = rss + 2.0 * dof;
-            a.bic[k] = rss + log(a.n) * dof;
-            a.beta0[k] = b0k;
+            a.aic[k] = rec[0] + 2.0 * rec[1];
+            a.bic[k] = rec[0] + log(a.n) * rec[1];
+            a.beta0[k] = a.intercept ? beta0c - rec[2] / a11 : 0.0;
         }
         __syncthreads();
+        LARS_TICK(7);
     }
+#ifdef DLSA_LARS_PROF
+    if (tid == 0) {
+        printf("LARS_PROF p=%d steps=%d us: prologue %.0f select %.0f direction %.0f u %.0f step %.0f drops %.0f record %.0f |",
+               p, k, lars_prof_t[0] * 0.01, lars_prof_t[2] * 0.01, lars_prof_t[3] * 0.01, lars_prof_t[4] * 0.01, lars_prof_t[5] * 0.01,
+               lars_prof_t[6] * 0.01, lars_prof_t[7] * 0.01);
+        printf(" append: gather %.0f r %.0f reduce %.0f column %.0f tail %.0f\n", lars_prof_t[8] * 0.01, lars_prof_t[9] * 0.01,
+               lars_prof_t[10] * 0.01, lars_prof_t[11] * 0.01, lars_prof_t[12] * 0.01);
+    }
+#endif
     if (tid == 0) *a.n_steps = k;
 }
 
@@ -397,8 +497,8 @@ extern "C" {
 
 size_t dlsa_lars_workspace_bytes(int p) {
     if (p <= 0) return 0;
-    const size_t m = (size_t)p;
-    return dlsa::align_up(m * m * 8, 256) * 2 + dlsa::align_up(12 * m * 8, 256) + dlsa::align_up(4 * m * 4, 256) + 512;
+    const size_t m = (size_t)p, ld = (m + 1) & ~(size_t)1;
+    return dlsa::align_up(m * ld * 8, 256) + dlsa::align_up((m * ld + dlsa::LARS_SLACK) * 8, 256) * 2 + dlsa::align_up(12 * m * 8, 256) + dlsa::align_up(4 * m * 4, 256) + 512;
 }
 
 int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p, int intercept, double n,
@@ -415,18 +515,24 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     }
     hipStream_t s = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
-    const size_t m = (size_t)p;
+    const size_t m = (size_t)p, ld = (m + 1) & ~(size_t)1;
     LarsArgs a;
     a.Sigma0 = Sigma0; a.b0 = b0; a.lds0 = lds; a.p = p; a.intercept = intercept ? 1 : 0; a.type = type;
     a.max_steps = max_steps; a.n = n; a.eps = eps;
-    a.S = (double*)ar.take(m * m * 8);
-    a.Rinv = (double*)ar.take(m * m * 8);
+    a.S = (double*)ar.take(m * ld * 8);
+    a.Rinv = (double*)ar.take((m * ld + LARS_SLACK) * 8);
+    a.RinvT = (double*)ar.take((m * ld + LARS_SLACK) * 8);
     a.vec = (double*)ar.take(12 * m * 8);
     a.ivec = (int*)ar.take(4 * m * 4);
     a.n_steps = (int*)ar.take(256);
     a.beta_path = beta_path; a.beta0 = beta0; a.aic = aic; a.bic = bic;
-    DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, m * m * 8, s));
-    const size_t shm = ((size_t)(p - (intercept ? 1 : 0)) * 12 + (size_t)LARS_THREADS * 8 + 64);
+    // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
+    DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
+    DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
+    const size_t shm = (size_t)LARS_THREADS * 16 + (size_t)(p - (intercept ? 1 : 0)) * 44 + 64;
+    DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
+    if (shm > 48 * 1024)
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
     DLSA_HIP_CHECK(hipGetLastError());
     int steps = 0;

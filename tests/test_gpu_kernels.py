@@ -315,6 +315,29 @@ def test_lars_intercept_matches_oracle(eng, orc):
     assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-8
 
 
+def _correlated_lsa_problem(p, rho, seed):
+    rng = np.random.default_rng(seed)
+    n = 6 * p
+    L = rng.standard_normal((3, p))
+    X = np.sqrt(1 - rho) * rng.standard_normal((n, p)) + np.sqrt(rho) * (rng.standard_normal((n, 3)) @ L)
+    S = X.T @ ((rng.random(n) * 0.25)[:, None] * X)
+    return S, rng.standard_normal(p), n
+
+
+@pytest.mark.parametrize("p,rho,seed,intercept", [(120, 0.98, 5, False), (257, 0.97, 11, False), (120, 0.98, 5, True)])
+def test_lars_lasso_drops_wide_matches_oracle(eng, orc, p, rho, seed, intercept):
+    """lsa.py:164-186 at sizes where the factor spans several row groups of the device mat-vecs: lasso drops
+    (the factor, R^{-T} s and Gi1 are rebuilt), an odd column count (padded row stride) and the intercept."""
+    S, b, n = _correlated_lsa_problem(p, rho, seed)
+    ro = orc.lars_lsa(S, b, intercept, n, type="lasso")
+    assert ro["beta"].shape[0] > (p - int(intercept)) + 1          # the path has drops
+    r = eng.lars_path(dev(S), dev(b), intercept, float(n), type="lasso")
+    assert r["beta"].shape == ro["beta"].shape
+    assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
+    assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7 or not intercept
+    assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
+
+
 def test_loglik_columns(eng, orc):
     rng = np.random.default_rng(8)
     n, p = 5000, 60
