@@ -21,6 +21,8 @@
 //     Givens-downdating R (lsa.py:35-80); the factor of the remaining ordered set is unique.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <algorithm>
 
 namespace dlsa {
 
@@ -34,7 +36,8 @@ constexpr int LARS_ROWGROUPS = LARS_THREADS / 16;
 #define DLSA_LARS_TRIP 2
 #endif
 constexpr int LARS_TRIP = DLSA_LARS_TRIP;      // loads per row, lane and trip in the triangular mat-vecs (four rows at a time)
-constexpr int LARS_SLACK = 16 * LARS_TRIP;     // zeroed elements after each factor matrix: the last rows' trips run into them
+constexpr int LARS_SLACK = 256;                // zeroed elements after each factor matrix: the last rows' trips run into them
+constexpr int LARS_MAX_WGS = 32;               // workgroups of the grid kernel (the barrier costs ~35 ns per workgroup beyond 16)
 
 struct LarsArgs {
     const double* Sigma0;   // p x p
@@ -51,6 +54,11 @@ struct LarsArgs {
     // outputs
     double* beta_path; double* beta0; double* aic; double* bic;
     int* n_steps;     // device scalar
+    // multi-workgroup kernel only
+    double* rbuf;     // m: r = R^{-T} x of the current append, gathered from the row owners
+    double* wbuf;     // m: equiangular weights, gathered from the row owners
+    double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
+    unsigned* bar;    // grid barrier counter (zero at launch)
 };
 
 // Optional phase timer (-DDLSA_LARS_PROF): thread 0 accumulates wall-clock ticks (100 MHz) per phase and prints them.
@@ -491,6 +499,385 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
     if (tid == 0) *a.n_steps = k;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Multi-workgroup variant.  One CU streams ~110 GB/s from L2, which bounds the single-workgroup kernel from
+// p ~ 500 up; here G workgroups (one per CU, cooperative launch) share the O(k^2) and O(kp) mat-vecs of a step and
+// replicate everything that is O(p): every workgroup keeps Cvec, beta, t, the active list ... in its own LDS, runs the
+// same instructions on the same numbers and so takes the same decisions -- no broadcast of scalars is ever needed.
+// Position i of the active list (row i of R^{-1} and of its transpose, Gi1[i], w[i]) belongs to workgroup i % G.
+// A step has two grid barriers (~1.3 us for 16 workgroups on gfx950, agent-scope release/acquire on a counter):
+//   append:  x = Sigma[new, active] (replicated gather);  r_i = (R^{-T} x)_i by the row owners -> rbuf
+//            -- barrier 1 --   everyone reads r; r.r and r.t give r_kk and t_k (replicated)
+//            c_i = -(R^{-1} r)_i / r_kk, Gi1_i += c_i t_k, w_i = A Gi1_i by the row owners -> wbuf
+//   u:       partial Sigma[own rows of the active set, :]' w_own -> upart[g][:]
+//            -- barrier 2 --   everyone reads w and sums the G partial vectors in a fixed order
+//   step length, lasso crossing, move, drops, Cmax: replicated in LDS;  workgroup 0 writes the path record.
+// A further append without an intervening barrier (ties, the rebuild after a lasso drop) first waits for the
+// column writes of the previous one.  The workgroups are left where the dispatcher puts them (round-robin over the
+// XCDs): confining them to one XCD makes the exchanged vectors L2 hits but was measured slower overall
+// (p=1000, 16 workgroups: 29.9 vs 22.2 ms) -- eight L2s hold more of Sigma and R^{-1} than one.
+
+__device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned nwg, unsigned& phase) {
+    __syncthreads();                 // this workgroup's global stores have reached L2 (vmcnt(0) before the barrier)
+    if (threadIdx.x == 0) {
+        ++phase;
+        const unsigned target = phase * nwg;
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+// y_i over the stored part of row i for the rows i = first, first + stride, ... < n this workgroup owns: one wave per
+// row, four loads per lane and trip at constant offsets (zero triangle + slack: only x is masked).
+template <bool LOWER, typename Emit>
+__device__ __forceinline__ void tri_matvec_rows(const double* __restrict__ M, int ld, int n, const double* xs, int first,
+                                                int stride, Emit&& emit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = first + wave * stride; i < n; i += LARS_WAVES * stride) {
+        const int lo = (LOWER ? 0 : i) + lane, hi = LOWER ? i + 1 : n;
+        const double* __restrict__ row = M + (int64_t)i * ld + lo;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int l = lo, o = 0; l < hi; l += 256, o += 256) {
+            const double m0 = row[o], m1 = row[o + 64], m2 = row[o + 128], m3 = row[o + 192];
+            const double x0 = xs[l];
+            const double x1 = l + 64 < hi ? xs[min(l + 64, hi - 1)] : 0.0;
+            const double x2 = l + 128 < hi ? xs[min(l + 128, hi - 1)] : 0.0;
+            const double x3 = l + 192 < hi ? xs[min(l + 192, hi - 1)] : 0.0;
+            s0 = fma(m0, x0, s0); s1 = fma(m1, x1, s1); s2 = fma(m2, x2, s2); s3 = fma(m3, x3, s3);
+        }
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) emit(i, s);
+    }
+}
+
+struct LarsGridState {
+    const double* __restrict__ S;
+    double* __restrict__ Rinv;
+    double* __restrict__ RinvT;
+    double* rbuf;
+    unsigned* bar;
+    int ld, g, G;
+    // LDS, replicated in every workgroup
+    int* act; float* sgn; double* t; double* xu; double* rw;
+    double* gi1;                       // LDS; entries of the positions this workgroup owns
+    double* red;
+};
+
+// Append variable `inew` with sign `sg` at position na.  All workgroups call it with the same arguments and get the
+// same answer; `dirty` says that column writes of an earlier append have not been followed by a grid barrier yet.
+__device__ int append_column_grid(const LarsGridState& f, int na, int inew, double sg, double eps, double& tsq,
+                                  unsigned& phase, bool& dirty) {
+    const int tid = threadIdx.x;
+    LARS_TICK(0);
+    if (dirty) { grid_barrier(f.bar, f.G, phase); dirty = false; }
+    const double* __restrict__ srow = f.S + (int64_t)inew * f.ld;
+    for (int i = tid; i < na; i += LARS_THREADS) f.xu[i] = srow[f.act[i]];
+    __syncthreads();
+    LARS_TICK(1);
+    double* __restrict__ rbuf = f.rbuf;
+    tri_matvec_rows<true>(f.RinvT, f.ld, na, f.xu, f.g, f.G, [&](int i, double s) { rbuf[i] = s; });
+    LARS_TICK(2);
+    grid_barrier(f.bar, f.G, phase);
+    LARS_TICK(3);
+    double acc[2] = {0.0, 0.0};
+    for (int i = tid; i < na; i += LARS_THREADS) {
+        const double ri = rbuf[i];
+        f.rw[i] = ri;
+        acc[0] = fma(ri, ri, acc[0]);
+        acc[1] = fma(ri, f.t[i], acc[1]);
+    }
+    block_reduce(acc, f.red, WaveOpSum());          // (its barriers also publish rw)
+    LARS_TICK(4);
+    double rpp = srow[inew] - acc[0];
+    if (na > 0 && rpp <= eps) return 0;  // rank did not grow: caller records an "ignore"
+    rpp = sqrt(rpp);
+    const double tn = (sg - acc[1]) / rpp;
+    tsq = fma(tn, tn, tsq);
+    double* __restrict__ Rinv = f.Rinv;
+    double* __restrict__ RinvT = f.RinvT;
+    const int ld = f.ld;
+    tri_matvec_rows<false>(Rinv, ld, na, f.rw, f.g, f.G, [&](int i, double s) {
+        const double c = -s / rpp;
+        Rinv[(int64_t)i * ld + na] = c;
+        RinvT[(int64_t)na * ld + i] = c;
+        f.gi1[i] = fma(c, tn, f.gi1[i]);
+    });
+    if (tid == 0) {
+        const double c = 1.0 / rpp;
+        if (na % f.G == f.g) {
+            Rinv[(int64_t)na * ld + na] = c;
+            RinvT[(int64_t)na * ld + na] = c;
+            f.gi1[na] = c * tn;
+        }
+        f.t[na] = tn;
+        f.sgn[na] = (float)sg;
+        f.act[na] = inew;
+    }
+    dirty = true;
+    __syncthreads();
+    LARS_TICK(5);
+    return 1;
+}
+
+__global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
+    __shared__ double red[4 * LARS_WAVES];
+    __shared__ int sh_i[4];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int p = a.p;
+    const int off = a.intercept ? 1 : 0;
+    const int m = p - off;
+    const int ld = (m + 1) & ~1;
+    const int mo = m / G + 2;                        // own-list capacity
+    const double eps = a.eps;
+    // LDS: sh_part[2 T] | Cvec, beta, xu, rw, t, gi1 [m] | own_w [mo] | sgn(f32), state, act [m] | own_act [mo]
+    double2* sh_part = reinterpret_cast<double2*>(dyn);
+    double* Cvec = dyn + 2 * LARS_THREADS;
+    double* beta = Cvec + m;
+    double* xu = beta + m;          // x of the append, then u of the step
+    double* rw = xu + m;            // r of the append, then w of the step
+    double* tv = rw + m;
+    double* gi1 = tv + m;
+    double* own_w = gi1 + m;
+    float* sgn = reinterpret_cast<float*>(own_w + mo);
+    int* state = reinterpret_cast<int*>(sgn + m);
+    int* act = state + m;
+    int* own_act = act + m;
+    int JT2 = 32;
+    while (2 * JT2 < m && JT2 < LARS_THREADS) JT2 *= 2;
+    const int GS = LARS_THREADS / JT2;
+    double* __restrict__ S = a.S;
+    double* b = a.vec + 0 * (int64_t)m;       // sign(b0)      (global: written and read by workgroup 0 only)
+    double* absb = a.vec + 1 * (int64_t)m;    // |b0|
+    double* a12 = a.vec + 9 * (int64_t)m;
+    double* zt = a.vec + 5 * (int64_t)m;      // unused here; lasso crossings are kept in registers
+    (void)zt;
+    double* upart = a.upart + (int64_t)g * ld;
+    unsigned phase = 0;
+    bool dirty = false;
+    LARS_PROF_DECL;
+    const LarsGridState fac{S, a.Rinv, a.RinvT, a.rbuf, a.bar, ld, g, G, act, sgn, tv, xu, rw, gi1, red};
+
+    // ---- prologue: intercept Schur complement (lsa.py:98-104) and rescaling (lsa.py:108-109).
+    // |b0|, a12 and sign(b0) are staged in LDS (rw, tv, beta) for the build of S; workgroup 0 keeps global copies.
+    double a11 = 1.0, beta0c = 0.0;
+    if (a.intercept) a11 = a.Sigma0[0];
+    for (int j = tid; j < m; j += LARS_THREADS) {
+        const double v = a.b0[j + off];
+        const double sb = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+        const double a12j = a.intercept ? a.Sigma0[(int64_t)(j + 1) * a.lds0] : 0.0;
+        rw[j] = fabs(v); tv[j] = a12j; beta[j] = sb;
+        if (g == 0) { absb[j] = fabs(v); b[j] = sb; a12[j] = a12j; }
+    }
+    __syncthreads();
+    if (a.intercept) {
+        double part = 0.0;
+        for (int j = tid; j < m; j += LARS_THREADS) part += tv[j] * a.b0[j + 1];
+        beta0c = block_sum(part, red) / a11;
+    }
+    int nown = 0;
+    for (int i = g; i < m; i += G, ++nown) {
+        for (int j = tid; j < ld; j += LARS_THREADS) {
+            double v = 0.0;
+            if (j < m) {
+                v = a.Sigma0[(int64_t)(i + off) * a.lds0 + (j + off)];
+                if (a.intercept) v -= tv[i] * tv[j] / a11;
+                v = rw[i] * v * rw[j];
+            }
+            S[(int64_t)i * ld + j] = v;
+        }
+        if (tid == 0) { own_act[nown] = i; own_w[nown] = beta[i]; }
+    }
+    __syncthreads();
+    // Cvec = b' Sigma (lsa.py:114) from the rows each workgroup just wrote
+    sym_matvec(S, ld, m, nown, own_w, own_act, upart, sh_part, JT2, GS);
+    grid_barrier(a.bar, G, phase);
+    for (int j = tid; j < m; j += LARS_THREADS) {
+        double s = 0.0;
+        for (int q = 0; q < G; ++q) s += a.upart[(int64_t)q * ld + j];
+        Cvec[j] = s;
+    }
+    __syncthreads();
+    int max_steps = a.max_steps > 0 ? a.max_steps : 8 * m;
+    // path row 0, and Cmax of the first step (lsa.py:128-129: max |Cvec| over the non-active variables)
+    double Cmax;
+    {
+        double rss[1] = {0.0}, cm[1] = {0.0};
+        for (int j = tid; j < m; j += LARS_THREADS) {
+            const double c = Cvec[j];
+            rss[0] += beta[j] * c;                   // beta still holds sign(b0)
+            cm[0] = fmax(cm[0], fabs(c));
+        }
+        if (tid == 0) { sh_i[0] = m; sh_i[2] = 0; }
+        block_reduce2(rss, WaveOpSum(), cm, WaveOpMax(), red);
+        Cmax = cm[0];
+        for (int j = tid; j < m; j += LARS_THREADS) {
+            beta[j] = 0.0;
+            state[j] = 0;
+            if (g == 0) a.beta_path[j] = 0.0;
+        }
+        if (g == 0 && tid == 0) {
+            a.aic[0] = rss[0]; a.bic[0] = rss[0];
+            a.beta0[0] = a.intercept ? beta0c : 0.0;
+        }
+        __syncthreads();
+    }
+    int na = 0, k = 0;
+    bool had_drops = false;
+    double tsq = 0.0;
+    while (k < max_steps && na < m) {
+        ++k;
+        if (!had_drops) {
+            // ---- new variables, in increasing index order (lsa.py:130-149)
+            int start = 0;
+            while (true) {
+                int cand = m, ncand = 0;
+                for (int j = start + tid; j < m; j += LARS_THREADS)
+                    if (state[j] == 0 && fabs(Cvec[j]) >= Cmax - eps) { cand = min(cand, j); ++ncand; }
+                if (ncand > 0) { atomicMin(&sh_i[0], cand); atomicAdd(&sh_i[2], ncand); }
+                __syncthreads();
+                const int inew = sh_i[0], left = sh_i[2] - 1;
+                if (inew >= m) break;
+                const double c = Cvec[inew];
+                const int grew = append_column_grid(fac, na, inew, (c > 0.0) ? 1.0 : ((c < 0.0) ? -1.0 : 0.0), eps, tsq, phase, dirty);
+                if (tid == 0) {
+                    state[inew] = grew ? 1 : 2;      // 2: machine-singular, ignored (lsa.py:139-144)
+                    sh_i[0] = m; sh_i[2] = 0;
+                }
+                if (grew) ++na;
+                start = inew + 1;
+                __syncthreads();
+                if (left <= 0) break;
+            }
+        }
+        if (na == 0) break;   // nothing could enter (degenerate input)
+        LARS_TICK(0);
+        // ---- equiangular direction (lsa.py:151-153): w_i = A Gi1_i for the positions this workgroup owns
+        const double A = 1.0 / sqrt(tsq);
+        nown = (na > g) ? (na - g + G - 1) / G : 0;
+        for (int q = tid; q < nown; q += LARS_THREADS) {
+            const int i = g + q * G;
+            const double wi = A * gi1[i];
+            own_w[q] = wi;
+            own_act[q] = act[i];
+            a.wbuf[i] = wi;
+        }
+        __syncthreads();
+        // ---- partial u = Sigma[own active rows, :]' w_own
+        sym_matvec(S, ld, m, nown, own_w, own_act, upart, sh_part, JT2, GS);
+        LARS_TICK(6);
+        grid_barrier(a.bar, G, phase);
+        LARS_TICK(7);
+        dirty = false;
+        for (int i = tid; i < na; i += LARS_THREADS) rw[i] = a.wbuf[i];
+        for (int j2 = tid; 2 * j2 < m; j2 += LARS_THREADS) {
+            const double2* src = reinterpret_cast<const double2*>(a.upart + 2 * j2);
+            double2 sum = {0.0, 0.0};
+            for (int q = 0; q < G; ++q) {
+                const double2 v = src[(int64_t)q * (ld / 2)];
+                sum.x += v.x; sum.y += v.y;
+            }
+            xu[2 * j2] = sum.x;
+            if (2 * j2 + 1 < m) xu[2 * j2 + 1] = sum.y;
+        }
+        __syncthreads();
+        LARS_TICK(8);
+        // ---- step length (lsa.py:154-162) and lasso modification (lsa.py:164-173)
+        double gamhat = Cmax / A;
+        double mins[2] = {INFINITY, INFINITY};
+        if (na < m) {
+            for (int j = tid; j < m; j += LARS_THREADS) {
+                if (state[j] != 0) continue;
+                const double c = Cvec[j], aj = xu[j];
+                const double g1 = (Cmax - c) / (A - aj);
+                const double g2 = (Cmax + c) / (A + aj);
+                if (g1 > eps) mins[0] = fmin(mins[0], g1);
+                if (g2 > eps) mins[0] = fmin(mins[0], g2);
+            }
+        }
+        if (a.type == 1) {
+            for (int i = tid; i < na; i += LARS_THREADS) {
+                const double z = -beta[act[i]] / rw[i];
+                if (z > eps) mins[1] = fmin(mins[1], z);
+            }
+        }
+        block_reduce(mins, red, WaveOpMin());
+        gamhat = fmin(mins[0], gamhat);
+        had_drops = false;
+        if (a.type == 1 && mins[1] < gamhat) {
+            gamhat = mins[1];
+            had_drops = true;
+        }
+        // ---- move (lsa.py:175-177); a crossing variable (lsa.py:179-186) leaves: beta = 0, state = inactive
+        for (int i = tid; i < na; i += LARS_THREADS) {
+            const int v = act[i];
+            const double z = -beta[v] / rw[i];
+            if (had_drops && z == gamhat) { beta[v] = 0.0; state[v] = 0; act[i] = -1 - v; }
+            else beta[v] += gamhat * rw[i];
+        }
+        for (int j = tid; j < m; j += LARS_THREADS) Cvec[j] -= gamhat * xu[j];
+        __syncthreads();
+        if (had_drops) {
+            if (tid == 0) {
+                int q = 0;
+                for (int i = 0; i < na; ++i)
+                    if (act[i] >= 0) { act[q] = act[i]; sgn[q] = sgn[i]; ++q; }
+                sh_i[1] = q;
+            }
+            __syncthreads();
+            const int keep = sh_i[1];
+            // rebuild R^{-1}, t and Gi1 for the remaining ordered active set
+            tsq = 0.0;
+            for (int i = 0; i < keep; ++i) append_column_grid(fac, i, act[i], (double)sgn[i], 0.0, tsq, phase, dirty);
+            na = keep;
+        }
+        LARS_TICK(9);
+        // ---- Cmax of the next step; workgroup 0 records the path point: un-scaled beta (lsa.py:194-201), RSS, dof,
+        // AIC/BIC (:190-210)
+        double rec[3] = {0.0, 0.0, 0.0}, cm[1] = {0.0};      // RSS, dof, a12 . beta
+        for (int j = tid; j < m; j += LARS_THREADS) {
+            const double cj = Cvec[j];
+            if (state[j] != 1) cm[0] = fmax(cm[0], fabs(cj));
+            if (g == 0) {
+                const double bj = beta[j];
+                const double ub = absb[j] * bj;
+                a.beta_path[(int64_t)k * m + j] = ub;
+                rec[0] += (b[j] - bj) * cj;
+                if (fabs(ub) > eps) rec[1] += 1.0;
+                if (a.intercept) rec[2] += a12[j] * ub;
+            }
+        }
+        block_reduce2(rec, WaveOpSum(), cm, WaveOpMax(), red);
+        Cmax = cm[0];
+        if (g == 0 && tid == 0) {
+            a.aic[k] = rec[0] + 2.0 * rec[1];
+            a.bic[k] = rec[0] + log(a.n) * rec[1];
+            a.beta0[k] = a.intercept ? beta0c - rec[2] / a11 : 0.0;
+        }
+        __syncthreads();
+        LARS_TICK(10);
+    }
+#ifdef DLSA_LARS_PROF
+    if (g == 0 && tid == 0)
+        printf("LARS_GRID_PROF p=%d G=%d steps=%d us: select %.0f gather %.0f r %.0f barrier1 %.0f reduce %.0f column %.0f | w+upartial %.0f barrier2 %.0f ureduce %.0f step %.0f record %.0f\n",
+               p, G, k, lars_prof_t[0] * 0.01, lars_prof_t[1] * 0.01, lars_prof_t[2] * 0.01, lars_prof_t[3] * 0.01, lars_prof_t[4] * 0.01,
+               lars_prof_t[5] * 0.01, lars_prof_t[6] * 0.01, lars_prof_t[7] * 0.01, lars_prof_t[8] * 0.01, lars_prof_t[9] * 0.01,
+               lars_prof_t[10] * 0.01);
+#endif
+    if (g == 0 && tid == 0) *a.n_steps = k;
+}
+
+// Workgroups for the path at width p (measured: p=200 1 wg 2.6 ms / 4 wgs 2.9; p=500 8.3 ms at 8; p=1000 22 ms at 16;
+// p=2000 74 ms at 32).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
+static int lars_workgroups(int p) {
+    int wgs = p < 384 ? 1 : (p < 768 ? 8 : (p < 1536 ? 16 : 32));
+    if (const char* e = getenv("DLSA_LARS_WGS")) wgs = atoi(e);
+    return std::max(1, std::min(wgs, LARS_MAX_WGS));
+}
+
 }  // namespace dlsa
 
 extern "C" {
@@ -498,7 +885,8 @@ extern "C" {
 size_t dlsa_lars_workspace_bytes(int p) {
     if (p <= 0) return 0;
     const size_t m = (size_t)p, ld = (m + 1) & ~(size_t)1;
-    return dlsa::align_up(m * ld * 8, 256) + dlsa::align_up((m * ld + dlsa::LARS_SLACK) * 8, 256) * 2 + dlsa::align_up(12 * m * 8, 256) + dlsa::align_up(4 * m * 4, 256) + 512;
+    return dlsa::align_up(m * ld * 8, 256) + dlsa::align_up((m * ld + dlsa::LARS_SLACK) * 8, 256) * 2 + dlsa::align_up(12 * m * 8, 256) +
+           dlsa::align_up(m * 8, 256) * 2 + dlsa::align_up(dlsa::LARS_MAX_WGS * ld * 8, 256) + 256 + dlsa::align_up(4 * m * 4, 256) + 512;
 }
 
 int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p, int intercept, double n,
@@ -525,16 +913,35 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.vec = (double*)ar.take(12 * m * 8);
     a.ivec = (int*)ar.take(4 * m * 4);
     a.n_steps = (int*)ar.take(256);
+    a.rbuf = (double*)ar.take(m * 8);
+    a.wbuf = (double*)ar.take(m * 8);
+    a.upart = (double*)ar.take((size_t)LARS_MAX_WGS * ld * 8);
+    a.bar = (unsigned*)ar.take(256);
     a.beta_path = beta_path; a.beta0 = beta0; a.aic = aic; a.bic = bic;
     // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
     DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
     DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
-    const size_t shm = (size_t)LARS_THREADS * 16 + (size_t)(p - (intercept ? 1 : 0)) * 44 + 64;
-    DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
-    if (shm > 48 * 1024)
-        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
-    DLSA_HIP_CHECK(hipGetLastError());
+    const size_t mm = (size_t)(p - (intercept ? 1 : 0));
+    const int wgs = lars_workgroups(p);
+    if (wgs > 1) {
+        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64;
+        DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
+        if (shm > 48 * 1024)
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
+        void* args[] = {&a};
+        // cooperative launch: all workgroups are resident together (the grid barrier spins), or the launch fails
+        DLSA_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lars_grid_kernel), dim3(wgs), dim3(LARS_THREADS),
+                                                  args, (unsigned)shm, s));
+    } else {
+        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 44 + 64;
+        DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
+        if (shm > 48 * 1024)
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
     int steps = 0;
     DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
     DLSA_HIP_CHECK(hipStreamSynchronize(s));

@@ -338,6 +338,28 @@ def test_lars_lasso_drops_wide_matches_oracle(eng, orc, p, rho, seed, intercept)
     assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
 
 
+@pytest.mark.parametrize("wgs", [1, 5, 16, 32])
+def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypatch, wgs):
+    """The multi-workgroup path kernel (cooperative launch, grid barriers) and the single-workgroup one walk the
+    same path: reference goldens incl. drops, wide lasso paths with drops, the intercept."""
+    monkeypatch.setenv("DLSA_LARS_WGS", str(wgs))
+    for name in F3:
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        typ = "lasso" if name.endswith("lasso") else "lar"
+        r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), False, float(z["n"]), type=typ)
+        assert r["beta"].shape == z["beta"].shape, name
+        assert rel_inf(r["beta"].cpu().numpy(), z["beta"]) < 1e-8, name
+        assert rel_inf(r["BIC"].cpu().numpy(), z["BIC"]) < 1e-8, name
+    for p, rho, seed, intercept in [(120, 0.98, 5, False), (257, 0.97, 11, False), (120, 0.98, 5, True)]:
+        S, b, n = _correlated_lsa_problem(p, rho, seed)
+        ro = orc.lars_lsa(S, b, intercept, n, type="lasso")
+        r = eng.lars_path(dev(S), dev(b), intercept, float(n), type="lasso")
+        assert r["beta"].shape == ro["beta"].shape
+        assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
+        assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7 or not intercept
+        assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
+
+
 def test_loglik_columns(eng, orc):
     rng = np.random.default_rng(8)
     n, p = 5000, 60
