@@ -129,13 +129,19 @@ def linear_config(name, n, p, K):
             print(msg, file=sys.stderr, flush=True)
     t_gram, _ = timed(lambda: engine.gram(X, None))
     t_xty, _ = timed(lambda: engine.xtv(X, y))
-    t_all, mb = timed(lambda: dlsa_amd.fit_linear_partitions(X, y, part_offsets=[int(n * k / K) for k in range(K + 1)]), reps=2)
+    offs = [int(n * k / K) for k in range(K + 1)]
+    t_all, mb = timed(lambda: dlsa_amd.fit_linear_partitions(X, y, part_offsets=offs), reps=2)
     out = dlsa_amd.dlsa_mapred(mb)
+
+    def whole():
+        o = dlsa_amd.dlsa_mapred(dlsa_amd.fit_linear_partitions(X, y, part_offsets=offs))
+        return dlsa_amd.dlsa(o.iloc[:, 2:], o["beta_byOLS"], n)
+    t_whole, _ = timed(whole, reps=2)
     fl = p * (p + 1)
     return {"config": name, "n": n, "p": p, "K": K, "dtype": "f32",
             "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
             "gram_GBps_alg": n * 4 * p / t_gram / 1e9, "xty_ms": t_xty * 1e3, "xty_GBps": n * 4 * (p + 1) / t_xty / 1e9,
-            "map_fit_s": t_all, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max())}
+            "map_fit_s": t_all, "map_reduce_lars_s": t_whole, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max())}
 
 
 def main():
