@@ -870,10 +870,11 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
     if (g == 0 && tid == 0) *a.n_steps = k;
 }
 
-// Workgroups for the path at width p (measured: p=200 1 wg 2.6 ms / 4 wgs 2.9; p=500 8.3 ms at 8; p=1000 22 ms at 16;
-// p=2000 74 ms at 32).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
+// Workgroups for the path at width p (measured: p=200 one workgroup 2.6 ms / four 2.9; p=300 5.1 / 4.7; p=500 8.3 ms
+// at 8; p=1000 22 ms at 16; p=2000 74 ms at 32; the grid kernel with ONE workgroup is slower than lars_kernel:
+// 4.0 vs 2.6 ms at p=200).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
 static int lars_workgroups(int p) {
-    int wgs = p < 384 ? 1 : (p < 768 ? 8 : (p < 1536 ? 16 : 32));
+    int wgs = p < 256 ? 1 : (p < 384 ? 4 : (p < 768 ? 8 : (p < 1536 ? 16 : 32)));
     if (const char* e = getenv("DLSA_LARS_WGS")) wgs = atoi(e);
     return std::max(1, std::min(wgs, LARS_MAX_WGS));
 }
@@ -922,10 +923,11 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
     DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
     const size_t mm = (size_t)(p - (intercept ? 1 : 0));
-    const int wgs = lars_workgroups(p);
+    int wgs = lars_workgroups(p);
+    // the grid kernel replicates more vectors in LDS; beyond its limit (m ~ 2440) the single-workgroup kernel still fits
+    if (wgs > 1 && (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64 > (size_t)kLdsBytes) wgs = 1;
     if (wgs > 1) {
         const size_t shm = (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64;
-        DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
         if (shm > 48 * 1024)
             DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

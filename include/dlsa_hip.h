@@ -130,10 +130,10 @@ int dlsa_spd_solve_f64(const double* S, int64_t lds, const double* v, int p, dou
  * Sigma0 p x p, b0 p (device).  type 0 = 'lar', 1 = 'lasso'.  max_steps <= 0 -> 8*m.
  * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
  * aic, bic (max_steps+1 each); n_steps_host = number of steps taken (path has n_steps+1
- * rows).  Runs as one persistent kernel on the device: a single workgroup for p < 384, a
- * cooperative launch of 8..32 workgroups (two grid barriers per step) above; the device must
- * be able to hold them at once (any gfx950 can), and p is bounded by the LDS per workgroup
- * (about 2600 columns). */
+ * rows).  Runs as one persistent kernel on the device: a single workgroup for p < 256, a
+ * cooperative launch of 4..32 workgroups (two grid barriers per step) above; the device must
+ * be able to hold them at once (any gfx950 can).  p is bounded by the LDS per workgroup:
+ * about 2400 columns for the grid kernel, 3300 for the single workgroup it falls back to. */
 size_t dlsa_lars_workspace_bytes(int p);
 int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p,
                       int intercept, double n, int type, double eps, int max_steps,
