@@ -475,6 +475,14 @@ __global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int
     }
 }
 
+template <typename T>
+void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream) {
+    dim3 rg((p + 127) / 128, p);
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
+}
+template void gram_reduce_launch<double>(const double*, int, int, int, double*, int64_t, int, hipStream_t);
+template void gram_reduce_launch<float>(const float*, int, int, int, float*, int64_t, int, hipStream_t);
+
 // ---------------------------------------------------------------------------------------
 // Host side: wave blocks -> workgroup items, cached per p on the device.
 // ---------------------------------------------------------------------------------------
@@ -719,6 +727,13 @@ size_t gram_wide_f32_ws_bytes(int64_t n, int p);
 int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H, int64_t ldh,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
+// gram_narrow.hip: the row-split fp64 kernel for 49 <= p <= 112
+bool gram_narrow_shape_ok(int64_t n, int p);
+bool gram_narrow_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p);
+size_t gram_narrow_ws_bytes(int64_t n, int p);
+int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
+                    int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
     std::vector<GramItem> items, listed;
@@ -730,6 +745,7 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const size_t PP = ((size_t)ntile * TILE + 63) / 64 * 64;
     size_t bytes = align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
     if (elem_bytes == 4 && gram_wide_f32_shape_ok(n, p)) bytes = std::max(bytes, gram_wide_f32_ws_bytes(n, p));
+    if (elem_bytes == 8 && gram_narrow_shape_ok(n, p)) bytes = std::max(bytes, gram_narrow_ws_bytes(n, p));
     return bytes;
 }
 
@@ -742,6 +758,9 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     if constexpr (sizeof(T) == 4) {
         if (gram_wide_f32_eligible(X, ldx, w, n, p))
             return gram_wide_f32(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
+    } else {
+        if (gram_narrow_eligible(X, ldx, w, n, p))
+            return gram_narrow_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
     }
     GramPlan pl;
     int rc = get_plan(p, pl);
@@ -789,8 +808,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
 #undef DLSA_LAUNCH_GRAM
 #undef DLSA_LAUNCH_GRAM_NT
     DLSA_HIP_CHECK(hipGetLastError());
-    dim3 rg((p + 127) / 128, p);
-    hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, (const T*)ws, nslab, pl.PP, p, H, ldh, accumulate);
+    gram_reduce_launch<T>((const T*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

@@ -101,6 +101,34 @@ def test_gram_dma_path_with_row_pitch(eng, orc, n, p, ld):
     assert rel_inf(H1, orc.gram(buf[:, :p])) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("n,p,ld", [(8192, 50, 50), (20001, 100, 100), (100003, 100, 104), (9000, 64, 70), (50000, 112, 112),
+                                    (33333, 98, 128), (8200, 80, 80), (262144 + 17, 100, 100)])
+def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
+    """49 <= p <= 112, even p, >= 8192 rows: the row-split kernel (every wave owns the whole triangle; LDS-DMA ring;
+    partial triangles meet in LDS).  Ragged row counts, row pitch != p (NaN padding), weighted and unweighted,
+    accumulate, and agreement with the tile-list kernel (DLSA_GRAM_DBG=64)."""
+    rng = np.random.default_rng(n + p)
+    buf = rng.random((n, ld)) - 0.5
+    buf[:, p:] = np.nan
+    Xd = dev(buf)[:, :p]
+    w = rng.random(n) * 0.25
+    Ho = orc.gram(buf[:, :p], w)
+    H = eng.gram(Xd, dev(w))
+    assert torch.equal(H, H.T)
+    assert rel_inf(H.cpu().numpy(), Ho) < TOL_KERNEL
+    assert rel_inf(eng.gram(Xd).cpu().numpy(), orc.gram(buf[:, :p])) < TOL_KERNEL
+    H0 = rng.random((p, p))
+    Hacc = dev(H0.copy())
+    eng.gram(Xd, dev(w), out=Hacc, accumulate=True)
+    assert rel_inf(Hacc.cpu().numpy(), H0 + Ho) < 1e-11
+    os.environ["DLSA_GRAM_DBG"] = "64"
+    try:
+        Hl = eng.gram(Xd, dev(w))
+    finally:
+        del os.environ["DLSA_GRAM_DBG"]
+    assert rel_inf(H.cpu().numpy(), Hl.cpu().numpy()) < 1e-12
+
+
 def test_logit_pass_with_row_pitch(eng, orc):
     rng = np.random.default_rng(17)
     n, p, ld = 3000, 70, 96
