@@ -132,8 +132,6 @@ __device__ __forceinline__ void block_reduce2(double (&va)[NA], OpA opa, double 
     }
 }
 __device__ double block_sum(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpSum()); return a[0]; }
-__device__ double block_max(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpMax()); return a[0]; }
-__device__ double block_min(double v, double* red) { double a[1] = {v}; block_reduce(a, red, WaveOpMin()); return a[0]; }
 
 // y_i = sum_l M[i][l] x[l] over the stored part of row i of a triangular matrix: l in [0, i] (LOWER) or [i, n).
 // The other triangle of M is zero (and so are LARS_SLACK elements after the matrix), so nothing but x is masked:
@@ -653,8 +651,6 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
     double* b = a.vec + 0 * (int64_t)m;       // sign(b0)      (global: written and read by workgroup 0 only)
     double* absb = a.vec + 1 * (int64_t)m;    // |b0|
     double* a12 = a.vec + 9 * (int64_t)m;
-    double* zt = a.vec + 5 * (int64_t)m;      // unused here; lasso crossings are kept in registers
-    (void)zt;
     double* upart = a.upart + (int64_t)g * ld;
     unsigned phase = 0;
     bool dirty = false;
