@@ -781,11 +781,16 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     }
     GramArgs<T> a;
     a.X = X; a.w = w; a.partial = (T*)ws; a.items = use_list ? pl.d_items_list : pl.d_items; a.ldx = ldx; a.n = n;
-    a.rows_per_slab = rps; a.p = p; a.PP = pl.PP; a.nitems = nitems; a.nslab = nslab;
+    // Odd p in an even row pitch (e.g. an intercept column in front of an even design): the kernel loads p + 1
+    // columns, so that rows stay 16-byte units for the vector / LDS-DMA staging.  Whatever sits in the pad column
+    // (even NaN) only reaches row and column p of the tile grid, which nobody reads: an MFMA output element depends on
+    // one row of A and one column of B only.  ceil(p / 16) does not change, p being odd.
+    const int p_load = (vec && (p & 1)) ? p + 1 : p;
+    a.rows_per_slab = rps; a.p = p_load; a.PP = pl.PP; a.nitems = nitems; a.nslab = nslab;
     a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
     a.dbg = dbg;
     if (a.dbg & 2) a.xcd_map = 0;
-    if (sizeof(T) == 8 && vec && (p % 2 == 0) && (!w || ((uintptr_t)w % 16) == 0) &&
+    if (sizeof(T) == 8 && vec && (p_load % 2 == 0) && (!w || ((uintptr_t)w % 16) == 0) &&
         (double)rps * (double)ldx * sizeof(T) < 2.0e9)
         mode = 2;                                        // direct global->LDS DMA
     if (a.dbg & 4) mode = vec ? 1 : 0;

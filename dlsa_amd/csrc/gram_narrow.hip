@@ -1,4 +1,5 @@
-// Weighted Gram H = X' diag(w) X for NARROW fp64 designs (49 <= p <= 112: config 2's p = 100, config 1's p = 50),
+// Weighted Gram H = X' diag(w) X for NARROW fp64 designs (49 <= p <= 112 in an even row pitch: config 2's p = 100,
+// config 1's p = 50, and the same with an intercept column),
 // reference call site dlsa/models.py:130.
 //
 // At these widths the whole upper triangle of H is at most 28 tiles of 16x16, i.e. <= 224 accumulator registers
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
     for (int e = tid; e < NARROW_STAGES * BUF; e += THREADS) lds[e] = 0.0;
     __syncthreads();
 
-    const bool col_in = 2 * lane < a.p;                 // p is even: both columns of the lane's 16 bytes are inside
+    const bool col_in = 2 * lane < a.p;                 // a.p is even: both columns of the lane's 16 bytes are loaded
     auto stage = [&](int chunk, int buf) {
         double* base = lds + buf * BUF;
 #pragma unroll
@@ -191,7 +192,7 @@ static int narrow_slabs(int64_t n, int p, int64_t& rows_per_slab) {
     return (int)((n + rows_per_slab - 1) / rows_per_slab);
 }
 
-bool gram_narrow_shape_ok(int64_t n, int p) { return p >= NARROW_MIN_P && p <= NARROW_MAX_P && p % 2 == 0 && n >= NARROW_MIN_ROWS; }
+bool gram_narrow_shape_ok(int64_t n, int p) { return p >= NARROW_MIN_P && p <= NARROW_MAX_P && n >= NARROW_MIN_ROWS; }
 
 bool gram_narrow_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p) {
     if (!gram_narrow_shape_ok(n, p)) return false;
@@ -212,7 +213,9 @@ size_t gram_narrow_ws_bytes(int64_t n, int p) {
 int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                     int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     NarrowArgs a;
-    a.X = X; a.w = w; a.partial = (double*)ws; a.ldx = ldx; a.n = n; a.p = p;
+    // odd p (in an even row pitch, checked by gram_narrow_eligible): load p + 1 columns; the pad column only reaches row
+    // and column p of the tile grid, which nobody reads (see gram_impl)
+    a.X = X; a.w = w; a.partial = (double*)ws; a.ldx = ldx; a.n = n; a.p = p + (p & 1);
     { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int nt = (p + 15) / 16;
     a.PP = (nt * 16 + 63) / 64 * 64;

@@ -151,11 +151,11 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
             counts = [n]
         part_offsets = np.concatenate([[0], np.cumsum(counts)])
     if fit_intercept:
-        X = torch.cat([torch.ones((n, 1), dtype=X.dtype, device=X.device), X], dim=1)
+        X = engine.with_ones_column(X)
     if names is None:
         names = ["x" + str(i) for i in range(p)]
     names = (["intercept"] if fit_intercept else []) + list(names)
-    r = engine.irls_fit(X.contiguous(), y.contiguous(), part_offsets, tol=tol, max_iter=max_iter)
+    r = engine.irls_fit(engine.row_major(X), y.contiguous(), part_offsets, tol=tol, max_iter=max_iter)
     return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], names, r["status"], r["n_iter"], r["loglik"],
                         sample_size=n)
 
@@ -229,8 +229,8 @@ def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_inter
             counts = [n]
         part_offsets = np.concatenate([[0], np.cumsum(counts)])
     if fit_intercept:
-        X = torch.cat([torch.ones((n, 1), dtype=X.dtype, device=X.device), X], dim=1)
-    X, y = X.contiguous(), y.contiguous()
+        X = engine.with_ones_column(X)
+    X, y = engine.row_major(X), y.contiguous()
     pp = X.shape[1]
     if names is None:
         names = ["x" + str(i) for i in range(p)]

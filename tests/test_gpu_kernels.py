@@ -129,6 +129,33 @@ def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
     assert rel_inf(H.cpu().numpy(), Hl.cpu().numpy()) < 1e-12
 
 
+@pytest.mark.parametrize("n,p,ld", [(9001, 51, 52), (30000, 101, 102), (8192, 111, 112), (4000, 501, 502), (5000, 37, 38),
+                                    (12000, 129, 136), (2000, 1, 2), (700, 255, 256)])
+def test_gram_odd_p_in_even_row_pitch(eng, orc, n, p, ld):
+    """An odd column count inside 16-byte-aligned rows (e.g. the intercept column in front of an even design) takes
+    the vector / LDS-DMA staging with p + 1 loaded columns; the pad column holds NaN here and must not reach H."""
+    rng = np.random.default_rng(n + p)
+    buf = rng.random((n, ld)) - 0.5
+    buf[:, p:] = np.nan
+    Xd = dev(buf)[:, :p]
+    w = rng.random(n) * 0.25
+    H = eng.gram(Xd, dev(w))
+    assert torch.equal(H, H.T) and bool(torch.isfinite(H).all())
+    assert rel_inf(H.cpu().numpy(), orc.gram(buf[:, :p], w)) < TOL_KERNEL
+    H1 = eng.gram(Xd).cpu().numpy()
+    assert rel_inf(H1, orc.gram(buf[:, :p])) < TOL_KERNEL
+
+
+def test_aligned_row_helpers(eng):
+    X = eng.empty_rows(10, 7)
+    assert X.shape == (10, 7) and X.stride(0) == 8 and X.stride(1) == 1
+    assert eng.empty_rows(10, 8).is_contiguous()
+    Z = torch.rand(5, 4, dtype=torch.float64, device="cuda")
+    A = eng.with_ones_column(Z)
+    assert A.shape == (5, 5) and A.stride(0) == 6 and bool((A[:, 0] == 1).all()) and torch.equal(A[:, 1:], Z)
+    assert eng.row_major(A) is A and eng.row_major(Z.T).is_contiguous()
+
+
 def test_logit_pass_with_row_pitch(eng, orc):
     rng = np.random.default_rng(17)
     n, p, ld = 3000, 70, 96
