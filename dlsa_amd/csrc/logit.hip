@@ -316,39 +316,60 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
 }
 
-// g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b].  One workgroup per 64 columns; 16 row
-// groups sum interleaved block ranges and are combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(1024) void logit_finish_kernel(const double* __restrict__ gpart,
-                                                            const double* __restrict__ llpart, int nblocks,
-                                                            int pitch, int p, double* __restrict__ g,
-                                                            double* __restrict__ loglik) {
-    __shared__ double red[16][65];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cx;
-    double s = 0.0;
-    if (g && col < p)
-        for (int b = ry; b < nblocks; b += 16) s += gpart[(int64_t)b * pitch + col];
-    red[ry][cx] = s;
-    __syncthreads();
-    if (ry == 0 && g && col < p) {
-        double t = red[0][cx];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) t += red[k][cx];
-        g[col] = t;
+// g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b].  One workgroup per 16 columns (32 workgroups at p = 500:
+// a 1e6-row partition pays this once per Newton iteration, so it is latency that counts); 64 row groups sum
+// interleaved block ranges with four loads in flight each and are combined through LDS in a fixed order
+// (deterministic).  The last workgroup also sums the log-likelihood partials.
+constexpr int FINISH_COLS = 16, FINISH_GROUPS = 64;
+__global__ __launch_bounds__(FINISH_COLS * FINISH_GROUPS) void logit_finish_kernel(const double* __restrict__ gpart,
+                                                                                    const double* __restrict__ llpart,
+                                                                                    int nblocks, int pitch, int p,
+                                                                                    double* __restrict__ g,
+                                                                                    double* __restrict__ loglik) {
+    __shared__ double red[FINISH_GROUPS][FINISH_COLS + 1];
+    const int cx = threadIdx.x % FINISH_COLS, ry = threadIdx.x / FINISH_COLS;
+    const int col = blockIdx.x * FINISH_COLS + cx;
+    if (g && blockIdx.x * FINISH_COLS < p) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (col < p) {
+            const double* src = gpart + col;
+            int b = ry;
+            for (; b + 3 * FINISH_GROUPS < nblocks; b += 4 * FINISH_GROUPS) {
+                s0 += src[(int64_t)b * pitch];
+                s1 += src[(int64_t)(b + FINISH_GROUPS) * pitch];
+                s2 += src[(int64_t)(b + 2 * FINISH_GROUPS) * pitch];
+                s3 += src[(int64_t)(b + 3 * FINISH_GROUPS) * pitch];
+            }
+            for (; b < nblocks; b += FINISH_GROUPS) s0 += src[(int64_t)b * pitch];
+        }
+        red[ry][cx] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (ry == 0 && col < p) {
+            double t = red[0][cx];
+            for (int k = 1; k < FINISH_GROUPS; ++k) t += red[k][cx];
+            g[col] = t;
+        }
     }
-    if (loglik && blockIdx.x == 0) {
+    if (loglik && blockIdx.x == gridDim.x - 1) {
         __syncthreads();
         double t = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 1024) t += llpart[b];
-        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-        if (cx == 0) red[ry][64] = t;
+        for (int b = threadIdx.x; b < nblocks; b += FINISH_COLS * FINISH_GROUPS) t += llpart[b];
+        t = wave_allreduce_sum(t);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][FINISH_COLS] = t;
         __syncthreads();
         if (threadIdx.x == 0) {
             double u = 0.0;
-            for (int k = 0; k < 16; ++k) u += red[k][64];
+            for (int k = 0; k < FINISH_COLS * FINISH_GROUPS / 64; ++k) u += red[k][FINISH_COLS];
             *loglik = u;
         }
     }
+}
+
+// (also the finish step of onehot.hip's structured logit pass)
+void logit_finish_launch(const double* gpart, const double* llpart, int nblocks, int pitch, int p, double* g,
+                         double* loglik, hipStream_t stream) {
+    hipLaunchKernelGGL(logit_finish_kernel, dim3((p + FINISH_COLS - 1) / FINISH_COLS + 1), dim3(FINISH_COLS * FINISH_GROUPS),
+                       0, stream, gpart, llpart, nblocks, pitch, p, g, loglik);
 }
 
 static int logit_nc(int p) {
@@ -405,8 +426,7 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     }
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, stream,
-                           (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, loglik);
+        logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, loglik, stream);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;
@@ -741,8 +761,7 @@ int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p
         case 8: blocks = logit_blocks(n, 2); launch_xtv<8, 2>(a, vec, blocks, s); break;
         default: blocks = logit_blocks(n, 1); launch_xtv<16, 1>(a, vec, blocks, s); break;
     }
-    hipLaunchKernelGGL(logit_finish_kernel, dim3((p + 63) / 64), dim3(1024), 0, s,
-                       (const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv);
+    logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv, s);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

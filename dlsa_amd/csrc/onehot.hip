@@ -174,8 +174,8 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
 }
 
 // g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b] in a fixed order: the dense pass's finish kernel (logit.hip)
-__global__ void logit_finish_kernel(const double* __restrict__ gpart, const double* __restrict__ llpart, int nblocks,
-                                    int pitch, int p, double* __restrict__ g, double* __restrict__ loglik);
+void logit_finish_launch(const double* gpart, const double* llpart, int nblocks, int pitch, int p, double* g,
+                         double* loglik, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
@@ -336,8 +336,7 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
                        ldc, y, beta, n, w_out, gpart, llpart);
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        hipLaunchKernelGGL(logit_finish_kernel, dim3((ds.p + 63) / 64), dim3(1024), 0, s, (const double*)gpart,
-                           (const double*)llpart, nb, ds.p, ds.p, g, loglik);
+        logit_finish_launch((const double*)gpart, (const double*)llpart, nb, ds.p, ds.p, g, loglik, s);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;
