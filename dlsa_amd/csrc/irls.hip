@@ -52,7 +52,7 @@ int launch_axpby(const double* a, const double* b, double sc, int n, double* out
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
 
 struct IrlsLayout {
-    size_t w, g, beta, beta_prev, delta, stats, L, Linv, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
+    size_t w, g, beta, beta_prev, delta, stats, L, Linv, Hinv, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, total;
 };
 
 // pass_bytes: scratch of the data source's logit / Gram passes (they never run concurrently)
@@ -68,8 +68,10 @@ static IrlsLayout irls_layout(int64_t max_rows, int p, size_t pass_bytes) {
     l.stats = take(8 * sizeof(double));
     l.L = take((size_t)p * p * sizeof(double));
     l.Linv = take((size_t)p * p * sizeof(double));
-    l.pass_bytes = pass_bytes;
-    l.pass = take(pass_bytes);
+    l.Hinv = take((size_t)p * p * sizeof(double));
+    // ... and of the p x p Gram pass that forms the explicit inverse of a reused factor
+    l.pass_bytes = std::max(pass_bytes, gram_workspace_bytes_impl(p, p, 8));
+    l.pass = take(l.pass_bytes);
     l.qn_s = take((size_t)QN_PAIRS * p * sizeof(double));
     l.qn_y = take((size_t)QN_PAIRS * p * sizeof(double));
     l.qn_rho = take(QN_PAIRS * sizeof(double));
@@ -172,14 +174,14 @@ __global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, c
     }
 }
 
-// One launch per quasi-Newton iteration: [push the new curvature pair] -> first loop -> x = Linv' (Linv q) -> second loop
+// One launch per quasi-Newton iteration: [push the new curvature pair] -> first loop -> x = H0^-1 q (explicit inverse) -> second loop
 // -> delta and stats, all in one 1024-thread workgroup (the separate kernels above cost five launches and their gaps
 // per iteration, which is what small partitions are made of).
 __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict__ beta, const double* __restrict__ prev,
                                                        double* __restrict__ gprev, const double* __restrict__ g,
                                                        double* __restrict__ S, double* __restrict__ Y, double* __restrict__ rho,
                                                        QnOrder ord, int push_slot, int p, double gscale,
-                                                       const double* __restrict__ Linv, double* __restrict__ delta,
+                                                       const double* __restrict__ Hinv, double* __restrict__ delta,
                                                        double* __restrict__ stats) {
     extern __shared__ double sm[];
     double* qv = sm;                 // p
@@ -219,24 +221,26 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
     }
     for (int i = tid; i < p; i += nth) qv[i] *= gscale;
     __syncthreads();
-    for (int i = wave; i < p; i += nw) {                   // y_i = sum_{k<=i} Linv[i][k] q[k]
-        const double* row = Linv + (int64_t)i * p;
-        double sacc = 0.0;
-        for (int k = lane; k <= i; k += 64) sacc = fma(row[k], qv[k], sacc);
-        sacc = wave_allreduce_sum(sacc);
-        if (lane == 0) yv[i] = sacc;
-    }
-    __syncthreads();
-    {
-        const int half = nth / 2, grp = tid / half, t = tid % half;
-        for (int k = t; k < p; k += half) {
-            double sacc = 0.0;
-            for (int i = k + grp; i < p; i += 2) sacc = fma(Linv[(int64_t)i * p + k], yv[i], sacc);
-            part[grp * p + k] = sacc;
+    // r = H0^-1 q with the explicit inverse: one wave per row, four rows (all their loads) in flight per trip
+    for (int i0 = 4 * wave; i0 < p; i0 += 4 * nw) {
+        double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* row = Hinv + (int64_t)min(i0 + r, p - 1) * p;
+            double s0 = 0.0, s1 = 0.0;
+            int k = lane;
+            for (; k + 64 < p; k += 128) { s0 = fma(row[k], qv[k], s0); s1 = fma(row[k + 64], qv[k + 64], s1); }
+            if (k < p) s0 = fma(row[k], qv[k], s0);
+            acc4[r] = s0 + s1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double t = wave_allreduce_sum(acc4[r]);
+            if (lane == 0 && i0 + r < p) part[i0 + r] = t;
         }
     }
     __syncthreads();
-    for (int i = tid; i < p; i += nth) qv[i] = part[i] + part[p + i];     // r = H0^-1 q
+    for (int i = tid; i < p; i += nth) qv[i] = part[i];
     __syncthreads();
     for (int k = 0; k < ord.m; ++k) {
         const int slot = ord.idx[k];
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
 }
 
 struct IrlsBuffers {
-    double *w, *g, *beta, *prev, *delta, *stats, *L, *Linv;
-    int* inv_valid;      // host flag: Linv is the inverse of the factor currently in L
+    double *w, *g, *beta, *prev, *delta, *stats, *L, *Linv, *Hinv;
+    int* inv_valid;      // host flag: Linv is the inverse of the factor currently in L (bit 0), Hinv = Linv' Linv (bit 1)
     double *qn_s, *qn_y, *qn_rho, *qn_alpha, *qn_q, *qn_gprev;
     void* ws_pass; size_t ws_pass_bytes;
 };
@@ -343,15 +347,23 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         const bool fused = qn_now && inv_enabled(p) && ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double) <= 64 * 1024;
         if (fused) {
             // reused factor, secant correction on: invert the factor once, then ONE launch per iteration
-            if (!*b.inv_valid) {
+            if (!(*b.inv_valid & 1)) {
                 rc = launch_tri_inverse(b.L, p, b.Linv, s);
                 if (rc) return rc;
                 *b.inv_valid = 1;
             }
+            if (!(*b.inv_valid & 2)) {
+                // H0^-1 = L^-T L^-1 is the Gram matrix of the rows of L^-1 (its upper triangle is zero): one tiny pass of
+                // the Gram kernel, after which H0^-1 q is ONE row-wise mat-vec instead of a row-wise and a column-wise
+                // triangular one (the column-wise one was 250 dependent loads per thread at p = 500)
+                rc = gram_impl_f64(b.Linv, p, nullptr, p, p, b.Hinv, p, 0, b.ws_pass, b.ws_pass_bytes, s);
+                if (rc) return rc;
+                *b.inv_valid |= 2;
+            }
             const size_t shm = ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double);
             hipLaunchKernelGGL(qn_step_kernel, dim3(1), dim3(1024), shm, s, (const double*)b.beta, (const double*)b.prev,
                                b.qn_gprev, (const double*)b.g, b.qn_s, b.qn_y, b.qn_rho, ord, push_slot, p, gscale,
-                               (const double*)b.Linv, b.delta, b.stats);
+                               (const double*)b.Hinv, b.delta, b.stats);
             DLSA_HIP_CHECK(hipGetLastError());
             qn_have_gprev = true;
         } else {
@@ -377,7 +389,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 rc = launch_chol_solve(H, p, 0, rhs, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
             } else if (inv_enabled(p)) {
                 // a reused factor: invert it once, then every solve is two mat-vecs instead of 2p/32 dependent block steps
-                if (!*b.inv_valid) {
+                if (!(*b.inv_valid & 1)) {
                     rc = launch_tri_inverse(b.L, p, b.Linv, s);
                     if (rc) return rc;
                     *b.inv_valid = 1;
@@ -460,6 +472,7 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
     b.stats = (double*)(base + l.stats);   // [0..2] solver stats, [3] loglik
     b.L = (double*)(base + l.L);
     b.Linv = (double*)(base + l.Linv);
+    b.Hinv = (double*)(base + l.Hinv);
     int inv_valid_flag = 0;
     b.inv_valid = &inv_valid_flag;
     b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
