@@ -176,7 +176,10 @@ __global__ __launch_bounds__(1024) void qn_post_kernel(double* __restrict__ r, c
 
 // One launch per quasi-Newton iteration: [push the new curvature pair] -> first loop -> x = H0^-1 q (explicit inverse) -> second loop
 // -> delta and stats, all in one 1024-thread workgroup (the separate kernels above cost five launches and their gaps
-// per iteration, which is what small partitions are made of).
+// per iteration, which is what small partitions are made of).  A thread owns EPT elements of every vector: q and the
+// (up to six) curvature pairs sit in registers, fetched with one round of independent loads, so the two loops are
+// register arithmetic + one block reduction per pair; only the mat-vec reads q through LDS.
+template <int EPT>
 __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict__ beta, const double* __restrict__ prev,
                                                        double* __restrict__ gprev, const double* __restrict__ g,
                                                        double* __restrict__ S, double* __restrict__ Y, double* __restrict__ rho,
@@ -185,53 +188,89 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
                                                        double* __restrict__ stats) {
     extern __shared__ double sm[];
     double* qv = sm;                 // p
-    double* yv = sm + p;             // p
-    double* part = yv + p;           // 2p
-    double* red = part + 2 * p;      // 48
-    double* alpha = red + 48;        // QN_PAIRS
-    double* srho = alpha + QN_PAIRS; // QN_PAIRS
+    double* part = sm + p;           // p
+    double* red = part + p;          // 48
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
-    if (push_slot >= 0) {
-        double* s = S + (int64_t)push_slot * p;
-        double* y = Y + (int64_t)push_slot * p;
-        double sy = 0.0;
-        for (int i = tid; i < p; i += nth) {
-            const double sv = beta[i] - prev[i], yv2 = gprev[i] - g[i];
-            s[i] = sv; y[i] = yv2;
-            sy = fma(sv, yv2, sy);
+    double q[EPT], sv[QN_PAIRS][EPT], yv[QN_PAIRS][EPT], rh[QN_PAIRS], alpha[QN_PAIRS];
+    // pairs by age (position k = ring slot ord.idx[k]); the pair pushed now is the newest one
+#pragma unroll
+    for (int k = 0; k < QN_PAIRS; ++k) {
+        const bool have = k < ord.m && !(push_slot >= 0 && k == ord.m - 1);
+        const int slot = ord.idx[k < ord.m ? k : 0];
+        rh[k] = have ? rho[slot] : 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * nth;
+            sv[k][e] = (have && i < p) ? S[(int64_t)slot * p + i] : 0.0;
+            yv[k][e] = (have && i < p) ? Y[(int64_t)slot * p + i] : 0.0;
         }
-        sy = block_sum(sy, red);
-        if (tid == 0) rho[push_slot] = (sy > 0.0 && isfinite(sy)) ? 1.0 / sy : 0.0;
-        __threadfence_block();
     }
-    for (int i = tid; i < p; i += nth) { const double gi = g[i]; qv[i] = gi; gprev[i] = gi; }
-    __syncthreads();
-    if (tid < QN_PAIRS) srho[tid] = rho[tid];
-    __syncthreads();
-    for (int k = ord.m - 1; k >= 0; --k) {
-        const int slot = ord.idx[k];
-        const double* s = S + (int64_t)slot * p;
-        const double* y = Y + (int64_t)slot * p;
-        double d = 0.0;
-        for (int i = tid; i < p; i += nth) d = fma(s[i], qv[i], d);
-        const double a = srho[slot] * block_sum(d, red);
-        if (tid == 0) alpha[slot] = a;
-        for (int i = tid; i < p; i += nth) qv[i] = fma(-a, y[i], qv[i]);
+    double sy = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nth;
+        const double gi = i < p ? g[i] : 0.0;
+        q[e] = gi;
+        if (push_slot >= 0 && i < p) {
+            const double s1 = beta[i] - prev[i], y1 = gprev[i] - gi;
+            S[(int64_t)push_slot * p + i] = s1;
+            Y[(int64_t)push_slot * p + i] = y1;
+            sy = fma(s1, y1, sy);
+#pragma unroll
+            for (int k = 0; k < QN_PAIRS; ++k)
+                if (k == ord.m - 1) { sv[k][e] = s1; yv[k][e] = y1; }
+        }
+        if (i < p) gprev[i] = gi;
+    }
+    if (push_slot >= 0) {
+        sy = block_sum(sy, red);
+        const double r1 = (sy > 0.0 && isfinite(sy)) ? 1.0 / sy : 0.0;
+        if (tid == 0) rho[push_slot] = r1;
+#pragma unroll
+        for (int k = 0; k < QN_PAIRS; ++k)
+            if (k == ord.m - 1) rh[k] = r1;
         __syncthreads();
     }
-    for (int i = tid; i < p; i += nth) qv[i] *= gscale;
+#pragma unroll
+    for (int k = QN_PAIRS - 1; k >= 0; --k) {
+        alpha[k] = 0.0;
+        if (k < ord.m) {
+            double d = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) d = fma(sv[k][e], q[e], d);
+            const double a = rh[k] * block_sum(d, red);
+            alpha[k] = a;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) q[e] = fma(-a, yv[k][e], q[e]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nth;
+        if (i < p) qv[i] = q[e] * gscale;
+    }
     __syncthreads();
-    // r = H0^-1 q with the explicit inverse: one wave per row, four rows (all their loads) in flight per trip
+    // r = H0^-1 q with the explicit inverse: a wave takes four rows at a time and issues their 32 loads per lane (512
+    // columns) before the first multiply -- clamped addresses, zero multipliers, no branches around the loads: this
+    // phase is one CU pulling p^2 doubles from L2, so what counts is loads in flight
     for (int i0 = 4 * wave; i0 < p; i0 += 4 * nw) {
         double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < p; k0 += 512) {
+            double hv[4][8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double* row = Hinv + (int64_t)min(i0 + r, p - 1) * p;
-            double s0 = 0.0, s1 = 0.0;
-            int k = lane;
-            for (; k + 64 < p; k += 128) { s0 = fma(row[k], qv[k], s0); s1 = fma(row[k + 64], qv[k + 64], s1); }
-            if (k < p) s0 = fma(row[k], qv[k], s0);
-            acc4[r] = s0 + s1;
+            for (int r = 0; r < 4; ++r) {
+                const double* row = Hinv + (int64_t)min(i0 + r, p - 1) * p;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) hv[r][c] = row[min(k0 + lane + 64 * c, p - 1)];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = k0 + lane + 64 * c;
+                const double x = k < p ? qv[min(k, p - 1)] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[r] = fma(hv[r][c], x, acc4[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -240,26 +279,35 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
         }
     }
     __syncthreads();
-    for (int i = tid; i < p; i += nth) qv[i] = part[i];
-    __syncthreads();
-    for (int k = 0; k < ord.m; ++k) {
-        const int slot = ord.idx[k];
-        const double* s = S + (int64_t)slot * p;
-        const double* y = Y + (int64_t)slot * p;
-        double d = 0.0;
-        for (int i = tid; i < p; i += nth) d = fma(y[i], qv[i], d);
-        const double c = alpha[slot] - srho[slot] * block_sum(d, red);
-        for (int i = tid; i < p; i += nth) qv[i] = fma(c, s[i], qv[i]);
-        __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nth;
+        q[e] = i < p ? part[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < QN_PAIRS; ++k) {
+        if (k < ord.m) {
+            double d = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) d = fma(yv[k][e], q[e], d);
+            const double c = alpha[k] - rh[k] * block_sum(d, red);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) q[e] = fma(c, sv[k][e], q[e]);
+            __syncthreads();
+        }
     }
     double mx = 0.0, mr = 0.0;
     int bad = 0;
-    for (int i = tid; i < p; i += nth) {
-        const double v = qv[i];
-        delta[i] = v;
-        mx = fmax(mx, fabs(v));
-        if (!isfinite(v)) bad = 1;
-        mr = fmax(mr, fabs(beta[i]));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nth;
+        if (i < p) {
+            const double v = q[e];
+            delta[i] = v;
+            mx = fmax(mx, fabs(v));
+            if (!isfinite(v)) bad = 1;
+            mr = fmax(mr, fabs(beta[i]));
+        }
     }
     for (int m = 32; m >= 1; m >>= 1) {
         mx = fmax(mx, __shfl_xor(mx, m, 64));
@@ -360,10 +408,13 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 if (rc) return rc;
                 *b.inv_valid |= 2;
             }
-            const size_t shm = ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double);
-            hipLaunchKernelGGL(qn_step_kernel, dim3(1), dim3(1024), shm, s, (const double*)b.beta, (const double*)b.prev,
-                               b.qn_gprev, (const double*)b.g, b.qn_s, b.qn_y, b.qn_rho, ord, push_slot, p, gscale,
-                               (const double*)b.Hinv, b.delta, b.stats);
+            const size_t shm = ((size_t)2 * p + 48) * sizeof(double);
+#define DLSA_QN_STEP(EPT) hipLaunchKernelGGL(qn_step_kernel<EPT>, dim3(1), dim3(1024), shm, s, (const double*)b.beta, \
+                                             (const double*)b.prev, b.qn_gprev, (const double*)b.g, b.qn_s, b.qn_y, b.qn_rho, ord, \
+                                             push_slot, p, gscale, (const double*)b.Hinv, b.delta, b.stats)
+            if (p <= 1024) DLSA_QN_STEP(1);
+            else DLSA_QN_STEP(2);
+#undef DLSA_QN_STEP
             DLSA_HIP_CHECK(hipGetLastError());
             qn_have_gprev = true;
         } else {
