@@ -25,6 +25,10 @@ namespace dlsa {
 constexpr int OH_MAXD = 8;            // dense columns (intercept + numerics) handled in registers
 constexpr int OH_MAXF = 8;            // factors
 constexpr int OH_THREADS = 256;
+#ifndef DLSA_OH_GRAM_THREADS
+#define DLSA_OH_GRAM_THREADS 1024
+#endif
+constexpr int OH_GRAM_THREADS = DLSA_OH_GRAM_THREADS;      // the Gram pass: one workgroup per CU (its tables fill the LDS), so all its latency hiding is waves
 constexpr int OH_LDS_BUDGET = 120 * 1024;     // bytes of histogram tables per workgroup role
 constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
@@ -49,6 +53,7 @@ struct OhDesc {                       // device-visible description of the desig
     int dense_col[OH_MAXD];           // output column of dense column a
     int lvl_off[OH_MAXF + 1];         // factor t's levels occupy [lvl_off[t], lvl_off[t+1]) of level_col
     int nlev_total;
+    int dbg;                          // DLSA_OH_DBG (timing experiments only, wrong results): 1 = no dense x level atomics, 2 = no pair-table atomics
 };
 
 }  // namespace dlsa
@@ -180,7 +185,7 @@ void logit_finish_launch(const double* gpart, const double* llpart, int nblocks,
 // ---------------------------------------------------------------------------------------------------------------
 // Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OH_THREADS) void oh_gram_kernel(OhDesc ds, const OhRole* __restrict__ roles, int nroles,
+__global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, const OhRole* __restrict__ roles, int nroles,
                                                              int blocks_per_role, const double* __restrict__ num, int64_t ldn,
                                                              const int32_t* __restrict__ codes, int64_t ldc,
                                                              const double* __restrict__ w, int64_t n,
@@ -222,13 +227,13 @@ __global__ __launch_bounds__(OH_THREADS) void oh_gram_kernel(OhDesc ds, const Oh
                     double* dst = tab + role.dense_off + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
 #pragma unroll
                     for (int a = 0; a < OH_MAXD; ++a)
-                        if (a < ds.D) unsafeAtomicAdd(dst + a, wi * d[a]);
+                        if (a < ds.D && !(ds.dbg & 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
                 }
         }
         for (int q = 0; q < role.ntab; ++q) {
             const OhTable tb = role.tab[q];
             const int lt = lv[tb.t], lu = lv[tb.u];
-            if (lt < 0 || lu < 0) continue;
+            if (lt < 0 || lu < 0 || (ds.dbg & 2)) continue;
             if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
             else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
         }
@@ -346,7 +351,8 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
                      const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s) {
     DLSA_REQUIRE(pl && H && ldh >= pl->desc.p && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot gram: null argument or ldh < p");
-    const OhDesc& ds = pl->desc;
+    OhDesc ds = pl->desc;
+    { const char* e = getenv("DLSA_OH_DBG"); ds.dbg = e ? atoi(e) : 0; }
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -361,7 +367,7 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
     const size_t shm = (max_cells + 16) * sizeof(double);
     if (shm > 64 * 1024)
         DLSA_HIP_CHECK(hipFuncSetAttribute((const void*)oh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(oh_gram_kernel, dim3(nb * nroles), dim3(OH_THREADS), shm, s, ds, (const OhRole*)pl->d_roles, nroles, nb,
+    hipLaunchKernelGGL(oh_gram_kernel, dim3(nb * nroles), dim3(OH_GRAM_THREADS), shm, s, ds, (const OhRole*)pl->d_roles, nroles, nb,
                        num, ldn, codes, ldc, w, n, (double*)ws, role_stride);
     DLSA_HIP_CHECK(hipGetLastError());
     for (int r = 0; r < nroles; ++r) {
