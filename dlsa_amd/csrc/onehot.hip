@@ -29,7 +29,7 @@ constexpr int OH_THREADS = 256;
 #define DLSA_OH_GRAM_THREADS 1024
 #endif
 constexpr int OH_GRAM_THREADS = DLSA_OH_GRAM_THREADS;      // the Gram pass: one workgroup per CU (its tables fill the LDS), so all its latency hiding is waves
-constexpr int OH_LDS_BUDGET = 120 * 1024;     // bytes of histogram tables per workgroup role
+constexpr int OH_LDS_BUDGET = 152 * 1024;     // bytes of histogram tables per workgroup role
 constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
 struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
@@ -42,7 +42,10 @@ struct OhRole {
     OhTable tab[OH_MAXF * (OH_MAXF + 1) / 2];
     int with_dense;                   // this role also accumulates H_DD and H_D,dummy
     int dense_off;                    // offset of the D x nlev_total block (H_D,dummy), if with_dense
-    int cells;                        // doubles in the LDS image
+    int cells;                        // doubles in the LDS image (and in the role's partial)
+    int dense_rep;                    // copies of the H_D,dummy block in LDS (copy r >= 1 sits after the image, at
+                                      // cells + (r-1) * nlev_total * OH_MAXD): lanes spread over them, so the lanes of a
+                                      // wave that share a hot level do not all serialise on the same eight addresses
 };
 
 struct OhDesc {                       // device-visible description of the design
@@ -194,9 +197,13 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
     const int role_id = blockIdx.x / blocks_per_role;
     const int bl = blockIdx.x % blocks_per_role;
     const OhRole& role = roles[role_id];
-    double* tab = sm;                              // role.cells
-    double* red = sm + role.cells;                 // 16
-    for (int j = threadIdx.x; j < role.cells; j += blockDim.x) tab[j] = 0.0;
+    const int dblock = ds.nlev_total * OH_MAXD;
+    const int lds_cells = role.cells + (role.with_dense ? (role.dense_rep - 1) * dblock : 0);
+    double* tab = sm;                              // lds_cells
+    double* red = sm + lds_cells;                  // 16
+    for (int j = threadIdx.x; j < lds_cells; j += blockDim.x) tab[j] = 0.0;
+    const int my_rep = role.with_dense ? (int)(threadIdx.x % role.dense_rep) : 0;
+    double* dense_tab = my_rep == 0 ? tab + role.dense_off : tab + role.cells + (my_rep - 1) * dblock;
     __syncthreads();
     double hdd[OH_MAXD * (OH_MAXD + 1) / 2];
 #pragma unroll
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
 #pragma unroll
             for (int t = 0; t < OH_MAXF; ++t)
                 if (t < ds.f && lv[t] >= 0) {
-                    double* dst = tab + role.dense_off + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
+                    double* dst = dense_tab + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
 #pragma unroll
                     for (int a = 0; a < OH_MAXD; ++a)
                         if (a < ds.D && !(ds.dbg & 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
@@ -239,6 +246,14 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
         }
     }
     __syncthreads();
+    if (role.with_dense && role.dense_rep > 1) {   // fold the copies (fixed order)
+        for (int j = threadIdx.x; j < dblock; j += blockDim.x) {
+            double t = tab[role.dense_off + j];
+            for (int r = 1; r < role.dense_rep; ++r) t += tab[role.cells + (r - 1) * dblock + j];
+            tab[role.dense_off + j] = t;
+        }
+        __syncthreads();
+    }
     double* out = partial + (int64_t)role_id * role_stride + (int64_t)bl * (role.cells + OH_MAXD * (OH_MAXD + 1) / 2);
     for (int j = threadIdx.x; j < role.cells; j += blockDim.x) out[j] = tab[j];
     if (dense) {
@@ -360,7 +375,10 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
     const int nb = oh_blocks(n);
     constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
     size_t per_role = 0, max_cells = 0;
-    for (auto& r : pl->roles) { per_role = std::max(per_role, (size_t)(r.cells + NDD)); max_cells = std::max(max_cells, (size_t)r.cells); }
+    for (auto& r : pl->roles) {
+        per_role = std::max(per_role, (size_t)(r.cells + NDD));
+        max_cells = std::max(max_cells, (size_t)r.cells + (r.with_dense ? (size_t)(r.dense_rep - 1) * ds.nlev_total * OH_MAXD : 0));
+    }
     const int64_t role_stride = (int64_t)(align_up(per_role * nb * sizeof(double), 256) / sizeof(double));
     const int nroles = (int)pl->roles.size();
     DLSA_HIP_CHECK(hipMemset2DAsync(H, (size_t)ldh * sizeof(double), 0, (size_t)ds.p * sizeof(double), (size_t)ds.p, s));
@@ -429,11 +447,15 @@ int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const 
     OhRole first; memset(&first, 0, sizeof(first));
     first.with_dense = 1; first.dense_off = 0; first.cells = ds.nlev_total * OH_MAXD;
     if (first.cells > budget) return fail("too many factor levels for the structured path");
+    // up to four LDS copies of the H_D,dummy block, as long as they leave half of the budget to the pair tables
+    first.dense_rep = 1;
+    while (first.dense_rep < 4 && 2 * first.dense_rep * first.cells <= budget / 2) first.dense_rep *= 2;
+    const int first_extra = (first.dense_rep - 1) * first.cells;
     pl->roles.push_back(first);
     for (auto& pd : pend) {
         if (pd.cells > budget) return fail("a factor-pair table exceeds the LDS budget: use the dense path");
         OhRole* dst = nullptr;
-        for (auto& r : pl->roles) if (r.cells + pd.cells <= budget) { dst = &r; break; }
+        for (auto& r : pl->roles) if (r.cells + (r.with_dense ? first_extra : 0) + pd.cells <= budget) { dst = &r; break; }
         if (!dst) { OhRole nr; memset(&nr, 0, sizeof(nr)); pl->roles.push_back(nr); dst = &pl->roles.back(); }
         dst->tab[dst->ntab++] = OhTable{pd.t, pd.u, dst->cells};
         dst->cells += pd.cells;
