@@ -536,7 +536,7 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
     const char* env_sub = getenv("DLSA_IRLS_SUBSAMPLE");
     const char* env_frz = getenv("DLSA_IRLS_FREEZE");
     const int sub_div = env_sub ? atoi(env_sub) : 16;          // 0/1 disables the warm start
-    const double freeze_at = env_frz ? atof(env_frz) : 1e-1;   // 0 disables the frozen Hessian
+    const double freeze_at = env_frz ? atof(env_frz) : 1.0;    // 0 disables the frozen Hessian
 
     const char* env_warm = getenv("DLSA_IRLS_WARM");
     const bool warm_ok = env_warm ? atoi(env_warm) != 0 : true;   // 0 disables partition-to-partition warm starts
