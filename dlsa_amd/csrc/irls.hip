@@ -361,7 +361,9 @@ static bool qn_enabled() {
 static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_iter,
                       double freeze_at, double* H, const IrlsBuffers& b, hipStream_t s, int* status, int* iters,
                       int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
-    double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY;
+    double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY, dprev2 = INFINITY;
+    const char* env_pred = getenv("DLSA_IRLS_PREDICT");
+    const bool predict_on = env_pred ? atoi(env_pred) != 0 : true;
     bool have_prev = false, need_H = !(inherit_scale > 0.0), have_factor = inherit_scale > 0.0;
     double gscale = inherit_scale > 0.0 ? 1.0 / inherit_scale : 1.0;
     int halvings = 0;
@@ -484,9 +486,23 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             *fresh = fresh_now;
             return DLSA_OK;
         }
+        // Predicted convergence: the steps have contracted by r <= 0.2 twice in a row, this one is within 100 tol, and the
+        // next one (<= r |delta|) would pass the test: take the step and stop.  The returned coef then meets the tolerance
+        // without the confirming logit pass; Sig_inv is evaluated |delta| <= 100 tol away from it (1e-11 relative).
+        if (predict_on && it >= 3 && isfinite(dprev2) && h[0] <= 100.0 * tol * scale) {
+            const double r = std::max(h[0] / dprev, dprev / dprev2);
+            if (r <= 0.2 && r * h[0] <= tol * scale) {
+                rc = launch_axpby(b.beta, b.delta, 1.0, p, b.beta, s);
+                if (rc) return rc;
+                *status = DLSA_PART_OK;
+                *fresh = false;
+                return DLSA_OK;
+            }
+        }
         // frozen-Hessian policy: keep the factor while steps are small and still shrinking fast
         if (!fresh_now && h[0] > 0.25 * dprev) need_H = true;            // stalled: refresh
         else need_H = h[0] > freeze_at * scale;
+        dprev2 = dprev;
         dprev = h[0];
         DLSA_HIP_CHECK(hipMemcpyAsync(b.prev, b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
         rc = launch_axpby(b.beta, b.delta, 1.0, p, b.beta, s);

@@ -101,7 +101,7 @@ def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
     base = eng.irls_fit(X, y, offs)
     assert base["status"] == [0, 0, 0]
     keys = ("DLSA_IRLS_SUBSAMPLE", "DLSA_IRLS_FREEZE", "DLSA_IRLS_WARM", "DLSA_IRLS_INHERIT", "DLSA_IRLS_SECANT",
-            "DLSA_IRLS_INVERSE", "DLSA_IRLS_POOL")
+            "DLSA_IRLS_INVERSE", "DLSA_IRLS_POOL", "DLSA_IRLS_PREDICT")
     try:
         for k in keys:
             os.environ[k] = "0"
