@@ -30,6 +30,7 @@ constexpr int OH_THREADS = 256;
 #endif
 constexpr int OH_GRAM_THREADS = DLSA_OH_GRAM_THREADS;      // the Gram pass: one workgroup per CU (its tables fill the LDS), so all its latency hiding is waves
 constexpr int OH_LDS_BUDGET = 152 * 1024;     // bytes of histogram tables per workgroup role
+constexpr int OH_LOGIT_REP = 8;             // LDS copies of the logit pass's residual histogram
 constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
 struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
@@ -125,10 +126,13 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
                                                               double* __restrict__ gpart, double* __restrict__ llpart) {
     extern __shared__ double sm[];
     double* sbeta = sm;                           // p
-    double* sg = sm + ds.p;                       // p   (histogram of residuals)
-    int* scol = reinterpret_cast<int*>(sm + 2 * ds.p);     // nlev_total
+    double* sg = sm + ds.p;                       // OH_LOGIT_REP x p (histograms of residuals; lanes spread over the copies,
+                                                  // so the lanes of a wave that share a hot level do not serialise on one address)
+    int* scol = reinterpret_cast<int*>(sm + (1 + OH_LOGIT_REP) * ds.p);     // nlev_total
     double* red = reinterpret_cast<double*>(scol + ((ds.nlev_total + 1) & ~1));
-    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) { sbeta[j] = beta[j]; sg[j] = 0.0; }
+    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) sbeta[j] = beta[j];
+    for (int j = threadIdx.x; j < OH_LOGIT_REP * ds.p; j += blockDim.x) sg[j] = 0.0;
+    double* sg_mine = sg + (threadIdx.x % OH_LOGIT_REP) * ds.p;
     for (int j = threadIdx.x; j < ds.nlev_total; j += blockDim.x) scol[j] = level_col[j];
     __syncthreads();
     double gd[OH_MAXD];
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
         for (int a = 0; a < OH_MAXD; ++a) gd[a] = fma(r, d[a], gd[a]);
 #pragma unroll
         for (int t = 0; t < OH_MAXF; ++t)
-            if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg[cols[t]], r);
+            if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg_mine[cols[t]], r);
     }
     __syncthreads();
 #pragma unroll
@@ -177,7 +181,11 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
     const double sll = oh_block_sum(ll, red);
     __syncthreads();
     double* gp = gpart + (int64_t)blockIdx.x * ds.p;
-    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) gp[j] = sg[j];
+    for (int j = threadIdx.x; j < ds.p; j += blockDim.x) {
+        double t = sg[j];
+        for (int r = 1; r < OH_LOGIT_REP; ++r) t += sg[r * ds.p + j];      // fixed order
+        gp[j] = t;
+    }
     if (threadIdx.x == 0) llpart[blockIdx.x] = sll;
 }
 
@@ -324,12 +332,20 @@ static int oh_blocks(int64_t n) {
     const int64_t want = (n + OH_THREADS * 16 - 1) / (OH_THREADS * 16);
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, OH_MAX_BLOCKS));
 }
+// The logit pass keeps little in LDS, so many small workgroups share a CU: four rows per thread, up to eight
+// workgroups per CU (a 1e6-row partition: 977 workgroups instead of 244 -- one per CU, four waves, nothing to hide the
+// row loads behind: 72 us for 76 MB)
+constexpr int OH_LOGIT_MAX_BLOCKS = 2048;
+static int oh_logit_blocks(int64_t n) {
+    const int64_t want = (n + OH_THREADS * 4 - 1) / (OH_THREADS * 4);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, OH_LOGIT_MAX_BLOCKS));
+}
 
 int onehot_plan_p(const dlsa_onehot_plan* pl) { return pl->desc.p; }
 
 size_t onehot_workspace_bytes_impl(const dlsa_onehot_plan* pl, int64_t n) {
-    const int nb = oh_blocks(n);
-    size_t logit = align_up((size_t)nb * pl->desc.p * sizeof(double), 256) + align_up((size_t)nb * sizeof(double), 256);
+    const int nb = oh_blocks(n), nbl = oh_logit_blocks(n);
+    size_t logit = align_up((size_t)nbl * pl->desc.p * sizeof(double), 256) + align_up((size_t)nbl * sizeof(double), 256);
     size_t gram = 0;
     constexpr int NDD = OH_MAXD * (OH_MAXD + 1) / 2;
     for (auto& r : pl->roles) gram = std::max(gram, (size_t)(r.cells + NDD));
@@ -347,11 +363,11 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
         set_error("onehot logit pass: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    const int nb = oh_blocks(n);
+    const int nb = oh_logit_blocks(n);
     Arena ar(ws, ws_bytes);
     double* gpart = (double*)ar.take((size_t)nb * ds.p * sizeof(double));
     double* llpart = (double*)ar.take((size_t)nb * sizeof(double));
-    const size_t shm = (size_t)(2 * ds.p + 16) * sizeof(double) + (size_t)((ds.nlev_total + 1) & ~1) * sizeof(int);
+    const size_t shm = (size_t)((1 + OH_LOGIT_REP) * ds.p + 16) * sizeof(double) + (size_t)((ds.nlev_total + 1) & ~1) * sizeof(int);
     hipLaunchKernelGGL(oh_logit_kernel, dim3(nb), dim3(OH_THREADS), shm, s, ds, (const int32_t*)pl->d_level_col, num, ldn, codes,
                        ldc, y, beta, n, w_out, gpart, llpart);
     DLSA_HIP_CHECK(hipGetLastError());
