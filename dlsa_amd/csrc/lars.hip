@@ -17,8 +17,9 @@
 //     same vector u by symmetry and are computed once;
 //   * RSS_k = (b-beta_k)' Sigma (b-beta_k) (lsa.py:190-192) equals (b-beta_k).Cvec_k because
 //     Cvec_k = Sigma (b - beta_k) is carried along the path -- O(p) per step instead of O(p^2);
-//   * a lasso drop (lsa.py:179-186) rebuilds R^{-1} for the remaining active set instead of
-//     Givens-downdating R (lsa.py:35-80); the factor of the remaining ordered set is unique.
+//   * a lasso drop (lsa.py:179-186) re-appends the positions from the first dropped one on (the factor of the ordered
+//     set before it is unchanged) instead of Givens-downdating R (lsa.py:35-80); the factor of the remaining ordered
+//     set is unique.
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -450,16 +451,24 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
                 if (dropf[i]) { beta[sh_act[i]] = 0.0; state[sh_act[i]] = 0; }
             __syncthreads();
             if (tid == 0) {
-                int q = 0;
-                for (int i = 0; i < na; ++i)
+                int q = 0, first = na;
+                for (int i = 0; i < na; ++i) {
                     if (!dropf[i]) { active[q] = active[i]; sgn[q] = sgn[i]; ++q; }
-                sh_i[1] = q;
+                    else if (first == na) first = i;
+                }
+                sh_i[1] = q; sh_i[3] = first;
             }
             __syncthreads();
-            const int keep = sh_i[1];
-            // rebuild R^{-1}, t and Gi1 for the remaining ordered active set
-            tsq = 0.0;
-            for (int i = 0; i < keep; ++i) append_column(fac, i, active[i], sgn[i], 0.0, tsq);
+            const int keep = sh_i[1], first = sh_i[3];
+            // The factor of the positions before the first dropped one is unchanged: they keep their rows of R^{-1} and
+            // their entries of t; Gi1 there loses the later positions' terms (one triangular mat-vec over [i, first)).
+            // The positions from `first` on are appended again.
+            double tpart = 0.0;
+            for (int i = tid; i < first; i += LARS_THREADS) tpart = fma(fac.t[i], fac.t[i], tpart);
+            tsq = block_sum(tpart, red);
+            tri_matvec<false>(fac.Rinv, ld, first, fac.t, [&](int i, double sum) { fac.gi1[i] = sum; });
+            __syncthreads();
+            for (int i = first; i < keep; ++i) append_column(fac, i, active[i], sgn[i], 0.0, tsq);
             na = keep;
         }
         LARS_TICK(6);
@@ -818,16 +827,23 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
         __syncthreads();
         if (had_drops) {
             if (tid == 0) {
-                int q = 0;
-                for (int i = 0; i < na; ++i)
+                int q = 0, first = na;
+                for (int i = 0; i < na; ++i) {
                     if (act[i] >= 0) { act[q] = act[i]; sgn[q] = sgn[i]; ++q; }
-                sh_i[1] = q;
+                    else if (first == na) first = i;
+                }
+                sh_i[1] = q; sh_i[3] = first;
             }
             __syncthreads();
-            const int keep = sh_i[1];
-            // rebuild R^{-1}, t and Gi1 for the remaining ordered active set
-            tsq = 0.0;
-            for (int i = 0; i < keep; ++i) append_column_grid(fac, i, act[i], (double)sgn[i], 0.0, tsq, phase, dirty);
+            const int keep = sh_i[1], first = sh_i[3];
+            // positions before the first dropped one keep their rows of R^{-1} and their entries of t (their Gi1 loses the
+            // later positions' terms: one triangular mat-vec by the row owners); the positions from `first` on are appended again
+            double part = 0.0;
+            for (int i = tid; i < first; i += LARS_THREADS) part = fma(tv[i], tv[i], part);
+            tsq = block_sum(part, red);
+            tri_matvec_rows<false>(a.Rinv, ld, first, tv, g, G, [&](int i, double sum) { gi1[i] = sum; });
+            __syncthreads();
+            for (int i = first; i < keep; ++i) append_column_grid(fac, i, act[i], (double)sgn[i], 0.0, tsq, phase, dirty);
             na = keep;
         }
         LARS_TICK(9);
