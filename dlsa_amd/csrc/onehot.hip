@@ -30,7 +30,13 @@ constexpr int OH_THREADS = 256;
 #endif
 constexpr int OH_GRAM_THREADS = DLSA_OH_GRAM_THREADS;      // the Gram pass: one workgroup per CU (its tables fill the LDS), so all its latency hiding is waves
 constexpr int OH_LDS_BUDGET = 152 * 1024;     // bytes of histogram tables per workgroup role
-constexpr int OH_LOGIT_REP = 8;             // LDS copies of the logit pass's residual histogram
+constexpr int OH_LOGIT_REP = 8;             // LDS copies (at most) of the logit pass's residual histogram
+// copies actually used: as many as keep the workgroup's LDS near 32 KB (several workgroups per CU), at least one
+static int oh_logit_rep(int p) {
+    int r = OH_LOGIT_REP;
+    while (r > 1 && (size_t)(1 + r) * p * sizeof(double) > 32 * 1024) r /= 2;
+    return r;
+}
 constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
 struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
@@ -123,16 +129,16 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
                                                               const int32_t* __restrict__ codes, int64_t ldc,
                                                               const double* __restrict__ y, const double* __restrict__ beta,
                                                               int64_t n, double* __restrict__ w_out,
-                                                              double* __restrict__ gpart, double* __restrict__ llpart) {
+                                                              double* __restrict__ gpart, double* __restrict__ llpart, int nrep) {
     extern __shared__ double sm[];
     double* sbeta = sm;                           // p
-    double* sg = sm + ds.p;                       // OH_LOGIT_REP x p (histograms of residuals; lanes spread over the copies,
+    double* sg = sm + ds.p;                       // nrep x p (histograms of residuals; lanes spread over the copies,
                                                   // so the lanes of a wave that share a hot level do not serialise on one address)
-    int* scol = reinterpret_cast<int*>(sm + (1 + OH_LOGIT_REP) * ds.p);     // nlev_total
+    int* scol = reinterpret_cast<int*>(sm + (1 + nrep) * ds.p);     // nlev_total
     double* red = reinterpret_cast<double*>(scol + ((ds.nlev_total + 1) & ~1));
     for (int j = threadIdx.x; j < ds.p; j += blockDim.x) sbeta[j] = beta[j];
-    for (int j = threadIdx.x; j < OH_LOGIT_REP * ds.p; j += blockDim.x) sg[j] = 0.0;
-    double* sg_mine = sg + (threadIdx.x % OH_LOGIT_REP) * ds.p;
+    for (int j = threadIdx.x; j < nrep * ds.p; j += blockDim.x) sg[j] = 0.0;
+    double* sg_mine = sg + (threadIdx.x % nrep) * ds.p;
     for (int j = threadIdx.x; j < ds.nlev_total; j += blockDim.x) scol[j] = level_col[j];
     __syncthreads();
     double gd[OH_MAXD];
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
     double* gp = gpart + (int64_t)blockIdx.x * ds.p;
     for (int j = threadIdx.x; j < ds.p; j += blockDim.x) {
         double t = sg[j];
-        for (int r = 1; r < OH_LOGIT_REP; ++r) t += sg[r * ds.p + j];      // fixed order
+        for (int r = 1; r < nrep; ++r) t += sg[r * ds.p + j];      // fixed order
         gp[j] = t;
     }
     if (threadIdx.x == 0) llpart[blockIdx.x] = sll;
@@ -367,9 +373,10 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
     Arena ar(ws, ws_bytes);
     double* gpart = (double*)ar.take((size_t)nb * ds.p * sizeof(double));
     double* llpart = (double*)ar.take((size_t)nb * sizeof(double));
-    const size_t shm = (size_t)((1 + OH_LOGIT_REP) * ds.p + 16) * sizeof(double) + (size_t)((ds.nlev_total + 1) & ~1) * sizeof(int);
+    const int nrep = oh_logit_rep(ds.p);
+    const size_t shm = (size_t)((1 + nrep) * ds.p + 16) * sizeof(double) + (size_t)((ds.nlev_total + 1) & ~1) * sizeof(int);
     hipLaunchKernelGGL(oh_logit_kernel, dim3(nb), dim3(OH_THREADS), shm, s, ds, (const int32_t*)pl->d_level_col, num, ldn, codes,
-                       ldc, y, beta, n, w_out, gpart, llpart);
+                       ldc, y, beta, n, w_out, gpart, llpart, nrep);
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
         logit_finish_launch((const double*)gpart, (const double*)llpart, nb, ds.p, ds.p, g, loglik, s);
