@@ -1,22 +1,29 @@
 # Builds libdlsa_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+#   make            the product library (no wrong-result timing knobs: common.h DLSA_DBG_WRONG is the constant 0)
+#   make knobs      bench/libdlsa_hip_knobs.so with -DDLSA_DEBUG_KNOBS for timing experiments (never shipped / loaded by dlsa_amd)
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := dlsa_amd/csrc
-OUT   := dlsa_amd/libdlsa_hip.so
+OUT   ?= dlsa_amd/libdlsa_hip.so
+BUILD ?= build
+EXTRA ?=
 SRCS  := $(CSRC)/error.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
          $(CSRC)/irls.hip $(CSRC)/lars.hip
-OBJS  := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function
+OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function $(EXTRA)
 
 all: $(OUT)
 
-build/%.o: $(CSRC)/% $(CSRC)/common.h include/dlsa_hip.h
-	@mkdir -p build
+$(BUILD)/%.o: $(CSRC)/% $(CSRC)/common.h $(wildcard $(CSRC)/*.inc) include/dlsa_hip.h
+	@mkdir -p $(BUILD)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
+knobs:
+	$(MAKE) BUILD=build/knobs OUT=bench/libdlsa_hip_knobs.so EXTRA=-DDLSA_DEBUG_KNOBS
+
 clean:
-	rm -rf build $(OUT)
-.PHONY: all clean
+	rm -rf build $(OUT) bench/libdlsa_hip_knobs.so
+.PHONY: all clean knobs

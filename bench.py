@@ -2,22 +2,31 @@
 """bench.py -- rows/s through the X'WX Gram kernel at p=500 (BASELINE.json's metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload): BASELINE config 3's per-GPU row shard -- synthetic Gaussian logistic
-rows, 2.5e7 x 500 fp64 = 100 GB resident in HBM per GPU (weak scaling: every rank owns the rows
-[rank*R, (rank+1)*R) of the same seeded stream).  One STEP = one pass of the weighted Gram
-H = X' diag(w) X over the rank's shard (w = mu(1-mu) at the true coefficients) and, for N>1, the
-algorithm's one-round communication: a single RCCL all-reduce of the [Sig_inv | Sig_inv.theta |
-theta] message (p^2+2p doubles).  value = total rows of all ranks / max-over-ranks time.
+N = 1 runs in this process.  N > 1 needs one process per GPU: when the script is started WITHOUT a
+torch.distributed environment (no WORLD_SIZE) it launches the N ranks itself -- before anything in this
+process touches the GPU -- as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+and relays rank 0's JSON line; started under torch.distributed.run (the driver's form) it is one of the ranks and
+insists that WORLD_SIZE == --gpus.
 
-The same JSON line carries `roofline` (Gram kernel vs the fp64 MFMA peak, HIP-event timed on
-the launch stream) and `cpu_baseline` (the numpy oracle's Gram on the host cores, bounded
-sample), plus `extra` with the HBM-bound logit pass and the end-to-end fit for reference.
+Workload (config.workload): BASELINE config 3's per-GPU row shard -- synthetic Gaussian logistic rows,
+2.5e7 x 500 fp64 = 100 GB resident in HBM per GPU (weak scaling: every rank owns the rows [rank*R, (rank+1)*R) of the
+same seeded stream).  One STEP = one pass of the weighted Gram H = X' diag(w) X over the rank's shard (w = mu(1-mu)
+at the true coefficients) and, for N>1, the algorithm's one round of communication (reference dlsa/dlsa.py:30-34):
+a single all-reduce (RCCL over xGMI) of the [Sig_inv | Sig_inv.theta | theta] message (p^2+2p doubles).
+value = total rows of all ranks / max-over-ranks time.
+
+The same JSON line carries `roofline` (Gram kernel vs the fp64 MFMA peak, HIP-event timed on the launch stream),
+`allreduce` (the collective, timed inside the steps and on its own), `cpu_baseline` (the numpy oracle of the hot
+path on the host cores, bounded sample; N=1 only) and `extra` (the HBM-bound logit pass, optionally the whole fit).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TF = 78.6    # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (= fp32 vector 157.3 / 2; DESIGN.md)
+FP64_MFMA_PEAK_TF = 78.6    # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (= fp32 vector 157.3 / 2; DESIGN.md section 2)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -42,61 +51,122 @@ def parse():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the end-to-end fit (IRLS + combine + LARS); off by default so that every\n"
                          "gram_kernel launch of the default command has the benchmark's size (rocprof averages)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    return ap.parse_args()
+    ap.add_argument("--cpu-rows-per-partition", type=int, default=0, help="0 = sized by oracle/cpu_baseline.py")
+    ap.add_argument("--cpu-gram-rows", type=int, default=400_000)
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(p, sample_rows, seed):
-    """The oracle's Gram (numpy -> multithreaded BLAS dgemm, what models.py:130 runs) on a
-    bounded sample of the same synthetic rows, timed on this box's host cores."""
-    import numpy as np
-    from oracle import dlsa_oracle as orc
-    X = orc.synth_features(seed, 0, sample_rows, p, orc.SYNTH_GAUSSIAN)
-    beta = orc.true_beta(p)
-    w, _, _ = orc.logit_pass(X, np.zeros(sample_rows), beta)
-    orc.gram(X[:20000], w[:20000])          # warm the BLAS threads
-    reps, t_total = 0, 0.0
-    while t_total < 10.0 and reps < 50:
-        t0 = time.perf_counter()
-        orc.gram(X, w)
-        t_total += time.perf_counter() - t0
-        reps += 1
+# --------------------------------------------------------------------------------------------------
+# N > 1 without a torch.distributed environment: start the ranks (this process never touches the GPU)
+# --------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("[bench] the %d-rank run failed (exit code %d, %s JSON line)" %
+              (args.gpus, proc.returncode, "no" if line is None else "a"), file=sys.stderr)
+        return proc.returncode or 1
+    out = json.loads(line)
+    if out.get("n_gpus") != args.gpus:
+        print("[bench] rank 0 reported n_gpus=%r, expected %d" % (out.get("n_gpus"), args.gpus), file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------
+def _sha16(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def traffic_from_profile(p, R):
+    """HBM-side bytes per Gram launch from the committed PMC passes (profiles/pmc_latest.json: FETCH_SIZE x2, the
+    gfx950 correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE, both in KB), scaled to R rows.  The profile
+    records the hash of the kernel source it was taken from: a profile of a different gram.hip gives null."""
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": sample_rows * reps / t_total, "unit": "rows/s", "cores": int(cores), "kind": "port",
-            "sample": "oracle.gram (numpy/BLAS X'diag(w)X) on %d x %d fp64 synthetic Gaussian rows, %d passes, %.1f s"
-                      % (sample_rows, p, reps, t_total)}
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if prof.get("p", 500) != p:
+            return None, "profiles/pmc_latest.json is for p=%s" % prof.get("p")
+        have = _sha16(os.path.join(ROOT, "dlsa_amd", "csrc", "gram.hip"))
+        if prof.get("gram_hip_sha16") != have:
+            return None, "stale: profiles/pmc_latest.json was taken from gram.hip %s, the tree has %s" % (
+                prof.get("gram_hip_sha16"), have)
+        kk = [k for k in prof["kernels"] if "gram_kernel<double" in k][0]
+        per_row = (2.0 * prof["kernels"][kk]["FETCH_SIZE"] + prof["kernels"][kk]["WRITE_SIZE"]) * 1024.0 / prof["rows_per_gpu"]
+        return per_row * R, ("profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in KB; FETCH x2 per "
+                             "MI355X_MICROARCH.md; gram.hip %s)" % have)
+    except Exception as e:
+        return None, "unavailable: %r" % (e,)
 
 
-def main():
-    args = parse()
-    import torch
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches the "
+                         "ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    p = args.p
+
+    # ---- CPU baseline first (rank 0, N=1 only): its worker processes are started before this process initialises
+    # the GPU, and it does not share the host with the GPU timing below
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline
+        cpu = cpu_baseline.run(p, args.seed, rows_per_partition=args.cpu_rows_per_partition or None,
+                               gram_rows=args.cpu_gram_rows)
+
+    import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    dist = None
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local % max(1, ndev))
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DLSA_BENCH_BACKEND", "nccl")      # "gloo": lets two ranks share one GPU in a dry run
         if backend == "nccl":
+            if ndev < world:
+                raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (DLSA_BENCH_BACKEND=gloo "
+                                 "lets ranks share a GPU for a dry run)" % (world, world, ndev))
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     from dlsa_amd import engine
 
-    p, R = args.p, args.rows_per_gpu
+    R = args.rows_per_gpu
+    sharing = max(1, (world + ndev - 1) // max(1, ndev))        # ranks per GPU (1 except in the gloo dry run)
     free, _ = torch.cuda.mem_get_info()
     need = R * p * 8 * 1.08
-    if need > free:
-        R = int(free / 1.08 / (p * 8))
+    if need > free / sharing:
+        R = int(free / sharing / 1.08 / (p * 8))
         print("[bench] shrinking rows-per-gpu to %d to fit %.0f GB free HBM" % (R, free / 1e9), file=sys.stderr)
+    if dist is not None:            # every rank must own the same number of rows (weak scaling)
+        rmin = torch.tensor([R], dtype=torch.int64, device="cuda")
+        dist.all_reduce(rmin, op=dist.ReduceOp.MIN)
+        R = int(rmin.item())
 
     def barrier():
         torch.cuda.synchronize()
@@ -115,7 +185,8 @@ def main():
 
     msg = torch.zeros(p * p + 2 * p, dtype=torch.float64, device="cuda")
     H = msg[: p * p].view(p, p)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    mk = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [(mk(), mk(), mk()) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
@@ -125,6 +196,8 @@ def main():
             ev[i][1].record()
         if dist is not None:
             dist.all_reduce(msg)
+        if i is not None:
+            ev[i][2].record()
 
     for _ in range(args.warmup):
         step()
@@ -138,7 +211,26 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    kern_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
+    comm_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
+
+    # ---- the collective on its own (all ranks): 20 back-to-back all-reduces of the message
+    allreduce = None
+    if dist is not None:
+        reps = 20
+        for _ in range(3):
+            dist.all_reduce(msg)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(msg)
+        barrier()
+        iso = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(iso, op=dist.ReduceOp.MAX)
+        nbytes = msg.numel() * 8
+        allreduce = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world, "payload_bytes": nbytes,
+                     "ms_in_step": comm_ms, "ms_isolated": float(iso.item()),
+                     "busbw_GBps_isolated": 2.0 * (world - 1) / world * nbytes / (float(iso.item()) * 1e-3) / 1e9}
 
     out = None
     if rank == 0:
@@ -147,23 +239,17 @@ def main():
         flops_row = p * (p + 1) + p             # algorithmic: upper triangle outer product + w scaling
         bytes_row = 8 * (p + 1)                 # algorithmic: the X row + w_i
         ach_tf = R * flops_row / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        try:    # HBM-side bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            assert prof.get("p", 500) == p
-            kk = [k for k in prof["kernels"] if "gram_kernel<double" in k][0]
-            per_row = (2.0 * prof["kernels"][kk]["FETCH_SIZE"] + prof["kernels"][kk]["WRITE_SIZE"]) * 1024.0 / prof["rows_per_gpu"]
-            traffic, traffic_src = per_row * R, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, KB; FETCH x2 per MI355X_MICROARCH.md)"
-        except Exception:
-            pass
+        traffic, traffic_src = traffic_from_profile(p, R)
         out = {
             "metric": "rows/sec through X'WX kernel at p=%d" % p, "value": value, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_ranks": world if backend == "nccl" else 0,
             "config": {"workload": "Logistic DLSA config 3 per-GPU row shard: synthetic Gaussian n=%d x p=%d fp64 "
                                    "per GPU (%.1f GB in HBM), weighted Gram X'WX pass%s" %
-                                   (R, p, R * p * 8 / 1e9, " + 1 RCCL all-reduce of p^2+2p f64" if world > 1 else ""),
+                                   (R, p, R * p * 8 / 1e9, " + 1 all-reduce of p^2+2p f64 (%s)" %
+                                    ("RCCL" if backend == "nccl" else backend) if world > 1 else ""),
                        "rows_per_gpu": R, "p": p, "partitions_per_gpu": 1, "parallelism": "row-shards x%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": traffic, "traffic_unit": "bytes per launch",
@@ -172,12 +258,13 @@ def main():
                          "algorithmic_flops_per_row": flops_row, "algorithmic_bytes_per_row": bytes_row,
                          "hbm_GBps_algorithmic": R * bytes_row / (kern_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": R * bytes_row / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "allreduce": allreduce,
         }
 
-    # ---- extras (rank 0, N=1 only): HBM-bound logit pass, end-to-end fit, config 2
+    # ---- extras (rank 0, N=1 only): HBM-bound logit pass, end-to-end fit
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {"gen_seconds": t_gen}
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = mk(), mk()
         engine.logit_pass(X, y, beta_true)
         torch.cuda.synchronize()
         e0.record()
@@ -204,20 +291,23 @@ def main():
                                        "map_plus_combine_s": t2 - t1, "lars_s": t3 - t2,
                                        "rows_per_s_whole_fit": R / (t3 - t1),
                                        "theta_err_vs_truth_linf": float((theta - beta_true).abs().max())}
-            del fit
+            del fit, path
         out["extra"] = extra
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        del X, y, w
-        torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_rows, args.seed)
-    elif rank == 0:
-        out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/dlsa_hip.h"
 
 namespace dlsa {
@@ -97,6 +98,26 @@ __device__ __forceinline__ double wave_allreduce_sum(double s) { return wave_all
 __device__ __forceinline__ double wave_allreduce_max(double s) { return wave_allreduce(s, WaveOpMax()); }
 __device__ __forceinline__ double wave_allreduce_min(double s) { return wave_allreduce(s, WaveOpMin()); }
 #endif
+
+// Timing-experiment knobs that produce WRONG RESULTS (DLSA_GRAM_DBG bits 1 / 16 / 128, DLSA_OH_DBG) exist only in
+// builds made with -DDLSA_DEBUG_KNOBS (bench/ experiment builds; never `make`): in the shipped library the tests
+// below are the constant 0 and the environment cannot change a result.  The valid-result A/B switches
+// (DLSA_GRAM_DBG 2 / 4 / 32 / 64, DLSA_GRAM_NOWIDE, DLSA_IRLS_*, DLSA_LARS_WGS) stay runtime switches.
+#ifdef DLSA_DEBUG_KNOBS
+#define DLSA_DBG_WRONG(mask, bit) ((mask) & (bit))
+#else
+#define DLSA_DBG_WRONG(mask, bit) 0
+#endif
+constexpr int kGramDbgValidBits = 2 | 4 | 32 | 64;
+static inline int gram_dbg_env() {
+    const char* e = getenv("DLSA_GRAM_DBG");
+    const int v = e ? atoi(e) : 0;
+#ifdef DLSA_DEBUG_KNOBS
+    return v;
+#else
+    return v & kGramDbgValidBits;
+#endif
+}
 
 constexpr int kNumXCD = 8;
 constexpr int kNumCU = 256;

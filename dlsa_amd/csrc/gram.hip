@@ -309,7 +309,7 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks && !(a.dbg & 1)) {
+        if (c + 1 < nchunks && !DLSA_DBG_WRONG(a.dbg, 1)) {
             if constexpr (DMA) stage_dma(c + 1, (c + 1) & 1);
             else stage_load(c + 1);
         }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
         } else {
             if (c + 1 < nchunks) stage_write((c + 1) & 1);
         }
-        if (!(a.dbg & 16)) __syncthreads();                    // dbg 16: timing experiment only (wrong results)
+        if (!DLSA_DBG_WRONG(a.dbg, 16)) __syncthreads();                    // dbg 16: timing experiment only (wrong results)
     }
 
     // epilogue: stored tiles -> this slab's partial buffer
@@ -767,7 +767,7 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     if (rc) return rc;
     const bool vec = (ldx % 2 == 0) && (((uintptr_t)X % (2 * sizeof(T))) == 0);
     int dbg = 0;
-    { const char* e = getenv("DLSA_GRAM_DBG"); dbg = e ? atoi(e) : 0; }
+    dbg = gram_dbg_env();
     int mode = vec ? 1 : 0;
     const bool use_list = pl.nt_list != 0 && vec && !(dbg & 32);      // list plan needs the aligned staging paths
     const int nitems = use_list ? pl.nitems_list : pl.nitems;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     int cur = 0, nxt2 = 2;                               // ring positions of chunk c and chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
-        if (!(a.dbg & 1)) stage(c + 2, nxt2);            // past the slab end: bounds-checked zeros, no traffic
+        if (!DLSA_DBG_WRONG(a.dbg, 1)) stage(c + 2, nxt2);            // past the slab end: bounds-checked zeros, no traffic
         const double* base = lds + cur * BUF;
         // all of this wave's fragments of the chunk are requested up front: only the first k-step waits for LDS
         double f[KC / 16][NT], wv[KC / 16];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
             double g[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) g[t] = HASW ? f[kk][t] * wv[kk] : f[kk][t];
-            if (!(a.dbg & 128)) narrow_kstep<NT>(f[kk], g);      // tile (ti, tj) += f[ti] (x) g[tj] for all ti <= tj
+            if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT>(f[kk], g);      // tile (ti, tj) += f[ti] (x) g[tj] for all ti <= tj
             else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]));
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
@@ -196,7 +196,7 @@ bool gram_narrow_shape_ok(int64_t n, int p) { return p >= NARROW_MIN_P && p <= N
 
 bool gram_narrow_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p) {
     if (!gram_narrow_shape_ok(n, p)) return false;
-    if (const char* e = getenv("DLSA_GRAM_DBG")) if (atoi(e) & 64) return false;      // 64: keep the list plan (A/B runs)
+    if (gram_dbg_env() & 64) return false;      // 64: keep the list plan (A/B runs)
     int64_t rps;
     narrow_slabs(n, p, rps);
     return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && (!w || ((uintptr_t)w % 16) == 0) &&
@@ -216,7 +216,7 @@ int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
     // odd p (in an even row pitch, checked by gram_narrow_eligible): load p + 1 columns; the pad column only reaches row
     // and column p of the tile grid, which nobody reads (see gram_impl)
     a.X = X; a.w = w; a.partial = (double*)ws; a.ldx = ldx; a.n = n; a.p = p + (p & 1);
-    { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = gram_dbg_env();
     const int nt = (p + 15) / 16;
     a.PP = (nt * 16 + 63) / 64 * 64;
     const int nslab = narrow_slabs(n, p, a.rows_per_slab);

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
         if (c + WAHEAD - 1 < nchunks) wait_prev();     // chunk c landed (the newer ones may be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0, i.e. wait for chunk c+1 as well
-        if (!(a.dbg & 16)) asm volatile("s_barrier" ::: "memory");   // chunk c landed for every wave; stage (c-1)%S is free again
-        if (c + WAHEAD < nchunks && !(a.dbg & 1)) stage_dma(c + WAHEAD, (c + WAHEAD) % WSTAGES);
+        if (!DLSA_DBG_WRONG(a.dbg, 16)) asm volatile("s_barrier" ::: "memory");   // chunk c landed for every wave; stage (c-1)%S is free again
+        if (c + WAHEAD < nchunks && !DLSA_DBG_WRONG(a.dbg, 1)) stage_dma(c + WAHEAD, (c + WAHEAD) % WSTAGES);
         if (active) {
             const float* base = lds + (c % WSTAGES) * WBUF_ELEMS;
             // fragments of k-step ks+1 are fetched while the 32 MFMAs of k-step ks issue (register double buffer)
@@ -354,7 +354,7 @@ int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
     WideArgs a;
     a.X = X; a.w = w; a.partial = (float*)ws; a.items = pl.d_items; a.ldx = ldx; a.n = n; a.rows_per_slab = rps;
     a.p = p; a.PP = pl.PP; a.nitems = pl.nitems; a.nslab = nslab; a.xcd_map = (nslab % kNumXCD == 0) ? 1 : 0;
-    { const char* e = getenv("DLSA_GRAM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = gram_dbg_env();
     if (a.dbg & 2) a.xcd_map = 0;
     const int blocks = pl.nitems * nslab;
     if (w) hipLaunchKernelGGL((gram_wide_f32_kernel<true>), dim3(blocks), dim3(WTHREADS), 0, stream, a);

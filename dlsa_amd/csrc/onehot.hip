@@ -248,13 +248,13 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
                     double* dst = dense_tab + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
 #pragma unroll
                     for (int a = 0; a < OH_MAXD; ++a)
-                        if (a < ds.D && !(ds.dbg & 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
+                        if (a < ds.D && !DLSA_DBG_WRONG(ds.dbg, 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
                 }
         }
         for (int q = 0; q < role.ntab; ++q) {
             const OhTable tb = role.tab[q];
             const int lt = lv[tb.t], lu = lv[tb.u];
-            if (lt < 0 || lu < 0 || (ds.dbg & 2)) continue;
+            if (lt < 0 || lu < 0 || DLSA_DBG_WRONG(ds.dbg, 2)) continue;
             if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
             else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
         }
@@ -390,7 +390,10 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
     DLSA_REQUIRE(pl && H && ldh >= pl->desc.p && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot gram: null argument or ldh < p");
     OhDesc ds = pl->desc;
+    ds.dbg = 0;
+#ifdef DLSA_DEBUG_KNOBS
     { const char* e = getenv("DLSA_OH_DBG"); ds.dbg = e ? atoi(e) : 0; }
+#endif
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;

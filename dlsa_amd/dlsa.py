@@ -37,8 +37,10 @@ def dlsa_mapred(model_mapped_sdf, num_partitions=None):
     Accepts the device-resident `MappedBlocks` of `fit_logistic_partitions`, a pandas frame in the
     reference's stacked layout, or any object with `.toPandas()` (and optionally
     `.rdd.getNumPartitions()`) such as a Spark DataFrame.  `num_partitions` is the divisor of the
-    one-shot mean (dlsa.py:51-52 uses the number of Spark partitions); default = number of blocks.
-    In a torch.distributed job every rank passes ITS blocks; the sums are all-reduced."""
+    one-shot mean and has the reference's meaning (dlsa.py:51-52: the number of partitions of the WHOLE
+    job): given explicitly, or read from `.rdd.getNumPartitions()`, it is used as is on every rank.
+    When it is not given the divisor is the number of blocks: this rank's count, summed over the ranks in
+    the same all-reduce as the blocks.  In a torch.distributed job every rank passes ITS blocks."""
     if isinstance(model_mapped_sdf, MappedBlocks):
         mb = model_mapped_sdf
         names, p = mb.names, mb.coef.shape[1]
@@ -52,10 +54,9 @@ def dlsa_mapred(model_mapped_sdf, num_partitions=None):
             pdf = pdf.toPandas()
         msg, names, p = _blocks_from_frame(pdf)
         nblocks = max(1, pdf.shape[0] // max(1, p))
-    counts = torch.tensor([float(nblocks if num_partitions is None else num_partitions)],
-                          dtype=torch.float64, device=msg.device)
+    counts = torch.tensor([float(nblocks)], dtype=torch.float64, device=msg.device)
     msg = distributed.allreduce_message(torch.cat([msg, counts]))
-    K = float(msg[-1].item())
+    K = float(msg[-1].item()) if num_partitions is None else float(num_partitions)
     Sig_inv_sum = msg[: p * p].view(p, p)
     Sig_invMcoef_sum = msg[p * p: p * p + p]
     # least-squares solution of an SPD system = Cholesky solve (dlsa.py:48-49)

@@ -33,9 +33,34 @@ def _require_gpu(*tensors):
             raise RuntimeError("dlsa_amd runs on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
 
 
+def _f64(t, name, dtype=torch.float64):
+    """The C ABI reads raw pointers: refuse anything that is not what the entry point expects -- the wrong dtype
+    would be reinterpreted (an fp32 X read as n*ldx doubles runs past the buffer; integer labels read as ~0.0), a
+    strided vector read as if it were contiguous.  2-D: row-major with unit column stride (any row pitch);
+    1-D: contiguous.  None passes (nullable arguments)."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor on the GPU" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s (no implicit casts at the C ABI: convert with .to(%s))"
+                        % (name, dtype, t.dtype, dtype))
+    if t.dim() == 2:
+        if t.shape[1] > 1 and t.stride(1) != 1:
+            raise ValueError("%s must be row-major (stride(1) == 1)" % name)
+        if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+            raise ValueError("%s: row pitch %d smaller than its %d columns" % (name, t.stride(0), t.shape[1]))
+    elif not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
 def _workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (256-byte aligned by the torch allocator)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, current stream), 256-byte aligned by the torch allocator.  The C ABI is
+    re-entrant across streams as long as concurrent calls bring their own workspace: work enqueued on two streams must
+    not share scratch, and work on ONE stream is ordered, so a buffer per stream is exactly enough."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
@@ -131,8 +156,13 @@ def gram(X, w=None, out=None, accumulate=False):
     """H = X' diag(w) X (dlsa/models.py:130) on the MFMA Gram kernel.  X [n,p] fp64/fp32."""
     lib = _lib.load()
     _require_gpu(X, w, out)
+    if X.dtype not in (torch.float64, torch.float32):
+        raise TypeError("gram: X must be float64 or float32, got %s" % X.dtype)
+    _f64(X, "X", X.dtype); _f64(out, "out", X.dtype)
     n, p = X.shape
     ldx = _rowmajor(X)
+    if out is not None and (out.dim() != 2 or tuple(out.shape) != (p, p)):
+        raise ValueError("gram: out must be p x p")
     H = out if out is not None else torch.empty((p, p), dtype=X.dtype, device=X.device)
     es = X.element_size()
     nb = lib.dlsa_gram_workspace_bytes(n, p, es)
@@ -140,7 +170,7 @@ def gram(X, w=None, out=None, accumulate=False):
     fn = lib.dlsa_gram_f64 if X.dtype == torch.float64 else lib.dlsa_gram_f32
     if w is not None and (w.dtype != X.dtype or not w.is_contiguous() or w.numel() != n):
         raise ValueError("w must be a contiguous vector of n elements with X's dtype")
-    check(fn(_ptr(X), ldx, _ptr(w), n, p, _ptr(H), H.stride(0), 1 if accumulate else 0,
+    check(fn(_ptr(X), ldx, _ptr(w), n, p, _ptr(H), _rowmajor(H), 1 if accumulate else 0,
              _ptr(ws), ws.numel(), _stream()))
     return H
 
@@ -149,7 +179,10 @@ def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True):
     """One fused pass: w = mu(1-mu), g = X'(y-mu), loglik.  Returns (w, g, loglik) tensors."""
     lib = _lib.load()
     _require_gpu(X, y, beta)
+    _f64(X, "X"); _f64(y, "y"); _f64(beta, "beta")
     n, p = X.shape
+    if y.numel() != n or beta.numel() != p:
+        raise ValueError("logit_pass: y must have n = %d and beta p = %d elements" % (n, p))
     ldx = _rowmajor(X)
     w = torch.empty((n,), dtype=torch.float64, device=X.device) if want_w else None
     g = torch.empty((p,), dtype=torch.float64, device=X.device) if want_g else None
@@ -165,8 +198,12 @@ def loglik(X, y, par):
     """Log-likelihood of each column of par [p, c] (dlsa/models.py:217-222)."""
     lib = _lib.load()
     _require_gpu(X, y, par)
+    _f64(X, "X"); _f64(y, "y")
     n, p = X.shape
     par = par.contiguous()
+    _f64(par, "par")
+    if par.dim() != 2 or par.shape[0] != p or y.numel() != n:
+        raise ValueError("loglik: par must be [p, c] and y [n]")
     c = par.shape[1]
     out = torch.empty((c,), dtype=torch.float64, device=X.device)
     nb = lib.dlsa_logit_workspace_bytes(n, p)
@@ -180,7 +217,13 @@ def xtv(X, v):
     """g = X'v and v'v in one read of X (linear-model map step).  Returns (g [p], vv [1]) in X's dtype."""
     lib = _lib.load()
     _require_gpu(X, v)
+    if X.dtype not in (torch.float64, torch.float32):
+        raise TypeError("xtv: X must be float64 or float32")
+    _f64(X, "X", X.dtype)
+    v = _f64(v.contiguous(), "v", X.dtype)
     n, p = X.shape
+    if v.numel() != n:
+        raise ValueError("xtv: v must have n = %d elements" % n)
     g = torch.empty((p,), dtype=X.dtype, device=X.device)
     vv = torch.empty((1,), dtype=X.dtype, device=X.device)
     nb = lib.dlsa_logit_workspace_bytes(n, p) * (2 if X.dtype == torch.float32 else 1)
@@ -200,7 +243,10 @@ def irls_fit(X, y, part_offsets, tol=1e-13, max_iter=100):
     coef [K,p], Sig_invMcoef [K,p], Sig_inv [K,p,p] (device) and n_iter/status/loglik (host)."""
     lib = _lib.load()
     _require_gpu(X, y)
+    _f64(X, "X"); _f64(y, "y")
     n, p = X.shape
+    if y.numel() != n:
+        raise ValueError("irls_fit: y must have n = %d elements" % n)
     offs = [int(v) for v in part_offsets]
     K = len(offs) - 1
     if offs[0] < 0 or offs[-1] > n:
@@ -229,7 +275,12 @@ def sum_blocks(coef, smc, sig, mask=None):
     """[sum Sig_inv | sum Sig_invMcoef | sum coef]: the rank's all-reduce message (dlsa.py:30-34)."""
     lib = _lib.load()
     _require_gpu(coef, smc, sig)
+    _f64(coef, "coef"); _f64(smc, "Sig_invMcoef")
+    if sig.dtype != torch.float64:
+        raise TypeError("Sig_inv must be float64, got %s" % sig.dtype)
     K, p = coef.shape
+    if tuple(smc.shape) != (K, p) or tuple(sig.shape) != (K, p, p):
+        raise ValueError("sum_blocks: expected coef / Sig_invMcoef [K, p] and Sig_inv [K, p, p]")
     out = torch.empty((p * p + 2 * p,), dtype=torch.float64, device=coef.device)
     cmask = (ctypes.c_int * K)(*[int(v) for v in mask]) if mask is not None else None
     check(lib.dlsa_sum_blocks_f64(_ptr(coef.contiguous()), _ptr(sig.contiguous()), _ptr(smc.contiguous()),
@@ -241,11 +292,15 @@ def spd_solve(S, v):
     """theta = S^{-1} v by device Cholesky (the WLS combine, dlsa/dlsa.py:48-49)."""
     lib = _lib.load()
     _require_gpu(S, v)
+    _f64(S, "S")
+    v = _f64(v.contiguous(), "v")
     p = S.shape[0]
+    if S.dim() != 2 or S.shape[1] != p or v.numel() != p:
+        raise ValueError("spd_solve: S must be p x p and v of length p")
     theta = torch.empty((p,), dtype=torch.float64, device=S.device)
     nb = lib.dlsa_solve_workspace_bytes(p)
     ws = _workspace(nb, S.device)
-    check(lib.dlsa_spd_solve_f64(_ptr(S), S.stride(0), _ptr(v.contiguous()), p, _ptr(theta),
+    check(lib.dlsa_spd_solve_f64(_ptr(S), _rowmajor(S), _ptr(v), p, _ptr(theta),
                                  _ptr(ws), ws.numel(), _stream()))
     return theta
 
@@ -255,9 +310,14 @@ def lars_path(Sigma0, b0, intercept, n, type="lar", eps=2.220446049250313e-16, m
     Returns dict of device tensors AIC, BIC [steps+1], beta [steps+1, m], beta0 [steps+1]."""
     lib = _lib.load()
     _require_gpu(Sigma0, b0)
+    _f64(Sigma0, "Sigma0")
+    b0 = _f64(b0.contiguous(), "b0")
     p = Sigma0.shape[0]
+    if Sigma0.dim() != 2 or Sigma0.shape[1] != p or b0.numel() != p:
+        raise ValueError("lars_path: Sigma0 must be p x p and b0 of length p")
     m = p - (1 if intercept else 0)
-    ms = 8 * m if max_steps is None else int(max_steps)
+    # lsa.py:93-94: max_steps defaults to 8 m; the C ABI reads <= 0 as that default, so the buffers are sized for it too
+    ms = 8 * m if (max_steps is None or int(max_steps) <= 0) else int(max_steps)
     dev = Sigma0.device
     beta = torch.zeros((ms + 1, m), dtype=torch.float64, device=dev)
     beta0 = torch.zeros((ms + 1,), dtype=torch.float64, device=dev)
@@ -266,7 +326,7 @@ def lars_path(Sigma0, b0, intercept, n, type="lar", eps=2.220446049250313e-16, m
     nb = lib.dlsa_lars_workspace_bytes(p)
     ws = _workspace(nb, dev)
     steps = ctypes.c_int(0)
-    check(lib.dlsa_lars_lsa_f64(_ptr(Sigma0), Sigma0.stride(0), _ptr(b0.contiguous()), p, 1 if intercept else 0,
+    check(lib.dlsa_lars_lsa_f64(_ptr(Sigma0), _rowmajor(Sigma0), _ptr(b0), p, 1 if intercept else 0,
                                 float(n), {"lar": 0, "lasso": 1}[type], float(eps), ms,
                                 _ptr(beta), _ptr(beta0), _ptr(aic), _ptr(bic), ctypes.byref(steps),
                                 _ptr(ws), ws.numel(), _stream()))
@@ -317,6 +377,7 @@ def onehot_logit_pass(plan, num, codes, y, beta, want_w=True, want_g=True, want_
     """logit_pass on the raw representation of a one-hot design (num [n,q] fp64, codes [n,f] int32)."""
     lib = _lib.load()
     _require_gpu(y, beta)
+    _f64(y, "y"); _f64(beta, "beta")
     n = y.numel()
     dev = y.device
     w = torch.empty((n,), dtype=torch.float64, device=dev) if want_w else None
@@ -333,6 +394,7 @@ def onehot_gram(plan, num, codes, w, n=None):
     """X' diag(w) X of a one-hot design from its raw representation: the same p x p matrix as gram()."""
     lib = _lib.load()
     _require_gpu(w)
+    _f64(w, "w")
     n = int(n if n is not None else (w.numel() if w is not None else (codes.shape[0] if codes is not None else num.shape[0])))
     dev = (codes if codes is not None else num).device
     H = torch.empty((plan.p, plan.p), dtype=torch.float64, device=dev)
@@ -346,6 +408,7 @@ def onehot_irls_fit(plan, num, codes, y, part_offsets, tol=1e-13, max_iter=100):
     """irls_fit on the raw representation of a one-hot design; same result dict."""
     lib = _lib.load()
     _require_gpu(y)
+    _f64(y, "y")
     p = plan.p
     offs = [int(v) for v in part_offsets]
     K = len(offs) - 1

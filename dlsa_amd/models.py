@@ -139,6 +139,10 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
     leading ones column is materialised (models.py:121-122).  Returns MappedBlocks."""
     if not X.is_cuda:
         raise RuntimeError("fit_logistic_partitions runs on the GPU only (no CPU fallback)")
+    if X.dtype != torch.float64:
+        raise TypeError("fit_logistic_partitions: X must be float64 (the logistic path is fp64 end to end; "
+                        "fit_linear_partitions takes fp32 rows), got %s" % X.dtype)
+    y = y.to(torch.float64)                 # labels may arrive as integers / bools / fp32
     n, p = X.shape
     if part_offsets is None:
         K = int(partition_num) if partition_num else 1
@@ -170,6 +174,9 @@ def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=No
     kernels run.  Same MappedBlocks either way."""
     if not y.is_cuda:
         raise RuntimeError("fit_logistic_design runs on the GPU only (no CPU fallback)")
+    y = y.to(torch.float64)
+    if num is not None and num.dtype != torch.float64:
+        raise TypeError("fit_logistic_design: num must be float64, got %s" % num.dtype)
     n = y.numel()
     if part_offsets is None:
         K = int(partition_num) if partition_num else 1
@@ -217,6 +224,9 @@ def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_inter
     `loglik` slot carries the residual sum of squares of each partition."""
     if not X.is_cuda:
         raise RuntimeError("fit_linear_partitions runs on the GPU only (no CPU fallback)")
+    if X.dtype not in (torch.float64, torch.float32):
+        raise TypeError("fit_linear_partitions: X must be float64 or float32, got %s" % X.dtype)
+    y = y.to(X.dtype)
     n, p = X.shape
     if part_offsets is None:
         K = int(partition_num) if partition_num else 1

@@ -1,0 +1,169 @@
+"""TEST INFRASTRUCTURE ONLY -- the CPU baseline leg of bench.py.
+
+Times the numpy restatement of the hot path (oracle/dlsa_oracle.py) on the host cores of the box the
+benchmark runs on, on a bounded sample of the same seeded synthetic rows:
+
+  mode "pool":   os.cpu_count() single-threaded worker processes (OMP_NUM_THREADS=1), one partition each --
+                 the reference's geometry of one-core Spark executors (projects/bash/run_spark_dlsa.sh:15,42);
+                 every worker runs logistic_model_block (models.py:110-142) on its partition, the parent then
+                 runs the reduce + WLS combine (dlsa.py:30-59) and the LARS path + AIC/BIC pick (lsa.py:90-212,
+                 dlsa.py:87-105).  Walls are reported for map / reduce / LARS separately.
+  mode "single": one process, all BLAS threads, a few of the same partitions one after the other.
+  "gram":        the bare weighted Gram X'diag(w)X (models.py:130) as one multithreaded dgemm.
+
+It is a reported reference point, never the thing measured as `value` and never on the product path.
+"""
+import multiprocessing as mp
+import os
+import time
+
+_THREAD_VARS = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS")
+
+
+def _pool_worker(k, seed, rows, p, kind, barrier, queue):
+    """One single-threaded executor: generate partition k (untimed), wait for the common start, fit, report."""
+    from oracle import dlsa_oracle as orc, fast_synth
+    try:
+        X, y = fast_synth.synth_logistic(seed, k * rows, rows, p, kind)
+        barrier.wait(timeout=600)
+        t0 = time.perf_counter()
+        coef, smc, sig = orc.logistic_model_block(X, y)
+        t1 = time.perf_counter()
+        queue.put((k, coef, smc, sig, t1 - t0))
+    except Exception as e:         # never leave the parent waiting on the barrier / queue
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        queue.put((k, None, None, repr(e), 0.0))
+
+
+def pool_mode(p, rows_per_partition, seed, kind, cores=None):
+    """Mode (i): one partition per core, OMP_NUM_THREADS=1.  Returns a dict of walls and rows/s."""
+    import numpy as np
+    from oracle import dlsa_oracle as orc
+    cores = int(cores or os.cpu_count() or 1)
+    saved = {v: os.environ.get(v) for v in _THREAD_VARS}
+    for v in _THREAD_VARS:
+        os.environ[v] = "1"
+    try:
+        ctx = mp.get_context("spawn")           # fresh interpreters: the thread caps apply at their numpy import
+        barrier = ctx.Barrier(cores + 1)
+        queue = ctx.Queue()
+        procs = [ctx.Process(target=_pool_worker, args=(k, seed, rows_per_partition, p, kind, barrier, queue), daemon=True)
+                 for k in range(cores)]
+        for pr in procs:
+            pr.start()
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+    barrier.wait(timeout=600)
+    t0 = time.perf_counter()
+    got = [queue.get(timeout=1800) for _ in range(cores)]
+    t_gather = time.perf_counter()
+    for pr in procs:
+        pr.join(timeout=60)
+    bad = [g for g in got if g[1] is None]
+    if bad:
+        raise RuntimeError("cpu_baseline worker failed: %s" % bad[0][3])
+    got.sort(key=lambda g: g[0])
+    fit_walls = [g[4] for g in got]
+    # reduce + WLS combine (dlsa.py:30-59); the gather through the pipes above is the CPU's shuffle
+    t1 = time.perf_counter()
+    ols, oneshot, S = orc.dlsa_mapred_blocks([g[1] for g in got], [g[2] for g in got], [g[3] for g in got])
+    t2 = time.perf_counter()
+    n = cores * rows_per_partition
+    by_aic, by_bic, _ = orc.dlsa(S, ols, n)
+    t3 = time.perf_counter()
+    map_wall = max(fit_walls)
+    return {"workers": cores, "threads_per_worker": 1, "partitions": cores, "rows_per_partition": rows_per_partition,
+            "rows": n, "map_wall_s": map_wall, "map_wall_incl_gather_s": t_gather - t0,
+            "reduce_wall_s": t2 - t1, "lars_wall_s": t3 - t2,
+            "map_rows_per_s": n / map_wall, "whole_path_rows_per_s": n / ((t_gather - t0) + (t3 - t1)),
+            "theta_err_vs_truth_linf": float(np.max(np.abs(ols - orc.true_beta(p))))}
+
+
+def single_mode(p, rows_per_partition, seed, kind, partitions):
+    """Mode (ii): one process, all BLAS threads, `partitions` partitions one after the other."""
+    from oracle import dlsa_oracle as orc, fast_synth
+    blocks, t_map = [], 0.0
+    for k in range(partitions):
+        X, y = fast_synth.synth_logistic(seed, k * rows_per_partition, rows_per_partition, p, kind)
+        t0 = time.perf_counter()
+        blocks.append(orc.logistic_model_block(X, y))
+        t_map += time.perf_counter() - t0
+    t1 = time.perf_counter()
+    ols, _, S = orc.dlsa_mapred_blocks([b[0] for b in blocks], [b[1] for b in blocks], [b[2] for b in blocks])
+    t2 = time.perf_counter()
+    n = partitions * rows_per_partition
+    return {"partitions": partitions, "rows_per_partition": rows_per_partition, "rows": n, "blas_threads": blas_threads(),
+            "map_wall_s": t_map, "reduce_wall_s": t2 - t1, "map_rows_per_s": n / t_map}
+
+
+def _mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return float(line.split()[1]) * 1024.0
+    except Exception:
+        pass
+    return 16e9
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([d.get("num_threads", 1) for d in threadpool_info()] + [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def gram_mode(p, sample_rows, seed, kind, budget_s=6.0):
+    """The bare Gram of models.py:130 as numpy executes it (one multithreaded dgemm)."""
+    import numpy as np
+    from oracle import dlsa_oracle as orc, fast_synth
+    X = fast_synth.synth_features(seed, 0, sample_rows, p, kind)
+    w, _, _ = orc.logit_pass(X, np.zeros(sample_rows), orc.true_beta(p))
+    orc.gram(X[:20000], w[:20000])          # warm the BLAS threads
+    t0 = time.perf_counter()
+    orc.gram(X[:20000], w[:20000])
+    t_cal = time.perf_counter() - t0        # bound one pass to ~budget/3 on slow hosts
+    sample_rows = int(min(sample_rows, max(20000, 20000 * (budget_s / 3.0) / max(t_cal, 1e-4))))
+    X, w = X[:sample_rows], w[:sample_rows]
+    reps, t_total = 0, 0.0
+    while t_total < budget_s and reps < 50:
+        t0 = time.perf_counter()
+        orc.gram(X, w)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"rows_per_s": sample_rows * reps / t_total, "rows": sample_rows, "passes": reps, "wall_s": t_total,
+            "blas_threads": blas_threads()}
+
+
+def run(p, seed, rows_per_partition=None, gram_rows=400_000, single_partitions=None):
+    """The `cpu_baseline` object of bench.py's JSON line.  `value` = rows/s of the map step (per-partition
+    exact-MLE fit + Hessian, the step the GPU path replaces) in the reference's one-core-executor geometry."""
+    from oracle import dlsa_oracle as orc
+    cores = int(os.cpu_count() or 1)
+    kind = orc.SYNTH_GAUSSIAN
+    if rows_per_partition is None:
+        # ~8 Newton iterations x (2 n p^2 Gram + 4 n p) flop per partition at a few GFLOP/s per busy core: keep the
+        # map wall in the 5-15 s range ...
+        rows_per_partition = int(max(2000, min(200_000, 1.0e10 / (p * p))))
+        # ... and the workers' footprint (X, w*X and the generator's temporaries: ~4 copies of a partition each)
+        # under a quarter of the free host memory, 48 GB at most
+        budget = min(48e9, 0.25 * _mem_available())
+        rows_per_partition = int(max(40 * p, min(rows_per_partition, budget / (cores * 4 * 8 * p))))
+    pool = pool_mode(p, rows_per_partition, seed, kind, cores)
+    sp = single_partitions if single_partitions is not None else max(1, min(cores, 8))
+    single = single_mode(p, rows_per_partition, seed, kind, sp)
+    gram = gram_mode(p, gram_rows, seed, kind)
+    return {"value": pool["map_rows_per_s"], "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": "oracle (numpy restatement of models.py:110-142 + dlsa.py:30-59 + lsa.py:90-212) on %d partitions x %d "
+                      "rows x p=%d fp64 synthetic Gaussian (same seeded stream as the GPU run): value = rows/s of the map "
+                      "step with %d single-threaded workers, one partition each; rows/s measured on this sample, not extrapolated"
+                      % (cores, rows_per_partition, p, cores),
+            "pool": pool, "single_process": single, "gram": gram}

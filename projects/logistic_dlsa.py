@@ -79,7 +79,7 @@ def main():
     bad = [s for s in mapped.status if s != 0]
     if bad and rank == 0:
         print("warning: partitions with status", mapped.status)
-    Sig_inv_beta = dlsa_amd.dlsa_mapred(mapped, num_partitions=len(mine))
+    Sig_inv_beta = dlsa_amd.dlsa_mapred(mapped, num_partitions=K)      # K = partitions of the whole job (dlsa.py:51-52)
     torch.cuda.synchronize()
     tictoc["mapred"].append(time.perf_counter())
 

@@ -1,0 +1,99 @@
+"""CPU: bench.py's launcher half (no GPU touched) and the CPU-baseline harness of oracle/cpu_baseline.py."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gpus_n_without_a_distributed_env_launches_n_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus 4` must start 4 ranks under torch.distributed.run itself and relay rank 0's line."""
+    bench = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        line = json.dumps({"metric": "rows/sec through X'WX kernel at p=500", "value": 1.0, "n_gpus": 4})
+        return types.SimpleNamespace(returncode=0, stdout="[rank1] noise\n" + line + "\n")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 4
+    assert "torch" not in bench.__dict__           # the launcher never imported torch, let alone touched the GPU
+
+
+def test_launcher_fails_when_rank0_reports_another_world(monkeypatch):
+    bench = _load_bench()
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(
+        returncode=0, stdout=json.dumps({"metric": "m", "n_gpus": 1}) + "\n"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main() != 0
+
+
+def test_worker_refuses_world_size_mismatch(monkeypatch):
+    bench = _load_bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE" in str(e.value)
+
+
+def test_traffic_is_null_for_a_profile_of_another_kernel_source(monkeypatch, tmp_path):
+    bench = _load_bench()
+    t, src = bench.traffic_from_profile(500, 1000)
+    prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    have = bench._sha16(os.path.join(ROOT, "dlsa_amd", "csrc", "gram.hip"))
+    if prof.get("gram_hip_sha16") == have:
+        assert t is not None and t > 0 and have in src
+    else:
+        assert t is None and "stale" in src
+    assert bench.traffic_from_profile(100, 1000)[0] is None
+
+
+def test_fast_synth_matches_the_numpy_generator():
+    from oracle import dlsa_oracle as orc, fast_synth
+    fast_synth.build()
+    assert fast_synth.load() is not None
+    for row0 in (0, 12345678901):
+        A = fast_synth.synth_features(7, row0, 300, 33, orc.SYNTH_UNIFORM)
+        assert np.array_equal(A, orc.synth_features(7, row0, 300, 33, orc.SYNTH_UNIFORM))      # bit-identical
+        G = fast_synth.synth_features(7, row0, 300, 8, orc.SYNTH_GAUSSIAN)
+        assert np.max(np.abs(G - orc.synth_features(7, row0, 300, 8, orc.SYNTH_GAUSSIAN))) < 1e-15   # libm last ulp
+        assert np.array_equal(fast_synth.synth_label_uniforms(7, row0, 500), orc.synth_label_uniforms(7, row0, 500))
+
+
+def test_cpu_baseline_harness_small():
+    """The section-8(d) harness on a toy size: pool of single-threaded workers + single process + bare Gram."""
+    from oracle import cpu_baseline
+    r = cpu_baseline.run(12, 5, rows_per_partition=3000, gram_rows=20000, single_partitions=2)
+    assert r["kind"] == "port" and r["unit"] == "rows/s" and r["cores"] == os.cpu_count()
+    pool = r["pool"]
+    assert pool["workers"] == os.cpu_count() and pool["threads_per_worker"] == 1
+    assert pool["rows"] == os.cpu_count() * 3000 and pool["map_wall_s"] > 0 and pool["lars_wall_s"] > 0
+    assert pool["theta_err_vs_truth_linf"] < 0.6          # the combined estimate is near beta* (first 4 ones, rest 0)
+    assert r["single_process"]["partitions"] == 2 and r["gram"]["rows_per_s"] > 0
+    assert abs(r["value"] - pool["map_rows_per_s"]) < 1e-9
