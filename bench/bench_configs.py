@@ -49,42 +49,15 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
 
 
 def airline_shaped(n, seed=7):
-    """Config 4 surrogate: 7 numeric columns (standardised on the fly) + 5 Zipf factors whose
-    integer level codes are one-hot encoded ON THE DEVICE by dlsa_design_f64 (baseline level dropped,
-    intercept column first) -> p = 1 + 7 + 10+5+19+109+109 = 260."""
-    g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    num = torch.randn((n, 7), dtype=torch.float64, device="cuda", generator=g) * 3.0 + 1.5
-    levels = (11, 6, 20, 110, 110)
-    codes = torch.empty((n, len(levels)), dtype=torch.int32, device="cuda")
-    for fi, L in enumerate(levels):
-        pr = 1.0 / torch.arange(1, L + 1, dtype=torch.float64, device="cuda")
-        codes[:, fi] = torch.multinomial(pr / pr.sum(), n, replacement=True, generator=g).int()
-    kind, src, level, shift, scale = [0], [0], [0], [0.0], [1.0]
-    for j in range(7):
-        kind.append(1); src.append(j); level.append(0); shift.append(1.5); scale.append(3.0)
-    for fi, L in enumerate(levels):
-        for lv in range(1, L):                    # level 0 = baseline
-            kind.append(2); src.append(fi); level.append(lv); shift.append(0.0); scale.append(1.0)
-    d = lambda a, t: torch.tensor(a, dtype=t, device="cuda")
-    spec = (d(kind, torch.int32), d(src, torch.int32), d(level, torch.int32), d(shift, torch.float64), d(scale, torch.float64))
-    Xbuf = torch.empty((n, len(kind)), dtype=torch.float64, device="cuda")
+    """Config 4 surrogate (dlsa_amd/surrogates.py): timings of the design kernel and of the structured passes."""
+    from dlsa_amd.surrogates import airline_shaped as make
+    c = make(n, seed, dense=False)
+    num, codes, spec, plan, y, beta, p = c["num"], c["codes"], c["spec"], c["plan"], c["y"], c["beta"], c["p"]
+    Xbuf = torch.empty((n, p), dtype=torch.float64, device="cuda")
     t_design, (X, seen) = timed(lambda: engine.design(num, codes, *spec, out=Xbuf))
-    assert int(seen.sum()) == len(kind)
-    p = X.shape[1]
-    beta = torch.randn(p, dtype=torch.float64, device="cuda", generator=g) * 0.15
-    y = torch.empty(n, dtype=torch.float64, device="cuda")
-    for r in range(0, n, 1_000_000):
-        y[r:r + 1_000_000] = (torch.rand(min(1_000_000, n - r), dtype=torch.float64, device="cuda", generator=g)
-                              < torch.sigmoid(X[r:r + 1_000_000] @ beta)).double()
+    assert int(seen.sum()) == p
     info = {"design_ms": t_design * 1e3, "design_write_GBps": n * p * 8 / t_design / 1e9,
             "design_input_bytes_per_row": 7 * 8 + 5 * 4, "design_output_bytes_per_row": p * 8}
-    # the same fit on the RAW representation (gather / histogram passes, no dense matrix)
-    dense_idx = [j for j in range(p) if kind[j] in (0, 1)]
-    level_col, pos = [], 8
-    for L in levels:
-        level_col += [-1] + list(range(pos, pos + L - 1)); pos += L - 1
-    plan = engine.OnehotPlan(p, [kind[j] for j in dense_idx], [src[j] for j in dense_idx], [shift[j] for j in dense_idx],
-                             [scale[j] for j in dense_idx], dense_idx, list(levels), level_col)
     w, _, _ = engine.logit_pass(X, y, beta)
     t_og, Hs = timed(lambda: engine.onehot_gram(plan, num, codes, w))
     t_ol, _ = timed(lambda: engine.onehot_logit_pass(plan, num, codes, y, beta))

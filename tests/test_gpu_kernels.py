@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from golden_inputs import lars_case
+
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -342,19 +344,44 @@ def test_irls_separable_data_reports_not_converged_or_spd(eng):
 
 
 F3 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "F3_*.npz")))
+F3I = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "F3i_*.npz")))
+
+
+def _check_path(beta, z, tol=1e-8):
+    """beta path vs an F3 fixture (the p = 250 fixtures hold every 10th row)."""
+    if "beta" in z.files:
+        assert beta.shape == z["beta"].shape
+        assert rel_inf(beta, z["beta"]) < tol
+    else:
+        assert beta.shape[0] - 1 == int(z["steps"])
+        assert rel_inf(beta[z["beta_rows"]], z["beta_sub"]) < tol
 
 
 @pytest.mark.parametrize("name", F3)
 def test_lars_path_matches_reference_golden(eng, name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     typ = "lasso" if name.endswith("lasso") else "lar"
-    r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), False, float(z["n"]), type=typ)
+    S, b, n = lars_case(z)
+    r = eng.lars_path(dev(S), dev(b), False, float(n), type=typ)
     beta = r["beta"].cpu().numpy()
-    assert beta.shape == z["beta"].shape
-    assert rel_inf(beta, z["beta"]) < 1e-8
+    _check_path(beta, z)
     assert rel_inf(r["AIC"].cpu().numpy(), z["AIC"]) < 1e-8
     assert rel_inf(r["BIC"].cpu().numpy(), z["BIC"]) < 1e-8
     assert float(r["beta0"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", F3I)
+def test_lars_intercept_branch_matches_reference_golden(eng, name):
+    """lsa.py:98-104,194-204 -- the reference's intercept branch runs when called with n = p (defect D4); its beta,
+    beta0, AIC and BIC (with log(p)) for that call are the golden."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    typ = "lasso" if name.endswith("lasso") else "lar"
+    r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), True, float(z["n"]), type=typ)
+    assert r["beta"].shape == z["beta"].shape
+    assert rel_inf(r["beta"].cpu().numpy(), z["beta"]) < 1e-8
+    assert np.max(np.abs(r["beta0"].cpu().numpy() - z["beta0"])) < 1e-8 * max(1.0, np.max(np.abs(z["beta0"])))
+    assert rel_inf(r["AIC"].cpu().numpy(), z["AIC"]) < 1e-8
+    assert rel_inf(r["BIC"].cpu().numpy(), z["BIC"]) < 1e-8
 
 
 def test_lars_intercept_matches_oracle(eng, orc):
@@ -401,10 +428,15 @@ def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypa
     for name in F3:
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
         typ = "lasso" if name.endswith("lasso") else "lar"
-        r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), False, float(z["n"]), type=typ)
-        assert r["beta"].shape == z["beta"].shape, name
-        assert rel_inf(r["beta"].cpu().numpy(), z["beta"]) < 1e-8, name
+        S, b, n = lars_case(z)
+        r = eng.lars_path(dev(S), dev(b), False, float(n), type=typ)
+        _check_path(r["beta"].cpu().numpy(), z)
         assert rel_inf(r["BIC"].cpu().numpy(), z["BIC"]) < 1e-8, name
+    for name in F3I:                       # the reference's own intercept branch (callable with n = p)
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        r = eng.lars_path(dev(z["Sigma"]), dev(z["b"]), True, float(z["n"]), type="lasso" if name.endswith("lasso") else "lar")
+        assert rel_inf(r["beta"].cpu().numpy(), z["beta"]) < 1e-8, name
+        assert float((r["beta0"].cpu() - torch.from_numpy(z["beta0"])).abs().max()) < 1e-8, name
     for p, rho, seed, intercept in [(120, 0.98, 5, False), (257, 0.97, 11, False), (120, 0.98, 5, True)]:
         S, b, n = _correlated_lsa_problem(p, rho, seed)
         ro = orc.lars_lsa(S, b, intercept, n, type="lasso")

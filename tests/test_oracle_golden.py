@@ -8,6 +8,7 @@ import pytest
 
 from oracle import dlsa_oracle as orc
 from conftest import GOLDEN
+from golden_inputs import lars_case
 
 TOL_MLE = 1e-10      # oracle vs reference driven to the exact MLE (tol=1e-15 shim)
 TOL_SHIPPED = 2e-2   # oracle vs reference as shipped (sklearn tol=1e-4): sanity tier only
@@ -46,7 +47,10 @@ def test_map_step_matches_reference_mle(name):
     assert rel_inf(S, z["Sig_inv_sum"]) < TOL_MLE
 
 
-@pytest.mark.parametrize("name", F1)
+F1_SHIPPED = sorted(os.path.basename(f)[3:-12] for f in glob.glob(os.path.join(GOLDEN, "F1_*_shipped.npz")))
+
+
+@pytest.mark.parametrize("name", F1_SHIPPED)
 def test_map_step_close_to_reference_as_shipped(name):
     z = np.load(os.path.join(GOLDEN, "F1_%s_shipped.npz" % name))
     X, y = _inputs(z, name)
@@ -79,12 +83,45 @@ F3 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "F3
 def test_lars_lsa_path_matches_reference(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     typ = "lasso" if name.endswith("lasso") else "lar"
-    r = orc.lars_lsa(z["Sigma"], z["b"], False, int(z["n"]), type=typ)
-    assert r["beta"].shape == z["beta"].shape
-    assert rel_inf(r["beta"], z["beta"]) < 1e-9
+    S, b, n = lars_case(z)
+    r = orc.lars_lsa(S, b, False, n, type=typ)
+    if "beta" in z.files:
+        assert r["beta"].shape == z["beta"].shape
+        assert rel_inf(r["beta"], z["beta"]) < 1e-9
+    else:                                   # p = 250: every 10th path row is stored
+        assert r["beta"].shape[0] - 1 == int(z["steps"])
+        assert rel_inf(r["beta"][z["beta_rows"]], z["beta_sub"]) < 1e-9
     assert rel_inf(r["AIC"], z["AIC"]) < 1e-9
     assert rel_inf(r["BIC"], z["BIC"]) < 1e-9
     assert np.all(r["beta0"] == 0)
+
+
+F3I = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "F3i_*.npz")))
+
+
+@pytest.mark.parametrize("name", F3I)
+def test_lars_lsa_intercept_branch_matches_reference_called_with_n_equal_p(name):
+    """lsa.py:98-104,194-204: the reference's intercept branch indexes with n (defect D4) and therefore runs exactly when
+    n = p; its beta / beta0 / AIC / BIC for that call pin the oracle's intercept algebra (BIC then carries log(p))."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    typ = "lasso" if name.endswith("lasso") else "lar"
+    r = orc.lars_lsa(z["Sigma"], z["b"], True, int(z["n"]), type=typ)
+    assert r["beta"].shape == z["beta"].shape and r["beta"].shape[1] == z["Sigma"].shape[0] - 1
+    assert rel_inf(r["beta"], z["beta"]) < 1e-9
+    assert np.max(np.abs(r["beta0"] - z["beta0"])) < 1e-9 * max(1.0, np.max(np.abs(z["beta0"])))
+    assert rel_inf(r["AIC"], z["AIC"]) < 1e-9
+    assert rel_inf(r["BIC"], z["BIC"]) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["zero", "dup", "both"])
+def test_mapred_rank_deficient_blocks_give_the_min_norm_solution(case):
+    """dlsa.py:48-49: lstsq(rcond=None) on a singular sum of blocks returns the minimum-norm solution."""
+    z = np.load(os.path.join(GOLDEN, "F2r_rankdef_%s_K3_p6.npz" % case))
+    ols, oneshot, S = orc.dlsa_mapred_blocks(z["coef"], z["Sig_invMcoef"], z["Sig_inv"])
+    assert np.linalg.matrix_rank(S) == int(z["rank"]) < S.shape[0]
+    assert rel_inf(ols, z["beta_byOLS"]) < 1e-10
+    assert rel_inf(oneshot, z["beta_byONESHOT"]) < 1e-14
+    assert rel_inf(S, z["Sig_inv_sum"]) < 1e-14
 
 
 def test_lars_intercept_algebra():
