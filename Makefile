@@ -7,7 +7,7 @@ CSRC  := dlsa_amd/csrc
 OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
-SRCS  := $(CSRC)/error.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
+SRCS  := $(CSRC)/error.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
          $(CSRC)/irls.hip $(CSRC)/lars.hip
 OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function $(EXTRA)

@@ -37,6 +37,11 @@ SIGNATURES = {
     "dlsa_sum_blocks_f64": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_int), c_vp, c_vp]),
     "dlsa_solve_workspace_bytes": (c_sz, [c_int]),
     "dlsa_spd_solve_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_wls_solve_workspace_bytes": (c_sz, [c_int]),
+    "dlsa_wls_solve_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, ctypes.POINTER(c_int), c_vp, c_sz, c_vp]),
+    "dlsa_sym_pinv_workspace_bytes": (c_sz, [c_int]),
+    "dlsa_sym_pinv_solve_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_dbl),
+                                        c_vp, c_sz, c_vp]),
     "dlsa_lars_workspace_bytes": (c_sz, [c_int]),
     "dlsa_lars_lsa_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_int,
                                   c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp, c_sz, c_vp]),

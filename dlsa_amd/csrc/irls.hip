@@ -373,7 +373,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                       int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
     double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY, dprev2 = INFINITY;
     const char* env_pred = getenv("DLSA_IRLS_PREDICT");
-    // prediction leaves Sig_inv / loglik evaluated up to 100 tol away from the returned coef (see below): only when that
+    // prediction leaves Sig_inv / loglik evaluated up to 10 tol away from the returned coef (see below): only when that
     // is far below the 1e-10 parity tolerance, i.e. never for a loose caller-supplied tol
     const bool predict_on = (env_pred ? atoi(env_pred) != 0 : true) && tol <= 1e-10;
     bool have_prev = false, need_H = !(inherit_scale > 0.0), have_factor = inherit_scale > 0.0;
@@ -498,13 +498,14 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             *fresh = fresh_now;
             return DLSA_OK;
         }
-        // Predicted convergence: the steps have contracted by r <= 0.2 twice in a row, this one is within 100 tol, and the
+        // Predicted convergence: the steps have contracted by r <= 0.2 twice in a row, this one is within 10 tol, and the
         // next one (<= r |delta|) would pass the test: take the step and stop.  The returned coef then meets the tolerance
-        // without the confirming logit pass.  b.w and the log-likelihood are those of the PREVIOUS iterate, |delta| <= 100 tol
-        // (<= 1e-8 relative with the tol <= 1e-10 gate above, 1e-11 at the default tol) away from the returned coef; the
-        // closing Gram of irls_fit_core uses them, so Sig_inv carries that relative error (measured 2.4e-13 at the default
-        // tol, tests/test_gpu_edge.py) and loglik an O(delta^2) one (the gradient vanishes at the MLE).
-        if (predict_on && it >= 3 && isfinite(dprev2) && h[0] <= 100.0 * tol * scale) {
+        // without the confirming logit pass.  b.w and the log-likelihood are those of the PREVIOUS iterate, |delta| <= 10 tol
+        // (1e-12 relative at the default tol) away from the returned coef; the closing Gram of irls_fit_core uses them, so
+        // Sig_inv / Sig_invMcoef carry a relative error of that order (with a 100 tol window the 2.5e7 x 500 fit showed 3e-11
+        // on Sig_invMcoef against the confirmed run: too close to the 1e-10 parity tolerance) and loglik an O(delta^2) one
+        // (the gradient vanishes at the MLE).  tests/test_gpu_fullsize.py holds both to 1e-11 at config-3 scale.
+        if (predict_on && it >= 3 && isfinite(dprev2) && h[0] <= 10.0 * tol * scale) {
             const double r = std::max(h[0] / dprev, dprev / dprev2);
             if (r <= 0.2 && r * h[0] <= tol * scale) {
                 rc = launch_axpby(b.beta, b.delta, 1.0, p, b.beta, s);
@@ -688,7 +689,7 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
             have_warm = (st == DLSA_PART_OK) && warm_ok;
             if (st == DLSA_PART_OK && !fresh) {
                 // Sig_inv must be the Hessian AT the returned coef: b.w holds the weights of the last logit pass, which ran
-                // at exactly this beta -- or, after a predicted exit (newton_run), one step of <= 100 tol before it
+                // at exactly this beta -- or, after a predicted exit (newton_run), one step of <= 10 tol before it
                 rc = d.gram(b.w, nk, Hk, b, s);
                 if (rc) return rc;
             } else if (st == DLSA_PART_NOT_CONVERGED) {

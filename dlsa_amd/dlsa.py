@@ -6,6 +6,8 @@ communication), solves the WLS system on the GPU and returns the reference's fra
 `beta_byOLS, beta_byONESHOT, <names...>`.  `dlsa` (dlsa.py:70-107) runs the LARS path on the GPU
 and picks the AIC / BIC minimisers.  Aliases `dlsa_mapreduce` / `dlsa_fit` follow README.md:25-27.
 """
+import warnings
+
 import numpy as np
 import pandas as pd
 import torch
@@ -59,8 +61,12 @@ def dlsa_mapred(model_mapped_sdf, num_partitions=None):
     K = float(msg[-1].item()) if num_partitions is None else float(num_partitions)
     Sig_inv_sum = msg[: p * p].view(p, p)
     Sig_invMcoef_sum = msg[p * p: p * p + p]
-    # least-squares solution of an SPD system = Cholesky solve (dlsa.py:48-49)
-    beta_byOLS = engine.spd_solve(Sig_inv_sum, Sig_invMcoef_sum)
+    # dlsa.py:48-49 lstsq(rcond=None): a Cholesky solve for an SPD sum; the minimum-norm least-squares solution when the
+    # sum is singular (a dummy level present in no partition, models.py:84-91, or a collinear design)
+    beta_byOLS, rank = engine.wls_solve(Sig_inv_sum, Sig_invMcoef_sum)
+    if rank < p:
+        warnings.warn("dlsa_mapred: the summed Sig_inv has rank %d < %d; beta_byOLS is the minimum-norm least-squares "
+                      "solution (numpy.linalg.lstsq semantics)" % (rank, p))
     beta_byONESHOT = msg[p * p + p: p * p + 2 * p] / K                                  # dlsa.py:51-52
     out = torch.cat([beta_byOLS[:, None], beta_byONESHOT[:, None], Sig_inv_sum], 1).cpu().numpy()
     return pd.DataFrame(out, columns=["beta_byOLS", "beta_byONESHOT"] + list(names))

@@ -305,6 +305,43 @@ def spd_solve(S, v):
     return theta
 
 
+def _solve_args(S, v, who):
+    _require_gpu(S, v)
+    _f64(S, "S")
+    v = _f64(v.contiguous(), "v")
+    p = S.shape[0]
+    if S.dim() != 2 or S.shape[1] != p or v.numel() != p:
+        raise ValueError("%s: S must be p x p and v of length p" % who)
+    return v, p
+
+
+def wls_solve(S, v):
+    """theta = lstsq(S, v, rcond=None)[0] (dlsa/dlsa.py:48-49): Cholesky solve when S is SPD, the minimum-norm
+    least-squares solution (device Jacobi eigendecomposition) when it is singular.  Returns (theta, rank)."""
+    lib = _lib.load()
+    v, p = _solve_args(S, v, "wls_solve")
+    theta = torch.empty((p,), dtype=torch.float64, device=S.device)
+    ws = _workspace(lib.dlsa_wls_solve_workspace_bytes(p), S.device)
+    rank = ctypes.c_int(0)
+    check(lib.dlsa_wls_solve_f64(_ptr(S), _rowmajor(S), _ptr(v), p, _ptr(theta), ctypes.byref(rank),
+                                 _ptr(ws), ws.numel(), _stream()))
+    return theta, rank.value
+
+
+def sym_pinv_solve(S, v, rcond=None):
+    """theta = pinv(S) v for a symmetric S through its eigendecomposition (parallel Jacobi on the device), with
+    lstsq's singular-value cut (rcond=None -> eps * p).  Returns (theta, rank, eigenvalues as a host list)."""
+    lib = _lib.load()
+    v, p = _solve_args(S, v, "sym_pinv_solve")
+    theta = torch.empty((p,), dtype=torch.float64, device=S.device)
+    ws = _workspace(lib.dlsa_sym_pinv_workspace_bytes(p), S.device)
+    rank = ctypes.c_int(0)
+    eig = (ctypes.c_double * p)()
+    check(lib.dlsa_sym_pinv_solve_f64(_ptr(S), _rowmajor(S), _ptr(v), p, -1.0 if rcond is None else float(rcond),
+                                      _ptr(theta), ctypes.byref(rank), eig, _ptr(ws), ws.numel(), _stream()))
+    return theta, rank.value, list(eig)
+
+
 def lars_path(Sigma0, b0, intercept, n, type="lar", eps=2.220446049250313e-16, max_steps=None):
     """LARS / lasso path of the LSA objective on the device (dlsa/lsa.py:90-212).
     Returns dict of device tensors AIC, BIC [steps+1], beta [steps+1, m], beta0 [steps+1]."""

@@ -126,6 +126,22 @@ size_t dlsa_solve_workspace_bytes(int p);
 int dlsa_spd_solve_f64(const double* S, int64_t lds, const double* v, int p, double* theta,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a10, complete semantics: theta = lstsq(S, v, rcond=None)[0]  (dlsa/dlsa.py:48-49) -------------------------------
+ * For an SPD sum this is the Cholesky solve above.  When the sum is singular -- a dummy level that occurs in no partition
+ * leaves a zero row / column (models.py:84-91), a collinear dummy set survives -- numpy returns the MINIMUM-NORM least-squares
+ * solution with singular values <= eps * p * sigma_max treated as zero.  dlsa_wls_solve_f64 tries the Cholesky solve and
+ * falls back to dlsa_sym_pinv_solve_f64 when a pivot fails or is roundoff-sized (L_ii^2 <= 8 eps p S_ii);
+ * rank_host (nullable) receives the numerical rank (p for the SPD case).
+ * dlsa_sym_pinv_solve_f64: parallel two-sided Jacobi eigendecomposition of the symmetric S (p <= 2048), then
+ * theta = V diag(1 / lambda_i : |lambda_i| > rcond * max|lambda|) V' v.  rcond < 0 = eps * p (lstsq's rcond=None).
+ * eig_host (nullable, p doubles, host) receives the eigenvalues (unordered). */
+size_t dlsa_wls_solve_workspace_bytes(int p);
+int dlsa_wls_solve_f64(const double* S, int64_t lds, const double* v, int p, double* theta, int* rank_host,
+                       void* ws, size_t ws_bytes, void* stream);
+size_t dlsa_sym_pinv_workspace_bytes(int p);
+int dlsa_sym_pinv_solve_f64(const double* S, int64_t lds, const double* v, int p, double rcond, double* theta,
+                            int* rank_host, double* eig_host, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a13/a14: LARS path for the least-squares approximation (dlsa/lsa.py:90-212) ------
  * Sigma0 p x p, b0 p (device).  type 0 = 'lar', 1 = 'lasso'.  max_steps <= 0 -> 8*m.
  * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
