@@ -12,3 +12,7 @@ from .models import (MappedBlocks, fit_linear_partitions, fit_logistic_design, f
 from .design import DesignSpec, design_matrix                                                    # noqa: E402,F401
 from .dlsa import dlsa, dlsa_fit, dlsa_mapred, dlsa_mapreduce                                   # noqa: E402,F401
 from .lsa import lars_lsa                                                                        # noqa: E402,F401
+from .dummies import (cumsum_dicts, dummy_factors_counts, select_dummy_factors,                  # noqa: E402,F401
+                      select_dummy_factors_from_file)
+from .model_eval import logistic_model_eval_sdf, loglik_partitions                               # noqa: E402,F401
+from .results import coef_table, write_coef_csv                                                  # noqa: E402,F401

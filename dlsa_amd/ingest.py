@@ -1,0 +1,60 @@
+"""CSV ingestion for row shards: the reference's real-data branch reads the airline CSV, keeps
+`usecols_x + [Y_name]`, drops rows with missing values, binarises the response (ArrDelay > 0) and deals the rows to
+partitions with partition_id = row % K (projects/logistic_dlsa.py:108-110,218-237; the pandas variant is
+dlsa/utils.py:8-45 `clean_airlinedata`).  Here the same steps produce what the device path consumes: numeric columns as
+one fp64 array, categorical columns as int32 LEVEL CODES (DesignSpec.encode: dropped levels fold into 000_OTHERS,
+models.py:60), labels, and the rows of this rank's partitions grouped contiguously.  Parsing is pandas' C reader on the
+host; everything after it (one-hot, standardise, fit) runs on the GPU from the codes."""
+import math
+
+import numpy as np
+import pandas as pd
+
+from .design import DesignSpec
+
+# the airline schema of logistic_dlsa.py:108-140 restricted to usecols_x + Y
+AIRLINE_USECOLS_X = ["Year", "Month", "DayofMonth", "DayOfWeek", "DepTime", "CRSDepTime", "CRSArrTime", "UniqueCarrier",
+                     "ActualElapsedTime", "Origin", "Dest", "Distance"]
+AIRLINE_DUMMY_COLUMNS = ["Month", "DayOfWeek", "UniqueCarrier", "Origin", "Dest"]          # logistic_dlsa.py:156
+AIRLINE_Y = "ArrDelay"                                                                     # logistic_dlsa.py:172
+
+
+def read_csv_frame(path, usecols_x, Y_name, dummy_columns=(), binarize=True, nrows=None):
+    """select(usecols_x + [Y_name]).dropna() and the 0/1 response (logistic_dlsa.py:222-231).  Categorical columns are read
+    as strings (integer-looking levels keep their text, e.g. Month '1'), the rest as float64."""
+    dtypes = {c: "str" for c in dummy_columns}
+    pdf = pd.read_csv(path, usecols=list(usecols_x) + [Y_name], dtype=dtypes, nrows=nrows, engine="c", na_values=["NA"])
+    pdf = pdf.dropna().reset_index(drop=True)
+    for c in usecols_x:
+        if c not in dummy_columns:
+            pdf[c] = pdf[c].astype(np.float64)
+    if binarize:
+        pdf[Y_name] = (pdf[Y_name].astype(np.float64) > 0).astype(np.float64)          # F.when(Y > 0, 1).otherwise(0)
+    return pdf[list(usecols_x) + [Y_name]]
+
+
+def data_info_from_frame(pdf, numeric_cols):
+    """The three rows of Spark's describe() that models.py:99-101 reads: count, mean, stddev (sample std, ddof = 1)."""
+    d = pdf[list(numeric_cols)]
+    return pd.DataFrame({c: [str(len(d)), float(d[c].mean()), float(d[c].std(ddof=1))] for c in numeric_cols})
+
+
+def shard_from_frame(pdf, Y_name, dummy_info, dummy_factors_baseline, data_info, fit_intercept, sample_size_per_partition=1000000,
+                     world=1, rank=0, device="cuda"):
+    """Frame -> device-resident raw shard of this rank.  partition_num = ceil(n / sample_size_per_partition)
+    (logistic_dlsa.py:231-232), partition_id = row % partition_num (:235-237); rank r owns the partitions k % world == r,
+    each stored as a contiguous row range.  Returns dict(num, codes, y, part_offsets, spec, partition_num, sample_size,
+    partitions)."""
+    import torch
+    n = len(pdf)
+    K = max(1, int(math.ceil(n / float(sample_size_per_partition))))
+    spec = DesignSpec.from_reference(list(pdf.columns), Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
+    num, codes, unknown = spec.encode(pdf, dummy_info)
+    y = pdf[Y_name].to_numpy(dtype=np.float64)
+    pid = np.arange(n) % K
+    mine = [k for k in range(K) if k % world == rank]
+    order = np.concatenate([np.nonzero(pid == k)[0] for k in mine]) if mine else np.zeros(0, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum([int(np.sum(pid == k)) for k in mine])]).astype(np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return {"num": t(num[order]), "codes": t(codes[order]), "y": t(y[order]), "part_offsets": offs, "spec": spec,
+            "partition_num": K, "sample_size": n, "partitions": mine, "unknown_levels": bool(unknown)}

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--gaussian", action="store_true", help="N(0,1/12) features instead of U(-0.5,0.5)")
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--save", default="", help="pickle path for [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time]")
+    ap.add_argument("--coef-csv", default="", help="write the coefficient table Var, MLE, DLSA_AIC, DLSA_BIC, WLSE, ONE_SHOT "
+                    "(projects/results/plot_coef.py:43-51); the MLE column is the global fit of all rows as one partition per rank, combined")
     args = ap.parse_args()
 
     rank, world = distributed.init_from_env()
@@ -95,10 +97,7 @@ def main():
     out_par = out_dlsa.copy()
     out_par["beta_byOLS"] = Sig_inv_beta["beta_byOLS"]
     out_par["beta_byONESHOT"] = Sig_inv_beta["beta_byONESHOT"]
-    Xe = torch.cat([torch.ones((n_local, 1), dtype=torch.float64, device="cuda"), Xl], 1) if args.fit_intercept else Xl
-    par = torch.from_numpy(out_par.to_numpy(dtype=np.float64)).cuda()
-    ll = engine.loglik(Xe.contiguous(), yl, par)
-    ll = distributed.allreduce_message(ll)
+    ll = dlsa_amd.loglik_partitions(Xl, yl, out_par, fit_intercept=args.fit_intercept)      # model_eval.py:10-42, one all-reduce
     out_model_eval = pd.DataFrame({c: [float(v)] for c, v in zip(out_par.columns, ll.cpu().numpy())})
     tictoc["model_eval"].append(time.perf_counter())
 
@@ -111,6 +110,14 @@ def main():
         "time_repartition": tictoc["repartition"][1] - tictoc["repartition"][0],
         "time_mapred": time_mapred, "time_dlsa": time_dlsa, "time_model_fit": time_model_fit,
         "time_model_eval": tictoc["model_eval"][1] - tictoc["model_eval"][0]}, index=[0])
+    if args.coef_csv:
+        # the table's MLE column (plot_coef.py:20-41 takes it from a separate global fit): every rank fits ITS rows as one
+        # partition, the WLS combine of those fits is the global estimate up to O(1/n^2)
+        g = dlsa_amd.dlsa_mapred(dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=[0, n_local],
+                                                                 fit_intercept=args.fit_intercept, names=names))
+        if rank == 0:
+            from dlsa_amd import results
+            results.write_coef_csv(args.coef_csv, out_par, list(Sig_inv_beta.columns[2:]), beta_byMLE=g["beta_byOLS"].to_numpy())
     if rank == 0:
         if args.save:
             with open(os.path.expanduser(args.save), "wb") as f:

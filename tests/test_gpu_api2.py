@@ -1,0 +1,117 @@
+"""GPU: round-2 additions to the reference-named API surface -- logistic_model_eval_sdf (dlsa/model_eval.py:10-42), the
+CSV -> level codes -> device shard ingestion (projects/logistic_dlsa.py:218-237) feeding the map step, and the coef.csv
+table of the driver (projects/results/plot_coef.py:43-51)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from f4_fixture import load_f4
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_MLE = 1e-10
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def api():
+    assert torch.cuda.is_available()
+    import dlsa_amd
+    return dlsa_amd
+
+
+def test_logistic_model_eval_sdf_sums_partitions_to_the_reference_total(api):
+    """model_eval.py:10-42: per-partition logistic_model_eval, summed.  The reference's total over the whole F4 chunk must
+    come out whatever the partitioning."""
+    z, df, dummy_info, baseline, data_info = load_f4()
+    coef = z["coef_mle"]
+    par = pd.DataFrame({"beta_byOLS": coef, "beta_half": 0.5 * coef, "beta_zero": 0.0 * coef})
+    for K in (1, 3):
+        d = df.copy()
+        d["partition_id"] = np.arange(len(d)) % K
+        with pytest.warns() if K == 3 else _nullcontext():          # a small chunk may lack a level: eval warns, still evaluates
+            out = api.logistic_model_eval_sdf(d, par, True, "label", dummy_info, baseline, data_info)
+        assert list(out.columns) == list(par.columns) and out.shape == (1, 3)
+        assert rel_inf(out.to_numpy().ravel(), z["eval_loglik"]) < TOL_MLE
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_loglik_partitions_tensor_path(api):
+    from oracle import dlsa_oracle as orc
+    X, y = orc.synth_logistic(31, 0, 9000, 12)
+    par = np.random.default_rng(1).normal(size=(13, 10)) * 0.3          # 10 columns: two passes of <= 8
+    got = api.loglik_partitions(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda(), par, fit_intercept=True).cpu().numpy()
+    want = orc.logistic_loglik(np.column_stack([np.ones(9000), X]), y, par)
+    assert rel_inf(got, want) < 1e-12
+
+
+def test_csv_ingestion_feeds_the_map_step(api, tmp_path):
+    """CSV -> select / dropna / binarise -> level selection -> level codes on the device -> fit_logistic_design, against
+    logistic_model on the same partitions' frames (the reference-faithful path, pinned by F4)."""
+    from dlsa_amd import dummies, ingest
+    rng = np.random.default_rng(8)
+    n = 9000
+    raw = pd.DataFrame({"Distance": rng.normal(700, 300, n), "DepTime": rng.uniform(0, 2400, n),
+                        "UniqueCarrier": rng.choice(["AA", "UA", "DL", "WN", "HP", "TW"], n, p=[.35, .25, .2, .12, .05, .03]),
+                        "DayOfWeek": rng.integers(1, 8, n), "FlightNum": rng.integers(1, 999, n)})
+    eta = 0.5 * (raw["Distance"] - 700) / 300 - 0.4 * (raw["UniqueCarrier"] == "UA") + 0.3 * (raw["DayOfWeek"] == 5)
+    raw["ArrDelay"] = np.where(rng.random(n) < 1 / (1 + np.exp(-eta)), rng.uniform(1, 60, n), -rng.uniform(0, 30, n))
+    raw.loc[rng.choice(n, 40, replace=False), "DepTime"] = np.nan
+    path = str(tmp_path / "airline.csv")
+    raw.to_csv(path, index=False, na_rep="NA")
+    usecols, dummy_cols = ["Distance", "DepTime", "UniqueCarrier", "DayOfWeek"], ["UniqueCarrier", "DayOfWeek"]
+    pdf = ingest.read_csv_frame(path, usecols, "ArrDelay", dummy_columns=dummy_cols)
+    assert len(pdf) == n - 40
+    dummy_info = dummies.select_dummy_factors(dummies.dummy_factors_counts(pdf, dummy_cols), [0.93, 1], "000_OTHERS")
+    assert dummy_info["factor_dropped"]["UniqueCarrier"] == ["HP", "TW"]
+    baseline = ["UniqueCarrier_000_OTHERS", "DayOfWeek_" + str(dummy_info["factor_selected"]["DayOfWeek"][0])]
+    data_info = ingest.data_info_from_frame(pdf, ["Distance", "DepTime"])
+    sh = ingest.shard_from_frame(pdf, "ArrDelay", dummy_info, baseline, data_info, True, sample_size_per_partition=3000)
+    K = sh["partition_num"]
+    assert K == 3 and sh["partitions"] == [0, 1, 2] and int(sh["part_offsets"][-1]) == len(pdf) and not sh["unknown_levels"]
+    mb = api.fit_logistic_design(sh["num"], sh["codes"], sh["y"], sh["spec"], part_offsets=sh["part_offsets"])
+    assert mb.status == [0] * K
+    pid = np.arange(len(pdf)) % K
+    for k in range(K):
+        frame = pdf[pid == k].reset_index(drop=True)
+        out = api.logistic_model(frame, "ArrDelay", fit_intercept=True, dummy_info=dummy_info,
+                                 dummy_factors_baseline=baseline, data_info=data_info)
+        assert list(out.columns[3:]) == sh["spec"].names
+        assert rel_inf(mb.coef[k].cpu().numpy(), out["coef"].to_numpy()) < TOL_MLE
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), out.iloc[:, 3:].to_numpy()) < TOL_MLE
+    # two ranks: each owns its partitions, together they cover the frame
+    a = ingest.shard_from_frame(pdf, "ArrDelay", dummy_info, baseline, data_info, True, 3000, world=2, rank=0)
+    b = ingest.shard_from_frame(pdf, "ArrDelay", dummy_info, baseline, data_info, True, 3000, world=2, rank=1)
+    assert a["partitions"] == [0, 2] and b["partitions"] == [1]
+    assert int(a["part_offsets"][-1]) + int(b["part_offsets"][-1]) == len(pdf)
+
+
+def test_driver_writes_the_coef_csv(tmp_path):
+    out = str(tmp_path / "coef.csv")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "projects", "logistic_dlsa.py"), "--sample-size", "20000", "--p", "12",
+                         "--partition-num", "4", "--fit-intercept", "--coef-csv", out], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    tab = pd.read_csv(out, index_col="Var")
+    assert list(tab.columns) == ["MLE", "DLSA_AIC", "DLSA_BIC", "WLSE", "ONE_SHOT"]
+    assert list(tab.index) == ["intercept"] + ["x%d" % i for i in range(12)]
+    assert np.isfinite(tab.to_numpy()).all()
+    # the global MLE and the WLS estimate of 4 partitions of a well-specified model agree to O(1/n)
+    assert float(np.max(np.abs(tab["MLE"] - tab["WLSE"]))) < 0.05
