@@ -7,7 +7,7 @@ CSRC  := dlsa_amd/csrc
 OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
-SRCS  := $(CSRC)/error.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
+SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
          $(CSRC)/irls.hip $(CSRC)/lars.hip
 OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function $(EXTRA)
@@ -19,7 +19,7 @@ $(BUILD)/%.o: $(CSRC)/% $(CSRC)/common.h $(wildcard $(CSRC)/*.inc) include/dlsa_
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 
 $(OUT): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@
 
 knobs:
 	$(MAKE) BUILD=build/knobs OUT=bench/libdlsa_hip_knobs.so EXTRA=-DDLSA_DEBUG_KNOBS

@@ -35,6 +35,10 @@ SIGNATURES = {
                                   c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                   ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
     "dlsa_sum_blocks_f64": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_int), c_vp, c_vp]),
+    "dlsa_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "dlsa_comm_init_rank": (c_int, [ctypes.POINTER(c_vp), c_int, ctypes.c_char_p, c_int]),
+    "dlsa_comm_destroy": (c_int, [c_vp]),
+    "dlsa_allreduce_f64": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "dlsa_solve_workspace_bytes": (c_sz, [c_int]),
     "dlsa_spd_solve_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_wls_solve_workspace_bytes": (c_sz, [c_int]),

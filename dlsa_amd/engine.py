@@ -466,3 +466,45 @@ def onehot_irls_fit(plan, num, codes, y, part_offsets, tol=1e-13, max_iter=100):
         check(rc)
     return {"coef": coef, "Sig_invMcoef": smc, "Sig_inv": sig, "n_iter": list(n_iter), "status": list(status),
             "loglik": list(ll), "rc": rc}
+
+
+class RcclComm:
+    """An RCCL communicator opened through the C ABI (dlsa_comm_unique_id / dlsa_comm_init_rank), for hosts that do not
+    use torch.distributed: rank 0 creates `RcclComm.unique_id()`, ships the 128 bytes to the other ranks out of band, every
+    rank constructs RcclComm(nranks, id, rank) after selecting its device; `allreduce(msg)` is the algorithm's one round
+    of communication (dlsa/dlsa.py:30-34), in place on the current stream."""
+
+    def __init__(self, nranks, unique_id, rank):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("dlsa_amd runs on the GPU only (no CPU fallback)")
+        torch.cuda.current_device()         # the HIP context of this rank's device must exist before ncclCommInitRank
+        h = ctypes.c_void_p(0)
+        check(lib.dlsa_comm_init_rank(ctypes.byref(h), int(nranks), bytes(unique_id), int(rank)))
+        self._h, self._lib, self.nranks, self.rank = h, lib, int(nranks), int(rank)
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(128)
+        check(lib.dlsa_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce(self, msg):
+        _require_gpu(msg)
+        _f64(msg, "msg")
+        if msg.dim() != 1:
+            raise ValueError("allreduce: msg must be a contiguous vector")
+        check(self._lib.dlsa_allreduce_f64(self._h, _ptr(msg), msg.numel(), _stream()))
+        return msg
+
+    def close(self):
+        if self._h:
+            self._lib.dlsa_comm_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -120,6 +120,17 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y,
 int dlsa_sum_blocks_f64(const double* coef, const double* Sig_inv, const double* Sig_invMcoef,
                         int K, int p, const int* mask_host, double* out, void* stream);
 
+/* ---- a9, the exchange itself: ONE all-reduce (sum) of the rank's message over RCCL / xGMI (dlsa/dlsa.py:30-34: Spark
+ * groupby('par_id').sum + toPandas).  For hosts that do not use torch.distributed (whose "nccl" backend is the same RCCL):
+ * rank 0 calls dlsa_comm_unique_id and hands the DLSA_COMM_ID_BYTES bytes to the other ranks out of band, every rank calls
+ * dlsa_comm_init_rank after selecting its device (hipSetDevice), then dlsa_allreduce_f64(comm, msg, p*p + 2*p, stream)
+ * in place, enqueued on `stream`.  RCCL is resolved at run time (dlopen); without it these return DLSA_ERR_HIP. */
+#define DLSA_COMM_ID_BYTES 128
+int dlsa_comm_unique_id(char* id128);
+int dlsa_comm_init_rank(void** comm, int nranks, const char* id128, int rank);
+int dlsa_comm_destroy(void* comm);
+int dlsa_allreduce_f64(void* rccl_comm, double* buf, int64_t count, void* stream);
+
 /* ---- a10: WLS combine  theta = Sig_inv^{-1} v  (dlsa/dlsa.py:48-49, lstsq on an SPD
  * system) by Cholesky on the device.  S p x p (lds >= p) is not modified. */
 size_t dlsa_solve_workspace_bytes(int p);

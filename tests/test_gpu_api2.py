@@ -115,3 +115,26 @@ def test_driver_writes_the_coef_csv(tmp_path):
     assert np.isfinite(tab.to_numpy()).all()
     # the global MLE and the WLS estimate of 4 partitions of a well-specified model agree to O(1/n)
     assert float(np.max(np.abs(tab["MLE"] - tab["WLSE"]))) < 0.05
+
+
+def test_cabi_rccl_allreduce_single_rank_communicator():
+    """dlsa_allreduce_f64: the one-round reduce through the C ABI on an RCCL communicator the library opened
+    itself.  The test box has one GPU, so the communicator has one rank (RCCL refuses two ranks on a device): the message
+    must come back unchanged, on the caller's stream, and the library must have resolved RCCL at run time."""
+    from dlsa_amd import engine
+    uid = engine.RcclComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = engine.RcclComm(1, uid, 0)
+    p = 500
+    msg = torch.randn(p * p + 2 * p, dtype=torch.float64, device="cuda")
+    ref = msg.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = comm.allreduce(msg)
+        out = comm.allreduce(out)
+    s.synchronize()
+    assert out.data_ptr() == msg.data_ptr() and torch.equal(msg, ref)
+    with pytest.raises(TypeError):
+        comm.allreduce(msg.float())
+    comm.close()
