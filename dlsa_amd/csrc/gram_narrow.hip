@@ -5,15 +5,25 @@
 // At these widths the whole upper triangle of H is at most 28 tiles of 16x16, i.e. <= 224 accumulator registers
 // in fp64 -- it fits in ONE wave's AGPRs.  So instead of cutting the tiles over the four waves of a workgroup (gram.hip's
 // list plan: one fragment pair from LDS per MFMA, 86 instead of 64 cycles per tile-step, and 7 real tiles in 8
-// slots at p = 100), the four waves split the ROWS: every wave owns all NT(NT+1)/2 tiles and takes every fourth
-// 4-row k-step of a staged chunk.  Per k-step a wave reads its NT fragments once (A and B are the same fragments,
-// B scaled by w), and issues NT(NT+1)/2 MFMAs with no wasted slot: 7 LDS reads per 28 MFMAs at p = 100.
-// The accumulators live in AGPRs; the four partial triangles meet in LDS once per workgroup, at the end.
+// slots at p = 100), the four waves split the ROWS: every wave owns all tiles and takes every fourth 4-row k-step of a
+// staged chunk.  Per k-step a wave reads its fragments once (A and B are the same fragments, B scaled by w) and issues
+// its MFMAs with no wasted slot.  The accumulators live in AGPRs; the four partial triangles meet in LDS once per
+// workgroup, at the end.
+//
+// Columns are NOT padded to whole 16-wide tiles: p = 16 NT + (up to 12) columns are covered by NT full tiles
+// (NT (NT + 1) / 2 v_mfma_f64_16x16x4_f64 per k-step) plus G <= 3 four-column TAIL GROUPS.  A tail group costs NT + 1
+// v_mfma_f64_4x4x4_4b_f64: that instruction computes the four diagonal 4 x 4 blocks of the 16 x 16 outer product of two
+// fragments in the big MFMA's own lane layout (A[i = l & 15][k = l >> 4], probed in bench/probe_mfma4x4.hip), at a quarter
+// of the big MFMA's time (16 vs 64 cycles) -- so with the tail's four columns broadcast to the four blocks of B, fragment t
+// as A gives H[16 t .. 16 t + 15][tail columns] from registers the wave already holds.  p = 100: 21 tiles + 7 small MFMAs
+// = 1456 pipe cycles per k-step instead of 28 x 64 = 1792 (2.61 -> 2.24 ms per 1e7 rows); p = 50: 6 + 4 instead of 10 tiles.
+// PMC at p = 100 (profiles/r02_pmc_p100.json): SQ_VALU_MFMA_BUSY_CYCLES = 1456 per k-step exactly, the fp64 pipe 87 % busy
+// at the 1.9-2.0 GHz the chip sustains under this load (the clock, not the issue rate, is what is left).
 //
 // Rows stream global -> LDS with the LDS-DMA (buffer_load ... lds, 16 bytes per lane, one instruction per row)
 // through a ring of NSTAGE chunk buffers; two chunks are in flight while the third is consumed, with a counted
-// s_waitcnt vmcnt(N) + raw s_barrier per chunk (the DMA completes in order).  One workgroup per CU at 6-7 tiles (the
-// accumulators take most of the register file), two at 4-5; rows cut into as many slabs as workgroups fit at once.
+// s_waitcnt vmcnt(N) + raw s_barrier per chunk (the DMA completes in order).  Rows cut into as many slabs as workgroups
+// fit at once.
 #include "common.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -44,7 +54,7 @@ struct NarrowArgs {
 // LDS row pitch in elements: a k-step's fragment read is 4 rows x 16 columns of 8 bytes; 32 lanes (two rows) are
 // served per cycle, so consecutive rows must sit 128 bytes apart modulo 256: pitch = 16 mod 32.
 constexpr int narrow_pitch(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }
-constexpr int narrow_buf_elems(int nt) { return NARROW_KC * narrow_pitch(nt) + NARROW_KC; }     // chunk + its w
+constexpr int narrow_buf_elems(int nt, int kc) { return kc * narrow_pitch(nt) + kc; }     // chunk + its w
 // The MFMA block is inline assembly on explicitly numbered AGPRs (generated: tools/gen_gram_narrow_asm.py).  With the
 // builtin -- or with "+a"-constrained operands -- hipcc carries the 224 accumulator registers of the loop in VGPRs
 // and copies all of them into AGPRs and back around every k-step (448 v_accvgpr moves per 28 MFMAs: measured no
@@ -59,6 +69,14 @@ __device__ __forceinline__ void narrow_for_tiles(F&& fn) {
         narrow_tile_read<T>(v);
         fn(T, v);
         narrow_for_tiles<T + 1, TEND>(fn);
+    }
+}
+// fn(k, v) for the tail accumulators k in [K, NTAIL): v = the lane's double of accumulator k (AGPRs a[8 NTRI + 2k : +1])
+template <int NTRI, int NTAIL, int K, typename F>
+__device__ __forceinline__ void narrow_for_tails(F&& fn) {
+    if constexpr (K < NTAIL) {
+        fn(K, narrow_pair_read<8 * NTRI + 2 * K>());
+        narrow_for_tails<NTRI, NTAIL, K + 1>(fn);
     }
 }
 
@@ -89,25 +107,64 @@ __device__ __forceinline__ void narrow_meet(double* lds, int wave, int lane, dou
     }
 }
 
-// Workgroups per CU: up to 5 tiles per side (120 AGPRs, 62 KB of LDS) two fit, and one's LDS waits, barriers and DMA
-// issue hide under the other's MFMAs (p = 50: 1.22 -> 1.06 ms per 1e7 rows); 6 and 7 tiles take a CU alone.  (Splitting
-// the 28 tiles of p = 100 over wave PAIRS -- eight waves, 112 AGPRs each, two per SIMD -- was built and measured: 2.53 vs
-// 2.55 ms, no gain: with the DMA off the kernel runs 2.25 ms either way, i.e. the MFMA pipe is already ~90 % busy.)
-constexpr int narrow_wgs_per_cu(int nt) { return nt <= 5 ? 2 : 1; }
-constexpr int narrow_meetn(int nt) {      // tiles per meeting pass: three parked copies must fit in the ring
-    const int ntri = nt * (nt + 1) / 2, fit = (int)((size_t)NARROW_STAGES * narrow_buf_elems(nt) * 8 / (3 * 2048));
+// The tail accumulators meet the same way (one double per lane and accumulator).  Accumulator k = gi (NT + 1) + t, lane l:
+// H[16 t + 4 b + i][16 NT + 4 gi + j] with i = l >> 4, b = (l & 15) >> 2, j = l & 3.  (For the partial tile t = NT the
+// blocks b > gi lie below the diagonal or past p: stored into the slab partial all the same, never read by the reduce.)
+template <int NT, int G>
+__device__ __forceinline__ void narrow_meet_tails(double* lds, int wave, int lane, double* __restrict__ P, int PP) {
+    constexpr int NTRI = NT * (NT + 1) / 2, NTAIL = (NT + 1) * G;
+    if constexpr (NTAIL > 0) {
+        if (wave != 0)
+            narrow_for_tails<NTRI, NTAIL, 0>([&](int k, double v) { lds[((wave - 1) * NTAIL + k) * 64 + lane] = v; });
+        __syncthreads();
+        if (wave == 0)
+            narrow_for_tails<NTRI, NTAIL, 0>([&](int k, double v) {
+                const double* s1 = lds + k * 64 + lane;
+                const double sum = ((v + s1[0]) + s1[NTAIL * 64]) + s1[2 * NTAIL * 64];
+                const int gi = k / (NT + 1), t = k - gi * (NT + 1);
+                const int row = 16 * t + 4 * ((lane & 15) >> 2) + (lane >> 4), col = 16 * NT + 4 * gi + (lane & 3);
+                P[(int64_t)row * PP + col] = sum;
+            });
+        __syncthreads();
+    }
+}
+
+// Accumulator registers of a shape, and workgroups per CU: two fit when accumulators + ~72 fragment VGPRs stay within the 256
+// registers two waves per SIMD can have each (up to 6 tiles + one tail group: 182 + 72 = 254) and the two rings fit the
+// LDS (16-row chunks where 32-row ones would not: narrow_kc); one workgroup's LDS waits, barriers and DMA issue then hide
+// under the other's MFMAs (per 1e7 rows: p = 50 1.22 -> 1.06 ms, p = 100 2.32 -> 2.24 ms, p = 96 2.17 -> 2.08 ms).  Wider
+// shapes take a CU alone.  (Splitting the 28 tiles of 112 columns over wave PAIRS -- eight waves, 112 AGPRs each, two per
+// SIMD -- was built and measured in round 1: 2.53 vs 2.55 ms, no gain.)
+constexpr int narrow_nreg(int nt, int g) { return 8 * (nt * (nt + 1) / 2) + 2 * (nt + 1) * g; }
+#ifndef DLSA_NARROW_WGS2_MAXREG
+#define DLSA_NARROW_WGS2_MAXREG 184
+#endif
+constexpr int narrow_wgs_per_cu(int nt, int g) { return narrow_nreg(nt, g) <= DLSA_NARROW_WGS2_MAXREG ? 2 : 1; }
+// Rows per chunk: NARROW_KC (32: two k-steps per wave and barrier) unless two workgroups are to share a CU and their
+// rings would not fit the LDS side by side; then 16.
+constexpr int narrow_kc(int nt, int g) {
+    const int ntc = nt + (g > 0 ? 1 : 0);
+    return (narrow_wgs_per_cu(nt, g) == 2 && (size_t)2 * NARROW_STAGES * narrow_buf_elems(ntc, NARROW_KC) * 8 > (size_t)kLdsBytes) ? 16 : NARROW_KC;
+}
+constexpr int narrow_meetn(int nt, int ntc, int kc) {      // tiles per meeting pass: three parked copies must fit in the ring
+    const int ntri = nt * (nt + 1) / 2, fit = (int)((size_t)NARROW_STAGES * narrow_buf_elems(ntc, kc) * 8 / (3 * 2048));
     return fit < ntri ? fit : ntri;
 }
-constexpr size_t narrow_lds_bytes(int nt) { return (size_t)NARROW_STAGES * narrow_buf_elems(nt) * 8; }
+constexpr size_t narrow_lds_bytes(int ntc, int kc) { return (size_t)NARROW_STAGES * narrow_buf_elems(ntc, kc) * 8; }
 
-template <bool HASW, int NT>
-__global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel(NarrowArgs a) {
+// NT full 16-column tiles + G four-column tail groups: C = 16 NT + 4 G >= p columns (see gram_narrow_shape).
+template <bool HASW, int NT, int G>
+__global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_kernel(NarrowArgs a) {
+    constexpr int KC = narrow_kc(NT, G);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NWAVES = 4, THREADS = 64 * NWAVES;
-    constexpr int KC = NARROW_KC, LDP = narrow_pitch(NT), BUF = narrow_buf_elems(NT), NTRI = NT * (NT + 1) / 2;
-    constexpr int MEETN = narrow_meetn(NT);
+    constexpr int NTC = NT + (G > 0 ? 1 : 0);            // tile columns staged and read as fragments (the last one partial)
+    constexpr int LDP = narrow_pitch(NTC), BUF = narrow_buf_elems(NTC, KC), NTRI = NT * (NT + 1) / 2;
+    constexpr int NTAIL = (NT + 1) * G, GA = G > 0 ? G : 1;
+    constexpr int MEETN = narrow_meetn(NT, NTC, KC);
     constexpr int DMA_PER_CHUNK = KC / NWAVES + (HASW ? 1 : 0);        // instructions per wave and chunk
     static_assert(KC % 16 == 0 && 3 * MEETN >= NTRI, "chunk / meeting shape");
+    static_assert((size_t)3 * NTAIL * 64 <= (size_t)NARROW_STAGES * BUF, "tail meeting fits the ring");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +174,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
     const int64_t nrows = rend > rbeg ? rend - rbeg : 0;
     const int nchunks = (int)((nrows + KC - 1) / KC);
 
-    // rows past the slab end read as zeros through the buffer descriptors; columns p .. 16 NT - 1 are never written
+    // rows past the slab end read as zeros through the buffer descriptors; columns p .. 16 NTC - 1 are never written
     // by the DMA (lanes masked), so the ring is zeroed once
     const unsigned xbytes = nrows > 0 ? (unsigned)(((nrows - 1) * a.ldx + a.p) * 8) : 0u;
     __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
@@ -140,7 +197,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + KC * LDP), 16, lane * 16, chunk * KC * 8, 0, 0);
     };
 
-    narrow_acc_zero<NTRI>();
+    narrow_acc_zero<narrow_nreg(NT, G)>();
 
     stage(0, 0);
     stage(1, 1);
@@ -148,27 +205,33 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
     asm volatile("s_barrier" ::: "memory");
 
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
+    const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);      // the 4 tail columns, broadcast to the 4 blocks
     int cur = 0, nxt2 = 2;                               // ring positions of chunk c and chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
         if (!DLSA_DBG_WRONG(a.dbg, 1)) stage(c + 2, nxt2);            // past the slab end: bounds-checked zeros, no traffic
         const double* base = lds + cur * BUF;
         // all of this wave's fragments of the chunk are requested up front: only the first k-step waits for LDS
-        double f[KC / 16][NT], wv[KC / 16];
+        double f[KC / 16][NTC], wv[KC / 16], bt[KC / 16][GA];
 #pragma unroll
         for (int kk = 0; kk < KC / 16; ++kk) {
             const int ks = wave + 4 * kk;
-            const double* kb = base + ks * 4 * LDP + frag_off;
+            const double* kb = base + ks * 4 * LDP;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) f[kk][t] = kb[t * 16];
+            for (int t = 0; t < NTC; ++t) f[kk][t] = kb[frag_off + t * 16];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) bt[kk][gi] = kb[tail_off + 4 * gi];
             if (HASW) wv[kk] = base[KC * LDP + ks * 4 + (lane >> 4)];
         }
 #pragma unroll
         for (int kk = 0; kk < KC / 16; ++kk) {
-            double g[NT];
+            double g[NT], btw[GA];
 #pragma unroll
             for (int t = 0; t < NT; ++t) g[t] = HASW ? f[kk][t] * wv[kk] : f[kk][t];
-            if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT>(f[kk], g);      // tile (ti, tj) += f[ti] (x) g[tj] for all ti <= tj
-            else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]));
+#pragma unroll
+            for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? (HASW ? bt[kk][gi] * wv[kk] : bt[kk][gi]) : 0.0;
+            // tile (ti, tj) += f[ti] (x) g[tj] for all ti <= tj < NT;  tail (t, gi) += blockdiag(f[t] (x) btw[gi]) for t <= NT
+            if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT, G>(f[kk], g, btw);
+            else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]), "v"(btw[0]));
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
         asm volatile("s_barrier" ::: "memory");
@@ -184,10 +247,20 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT)) void gram_narrow_kernel
     narrow_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
+    narrow_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+}
+
+// p columns = NT full tiles + G tail groups of 4 (G <= 3; a fourth group makes a full tile)
+static void gram_narrow_shape(int p, int& nt, int& g) {
+    nt = p / 16;
+    g = (p - 16 * nt + 3) / 4;
+    if (g == 4) { ++nt; g = 0; }
 }
 
 static int narrow_slabs(int64_t n, int p, int64_t& rows_per_slab) {
-    int64_t ns = std::min<int64_t>((int64_t)kNumCU * narrow_wgs_per_cu((p + 15) / 16), std::max<int64_t>(1, n / 1024));
+    int nt, g;
+    gram_narrow_shape(p + (p & 1), nt, g);
+    int64_t ns = std::min<int64_t>((int64_t)kNumCU * narrow_wgs_per_cu(nt, g), std::max<int64_t>(1, n / 1024));
     rows_per_slab = ((n + ns - 1) / ns + NARROW_KC - 1) / NARROW_KC * NARROW_KC;
     return (int)((n + rows_per_slab - 1) / rows_per_slab);
 }
@@ -217,24 +290,30 @@ int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
     // and column p of the tile grid, which nobody reads (see gram_impl)
     a.X = X; a.w = w; a.partial = (double*)ws; a.ldx = ldx; a.n = n; a.p = p + (p & 1);
     a.dbg = gram_dbg_env();
-    const int nt = (p + 15) / 16;
-    a.PP = (nt * 16 + 63) / 64 * 64;
+    int nt, g;
+    gram_narrow_shape(a.p, nt, g);
+    a.PP = ((p + 15) / 16 * 16 + 63) / 64 * 64;
     const int nslab = narrow_slabs(n, p, a.rows_per_slab);
     const size_t need = (size_t)nslab * a.PP * a.PP * 8;
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-#define DLSA_LAUNCH_NARROW(HW, NTV) do { \
-        const size_t shm = narrow_lds_bytes(NTV); \
-        if (shm > 48 * 1024) DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_narrow_kernel<HW, NTV>), \
+#define DLSA_LAUNCH_NARROW(HW, NTV, GV) do { \
+        const size_t shm = narrow_lds_bytes(NTV + (GV > 0 ? 1 : 0), narrow_kc(NTV, GV)); \
+        if (shm > 48 * 1024) DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_narrow_kernel<HW, NTV, GV>), \
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL((gram_narrow_kernel<HW, NTV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+        hipLaunchKernelGGL((gram_narrow_kernel<HW, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_NARROW_G(HW, NTV) do { switch (g) { \
+        case 0: DLSA_LAUNCH_NARROW(HW, NTV, 0); break; case 1: DLSA_LAUNCH_NARROW(HW, NTV, 1); break; \
+        case 2: DLSA_LAUNCH_NARROW(HW, NTV, 2); break; default: DLSA_LAUNCH_NARROW(HW, NTV, 3); break; } } while (0)
 #define DLSA_LAUNCH_NARROW_NT(HW) do { switch (nt) { \
-        case 4: DLSA_LAUNCH_NARROW(HW, 4); break; case 5: DLSA_LAUNCH_NARROW(HW, 5); break; \
-        case 6: DLSA_LAUNCH_NARROW(HW, 6); break; default: DLSA_LAUNCH_NARROW(HW, 7); break; } } while (0)
+        case 3: DLSA_LAUNCH_NARROW_G(HW, 3); break; case 4: DLSA_LAUNCH_NARROW_G(HW, 4); break; \
+        case 5: DLSA_LAUNCH_NARROW_G(HW, 5); break; case 6: DLSA_LAUNCH_NARROW_G(HW, 6); break; \
+        default: DLSA_LAUNCH_NARROW(HW, 7, 0); break; } } while (0)
     if (w) DLSA_LAUNCH_NARROW_NT(true);
     else DLSA_LAUNCH_NARROW_NT(false);
+#undef DLSA_LAUNCH_NARROW_G
 #undef DLSA_LAUNCH_NARROW_NT
 #undef DLSA_LAUNCH_NARROW
     DLSA_HIP_CHECK(hipGetLastError());
