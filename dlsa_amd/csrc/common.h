@@ -108,7 +108,7 @@ __device__ __forceinline__ double wave_allreduce_min(double s) { return wave_all
 #else
 #define DLSA_DBG_WRONG(mask, bit) 0
 #endif
-constexpr int kGramDbgValidBits = 2 | 4 | 32 | 64;
+constexpr int kGramDbgValidBits = 2 | 4 | 8 | 32 | 64;
 static inline int gram_dbg_env() {
     const char* e = getenv("DLSA_GRAM_DBG");
     const int v = e ? atoi(e) : 0;

@@ -734,6 +734,13 @@ size_t gram_narrow_ws_bytes(int64_t n, int p);
 int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                     int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
+// gram_cyclic.hip: the balanced cyclic-tile fp64 kernel for the p = 500 class (481 <= p <= 508)
+bool gram_cyclic_shape_ok(int64_t n, int p);
+bool gram_cyclic_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p);
+size_t gram_cyclic_ws_bytes(int64_t n, int p);
+int gram_cyclic_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
+                    int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
     std::vector<GramItem> items, listed;
@@ -746,6 +753,7 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     size_t bytes = align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
     if (elem_bytes == 4 && gram_wide_f32_shape_ok(n, p)) bytes = std::max(bytes, gram_wide_f32_ws_bytes(n, p));
     if (elem_bytes == 8 && gram_narrow_shape_ok(n, p)) bytes = std::max(bytes, gram_narrow_ws_bytes(n, p));
+    if (elem_bytes == 8 && gram_cyclic_shape_ok(n, p)) bytes = std::max(bytes, gram_cyclic_ws_bytes(n, p));
     return bytes;
 }
 
@@ -761,6 +769,8 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     } else {
         if (gram_narrow_eligible(X, ldx, w, n, p))
             return gram_narrow_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
+        if (gram_cyclic_eligible(X, ldx, w, n, p))
+            return gram_cyclic_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
     }
     GramPlan pl;
     int rc = get_plan(p, pl);
