@@ -34,6 +34,14 @@ SIGNATURES = {
     "dlsa_irls_fit_f64": (c_int, [c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_int, c_int, c_dbl, c_int,
                                   c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                   ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
+    "dlsa_logit_pass_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_loglik_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_gram_icpt_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dlsa_gram_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dlsa_irls_ex_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_i64]),
+    "dlsa_irls_fit_ex_f64": (c_int, [c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i64, c_int, c_int, c_int,
+                                     c_dbl, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                     ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
     "dlsa_sum_blocks_f64": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_int), c_vp, c_vp]),
     "dlsa_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "dlsa_comm_init_rank": (c_int, [ctypes.POINTER(c_vp), c_int, ctypes.c_char_p, c_int]),

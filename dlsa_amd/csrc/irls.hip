@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <functional>
+#include <vector>
 
 namespace dlsa {
 int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
@@ -30,7 +31,9 @@ int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
 size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 size_t logit_workspace_bytes_impl(int64_t n, int p);
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
-                    double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream);
+                    double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept);
+int xtv_impl(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv, double* sv,
+             void* ws, size_t ws_bytes, hipStream_t s);
 int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const double* rhs, int64_t stride_rhs,
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor);
@@ -531,7 +534,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
 
 // The partition loop shared by every data representation.  make_data(r0) gives the passes over the rows that start
 // at row r0; pass_bytes(rows) the scratch those passes need.
-static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, const std::function<size_t(int64_t)>& pass_bytes,
+static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data, const std::function<size_t(int64_t)>& pass_bytes,
                          const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
                          double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
                          void* ws, size_t ws_bytes, void* stream) {
@@ -595,7 +598,7 @@ static int irls_fit_core(const std::function<IrlsData(int64_t)>& make_data, cons
     for (int k = 0; k < K; ++k) {
         const int64_t r0 = part_offsets_host[k];
         const int64_t nk = part_offsets_host[k + 1] - r0;
-        const IrlsData d = make_data(r0);
+        const IrlsData d = make_data(k, r0);
         double* Hk = Sig_inv + (int64_t)k * p * p;
         double* ck = coef + (int64_t)k * p;
         double* sk = Sig_invMcoef + (int64_t)k * p;
@@ -730,6 +733,33 @@ static size_t dense_pass_bytes(int64_t rows, int p) {
     return std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p));
 }
 
+// ---- implicit intercept (the ones column of models.py:121-122 is never materialised) --------------------------------
+// H = [1 | X]' diag(w) [1 | X]  (p + 1) x (p + 1):  the p x p block is the Gram kernel's, the border is sum(w) and X'w from
+// one streaming pass (xtv kernel: HBM-bound, ~1/6 of the Gram pass at p = 500); w == nullptr = all ones.
+__global__ void icpt_border_kernel(double* __restrict__ H, int64_t ldh, int p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) H[(int64_t)(i + 1) * ldh] = H[i + 1];
+}
+int gram_icpt_impl(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
+                   void* ws, size_t ws_bytes, hipStream_t s) {
+    int rc = gram_impl_f64(X, ldx, w, n, p, H + ldh + 1, ldh, 0, ws, ws_bytes, s);
+    if (rc) return rc;
+    if (n == 0) { DLSA_HIP_CHECK(hipMemsetAsync(H, 0, (size_t)(p + 1) * sizeof(double), s)); }
+    else {
+        rc = xtv_impl(X, ldx, w, n, p, H + 1, nullptr, H, ws, ws_bytes, s);       // row 0 = [sum w | X'w]
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(icpt_border_kernel, dim3((p + 255) / 256), dim3(256), 0, s, H, ldh, p);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+// out[j] = y[first + j * step]
+__global__ void gather_strided_kernel(const double* __restrict__ y, int64_t first, int64_t step, int64_t n, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = y[first + j * step];
+}
+
 }  // namespace dlsa
 
 extern "C" {
@@ -747,12 +777,12 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     DLSA_REQUIRE(X && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "irls_fit: null argument");
     DLSA_REQUIRE(K > 0 && p > 0 && p <= 2048 && ldx >= p, "irls_fit: bad shape K=%d p=%d ldx=%lld", K, p, (long long)ldx);
     DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit: bad tol/max_iter");
-    auto make_data = [=](int64_t r0) {
+    auto make_data = [=](int, int64_t r0) {
         const double* Xk = X + r0 * ldx;
         const double* yk = y + r0;
         IrlsData d;
         d.logit = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s) {
-            return logit_pass_impl(Xk, ldx, yk, beta, nrows, p, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
+            return logit_pass_impl(Xk, ldx, yk, beta, nrows, p, w, g, ll, b.ws_pass, b.ws_pass_bytes, s, 0);
         };
         d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
             return gram_impl_f64(Xk, ldx, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
@@ -761,6 +791,80 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, part_offsets_host, K, p, tol,
                          max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
+}
+
+size_t dlsa_irls_ex_workspace_bytes(int64_t max_rows_per_partition, int p, int intercept, int64_t row_step) {
+    if (p <= 0 || p + (intercept ? 1 : 0) > 2048 || max_rows_per_partition < 0 || row_step < 1) return 0;
+    const int pe = p + (intercept ? 1 : 0);
+    const size_t ybuf = row_step > 1 ? dlsa::align_up((size_t)std::max<int64_t>(max_rows_per_partition, 1) * sizeof(double), 256) : 0;
+    return ybuf + dlsa::irls_layout(max_rows_per_partition, pe, std::max(dlsa::dense_pass_bytes(max_rows_per_partition, p),
+                                                                         dlsa::dense_pass_bytes(max_rows_per_partition, pe))).total;
+}
+
+int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_first_host,
+                         const int64_t* part_rows_host, int64_t row_step, int K, int p, int intercept, double tol, int max_iter,
+                         double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+                         double* loglik_host, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(X && y && part_first_host && part_rows_host && coef && Sig_inv && Sig_invMcoef, "irls_fit_ex: null argument");
+    const int pe = p + (intercept ? 1 : 0);
+    DLSA_REQUIRE(K > 0 && p > 0 && pe <= 2048 && ldx >= p && row_step >= 1, "irls_fit_ex: bad shape K=%d p=%d ldx=%lld step=%lld", K, p,
+                 (long long)ldx, (long long)row_step);
+    DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit_ex: bad tol/max_iter");
+    int64_t max_rows = 0;
+    std::vector<int64_t> offs((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        DLSA_REQUIRE(part_rows_host[k] >= 0 && part_first_host[k] >= 0, "irls_fit_ex: negative partition shape");
+        max_rows = std::max(max_rows, part_rows_host[k]);
+        offs[(size_t)k + 1] = offs[(size_t)k] + part_rows_host[k];
+    }
+    const size_t need = dlsa_irls_ex_workspace_bytes(max_rows, p, intercept, row_step);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("irls_fit_ex: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
+    double* ybuf = (double*)ws;
+    const int64_t pitch = ldx * row_step;                     // rows first, first + step, ...: a strided view, no copy of X
+    hipStream_t st = (hipStream_t)stream;
+    auto make_data = [=](int k, int64_t) {
+        const double* Xk = X + part_first_host[k] * ldx;
+        const double* yk = y + part_first_host[k];
+        const int64_t nk = part_rows_host[k];
+        if (row_step > 1 && nk > 0) {                         // the labels of the partition, gathered once (8 bytes per row)
+            hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, y, part_first_host[k],
+                               row_step, nk, ybuf);
+            yk = ybuf;
+        }
+        IrlsData d;
+        d.logit = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s) {
+            return logit_pass_impl(Xk, pitch, yk, beta, nrows, p, w, g, ll, b.ws_pass, b.ws_pass_bytes, s, intercept);
+        };
+        d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
+            if (intercept) return gram_icpt_impl(Xk, pitch, w, nrows, p, H, pe, b.ws_pass, b.ws_pass_bytes, s);
+            return gram_impl_f64(Xk, pitch, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        return d;
+    };
+    return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },
+                         offs.data(), K, pe, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host,
+                         (char*)ws + ybytes, ws_bytes - ybytes, stream);
+}
+
+// The same Hessian as a stand-alone entry: H = [1 | X]' diag(w) [1 | X], (p + 1) x (p + 1), intercept first (models.py:121-130).
+size_t dlsa_gram_icpt_workspace_bytes(int64_t n, int p) {
+    if (p <= 0 || p > 2047 || n < 0) return 0;
+    return dlsa::dense_pass_bytes(n, p);
+}
+int dlsa_gram_icpt_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
+                       void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE((X || n == 0) && H && p > 0 && p <= 2047 && n >= 0 && ldx >= p && ldh >= p + 1, "gram_icpt: bad argument");
+    if (!ws || ws_bytes < dense_pass_bytes(n, p) || ((uintptr_t)ws & 255)) {
+        set_error("gram_icpt: workspace %zu bytes needed (256-aligned), got %zu", dense_pass_bytes(n, p), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    return gram_icpt_impl(X, ldx, w, n, p, H, ldh, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // One-hot designs: the same fit on raw numerics + level codes (onehot.hip), never materialising the dense matrix.
@@ -778,7 +882,7 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
     DLSA_REQUIRE(plan && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "onehot irls_fit: null argument");
     DLSA_REQUIRE(K > 0 && max_iter > 0 && tol > 0, "onehot irls_fit: bad K/tol/max_iter");
     const int p = onehot_plan_p(plan);
-    auto make_data = [=](int64_t r0) {
+    auto make_data = [=](int, int64_t r0) {
         const double* numk = num ? num + r0 * ldn : nullptr;
         const int32_t* codesk = codes ? codes + r0 * ldc : nullptr;
         const double* yk = y + r0;

@@ -175,6 +175,11 @@ struct LogitArgs {
     int64_t ldx;
     int64_t n;
     int p;
+    // implicit intercept (the ones column of models.py:121-122 is never materialised): beta0 = its coefficient (nullable =
+    // no intercept); s0part [nblocks] = per-block sum of the residuals (logit) / of v (xtv), i.e. the ones column's entry of
+    // X'(y - mu) resp. X'v.  For xtv, a null y stands for the all-ones vector.
+    const double* beta0;
+    double* s0part;
 };
 
 // g += sum_i resid(row i) * x_i : the residual of row i sits in lane lane_of_row(i) and is broadcast through SGPRs
@@ -193,10 +198,12 @@ __device__ __forceinline__ void rank1_update(double resid, const double2 (&x)[RB
 
 template <int NC, int RB, bool VEC>
 __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
-    __shared__ double red[NC * 128 + 1];
+    __shared__ double red[NC * 128 + 2];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const double b0 = a.beta0 ? *a.beta0 : 0.0;
+    double s0 = 0.0;
 
     double2 b[NC], g[NC];
 #pragma unroll
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
             for (int c = 0; c < NC; ++c) s = fma(x[i][c].x, b[c].x, fma(x[i][c].y, b[c].y, s));
             dot[i] = s;
         }
-        const double eta = merged_reduce<RB>(dot, lane);
+        const double eta = merged_reduce<RB>(dot, lane) + b0;
         const int64_t r = row0 + myrow;
         const bool valid = r < a.n;
         // e = exp(-|eta|);  mu = sigmoid(eta);  w = mu(1-mu) = e/(1+e)^2
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
             if (a.w_out) a.w_out[r] = wgt;
             // y log mu + (1-y) log(1-mu) = y*eta - softplus(eta)
             ll += yv * eta - sp;
+            s0 += resid;
         }
         rank1_update<RB, NC, 0>(resid, x, g);
     };
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     }
 
     // block reduction of g and loglik: waves add into LDS one after another (fixed order)
-    for (int m = 32; m >= 1; m >>= 1) ll += __shfl_xor(ll, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) { ll += __shfl_xor(ll, m, 64); s0 += __shfl_xor(s0, m, 64); }
     for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
         if (wave == wv) {
 #pragma unroll
@@ -307,13 +315,16 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
                 if (wv == 0) { dst[0] = g[c].x; dst[1] = g[c].y; }
                 else { dst[0] += g[c].x; dst[1] += g[c].y; }
             }
-            if (lane == 0) { if (wv == 0) red[NC * 128] = ll; else red[NC * 128] += ll; }
+            if (lane == 0) {
+                if (wv == 0) { red[NC * 128] = ll; red[NC * 128 + 1] = s0; }
+                else { red[NC * 128] += ll; red[NC * 128 + 1] += s0; }
+            }
         }
         __syncthreads();
     }
     double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 128);
     for (int col = tid; col < NC * 128; col += LOGIT_THREADS) gp[col] = red[col];
-    if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
+    if (tid == 0) { a.llpart[blockIdx.x] = red[NC * 128]; if (a.s0part) a.s0part[blockIdx.x] = red[NC * 128 + 1]; }
 }
 
 // g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b].  One workgroup per 16 columns (32 workgroups at p = 500:
@@ -325,7 +336,9 @@ __global__ __launch_bounds__(FINISH_COLS * FINISH_GROUPS) void logit_finish_kern
                                                                                     const double* __restrict__ llpart,
                                                                                     int nblocks, int pitch, int p,
                                                                                     double* __restrict__ g,
-                                                                                    double* __restrict__ loglik) {
+                                                                                    double* __restrict__ loglik,
+                                                                                    const double* __restrict__ s0part,
+                                                                                    double* __restrict__ s0) {
     __shared__ double red[FINISH_GROUPS][FINISH_COLS + 1];
     const int cx = threadIdx.x % FINISH_COLS, ry = threadIdx.x / FINISH_COLS;
     const int col = blockIdx.x * FINISH_COLS + cx;
@@ -350,26 +363,32 @@ __global__ __launch_bounds__(FINISH_COLS * FINISH_GROUPS) void logit_finish_kern
             g[col] = t;
         }
     }
-    if (loglik && blockIdx.x == gridDim.x - 1) {
-        __syncthreads();
-        double t = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += FINISH_COLS * FINISH_GROUPS) t += llpart[b];
-        t = wave_allreduce_sum(t);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][FINISH_COLS] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double u = 0.0;
-            for (int k = 0; k < FINISH_COLS * FINISH_GROUPS / 64; ++k) u += red[k][FINISH_COLS];
-            *loglik = u;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the last workgroup sums the scalar partials: the log-likelihood and the ones column's entry
+        for (int which = 0; which < 2; ++which) {
+            const double* part = which == 0 ? llpart : s0part;
+            double* out = which == 0 ? loglik : s0;
+            if (!out || !part) continue;
+            __syncthreads();
+            double t = 0.0;
+            for (int b = threadIdx.x; b < nblocks; b += FINISH_COLS * FINISH_GROUPS) t += part[b];
+            t = wave_allreduce_sum(t);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][FINISH_COLS] = t;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double u = 0.0;
+                for (int k = 0; k < FINISH_COLS * FINISH_GROUPS / 64; ++k) u += red[k][FINISH_COLS];
+                *out = u;
+            }
         }
     }
 }
 
 // (also the finish step of onehot.hip's structured logit pass)
 void logit_finish_launch(const double* gpart, const double* llpart, int nblocks, int pitch, int p, double* g,
-                         double* loglik, hipStream_t stream) {
+                         double* loglik, hipStream_t stream, const double* s0part, double* s0) {
     hipLaunchKernelGGL(logit_finish_kernel, dim3((p + FINISH_COLS - 1) / FINISH_COLS + 1), dim3(FINISH_COLS * FINISH_GROUPS),
-                       0, stream, gpart, llpart, nblocks, pitch, p, g, loglik);
+                       0, stream, gpart, llpart, nblocks, pitch, p, g, loglik, s0part, s0);
 }
 
 static int logit_nc(int p) {
@@ -397,11 +416,12 @@ size_t logit_workspace_bytes_impl(int64_t n, int p) {
     (void)n;
     const int nc = logit_nc(p);
     return align_up((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double), 256) +
-           align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
+           2 * align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
 }
 
+// intercept != 0: beta and g have p + 1 entries, [intercept | the p columns of X]; X itself has p columns.
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
-                    double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream) {
+                    double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept) {
     DLSA_REQUIRE(X && y && beta, "logit_pass: null X, y or beta");
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p, "logit_pass: bad shape n=%lld p=%d ldx=%lld", (long long)n, p, (long long)ldx);
     DLSA_REQUIRE(p <= 2048, "logit_pass: p=%d > 2048 not supported", p);
@@ -412,9 +432,11 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     }
     Arena ar(ws, ws_bytes);
     LogitArgs a;
-    a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p;
+    a.X = X; a.y = y; a.beta = intercept ? beta + 1 : beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p;
     a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
     a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    a.s0part = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    a.beta0 = intercept ? beta : nullptr;
     const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {
@@ -426,7 +448,8 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     }
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, loglik, stream);
+        logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, (g && intercept) ? g + 1 : g,
+                            loglik, stream, (g && intercept) ? (const double*)a.s0part : nullptr, (g && intercept) ? g : nullptr);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;
@@ -440,7 +463,8 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
 struct LoglikArgs {
     const double* X;
     const double* y;
-    const double* par;     // p x c row-major
+    const double* par;     // p x c row-major (the rows of the p columns of X)
+    const double* par0;    // implicit intercept: its row of c coefficients (nullable)
     double* llpart;        // [nblocks][C]
     int64_t ldx, ldpar, n;
     int p, c;
@@ -462,6 +486,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void loglik_kernel(LoglikArgs a) {
     const int myv = row_of_lane<RB * C>(lane);           // value index = row * C + column
     const int myrow = myv / C, mycol = myv % C;
     const bool rep = (lane & rep_mask<RB * C>()) == 0;
+    const double icpt = (a.par0 && mycol < a.c) ? a.par0[mycol] : 0.0;
     double ll = 0.0;
     const int64_t nbatch = (a.n + RB - 1) / RB;
     const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void loglik_kernel(LoglikArgs a) {
                 dot[i * C + j] = s;
             }
         }
-        const double eta = merged_reduce<RB * C>(dot, lane);
+        const double eta = merged_reduce<RB * C>(dot, lane) + icpt;
         const int64_t r = row0 + myrow;
         if (rep && r < a.n && mycol < a.c) {
             const double yv = a.y[r];
@@ -528,12 +553,12 @@ __global__ void loglik_finish_kernel(const double* __restrict__ llpart, int nblo
 // ---------------------------------------------------------------------------------------------
 template <int NC, int RB, bool VEC>
 __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
-    __shared__ double red[NC * 128 + 1];
+    __shared__ double red[NC * 128 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double2 g[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { g[c].x = 0.0; g[c].y = 0.0; }
-    double vv = 0.0;
+    double vv = 0.0, sv = 0.0;
     const int64_t nbatch = (a.n + RB - 1) / RB;
     const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
     for (int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave; bt < nbatch; bt += stride) {
@@ -543,7 +568,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
             // branch-free clamped loads (see logit_kernel): a row past n gets weight 0, columns past p land in
             // entries of g that nobody reads
             const int64_t r = min(row0 + i, a.n - 1);
-            const double yraw = a.y[r];
+            const double yraw = a.y ? a.y[r] : 1.0;
             const double* rowp = a.X + r * a.ldx;
             double2 v[NC];
 #pragma unroll
@@ -554,7 +579,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
                 else { v[c].x = rowp[c0]; v[c].y = rowp[col + 1 < a.p ? col + 1 : 0]; }
             }
             const double yv = (row0 + i < a.n) ? yraw : 0.0;
-            if (lane == 0) vv = fma(yv, yv, vv);
+            if (lane == 0) { vv = fma(yv, yv, vv); sv += yv; }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 g[c].x = fma(yv, v[c].x, g[c].x);
@@ -562,7 +587,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
             }
         }
     }
-    for (int m = 32; m >= 1; m >>= 1) vv += __shfl_xor(vv, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) { vv += __shfl_xor(vv, m, 64); sv += __shfl_xor(sv, m, 64); }
     for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
         if (wave == wv) {
 #pragma unroll
@@ -571,13 +596,16 @@ __global__ __launch_bounds__(LOGIT_THREADS) void xtv_kernel(LogitArgs a) {
                 if (wv == 0) { dst[0] = g[c].x; dst[1] = g[c].y; }
                 else { dst[0] += g[c].x; dst[1] += g[c].y; }
             }
-            if (lane == 0) { if (wv == 0) red[NC * 128] = vv; else red[NC * 128] += vv; }
+            if (lane == 0) {
+                if (wv == 0) { red[NC * 128] = vv; red[NC * 128 + 1] = sv; }
+                else { red[NC * 128] += vv; red[NC * 128 + 1] += sv; }
+            }
         }
         __syncthreads();
     }
     double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 128);
     for (int col = tid; col < NC * 128; col += LOGIT_THREADS) gp[col] = red[col];
-    if (tid == 0) a.llpart[blockIdx.x] = red[NC * 128];
+    if (tid == 0) { a.llpart[blockIdx.x] = red[NC * 128]; if (a.s0part) a.s0part[blockIdx.x] = red[NC * 128 + 1]; }
 }
 
 // fp32 rows (config 5, wide-p linear model): lane l holds columns 256c + 4l + {0..3} (16-byte loads);
@@ -688,9 +716,10 @@ static void launch_loglik(const LoglikArgs& a, bool vec, int blocks, hipStream_t
 
 extern "C" {
 
-// N1 (dlsa/models.py:217-222): all c <= 8 estimator columns in one read of X.
-int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
-                    int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream) {
+// N1 (dlsa/models.py:217-222): all c <= 8 estimator columns in one read of X.  intercept != 0: par has p + 1 rows, the
+// first one the intercepts (the ones column of models.py:162-165 is implicit).
+static int loglik_impl(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
+                       int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream, int intercept) {
     using namespace dlsa;
     DLSA_REQUIRE(X && y && par && out, "loglik: null argument");
     DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "loglik: bad shape n=%lld p=%d", (long long)n, p);
@@ -702,7 +731,8 @@ int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, in
     }
     hipStream_t s = (hipStream_t)stream;
     LoglikArgs a;
-    a.X = X; a.y = y; a.par = par; a.llpart = (double*)ws; a.ldx = ldx; a.ldpar = ldpar; a.n = n; a.p = p; a.c = c;
+    a.X = X; a.y = y; a.par = intercept ? par + ldpar : par; a.par0 = intercept ? par : nullptr;
+    a.llpart = (double*)ws; a.ldx = ldx; a.ldpar = ldpar; a.n = n; a.p = p; a.c = c;
     const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     const int nc = logit_nc(p);
     int blocks;
@@ -723,9 +753,9 @@ int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, in
             case 4: blocks = logit_blocks(n, 2); launch_loglik<4, 2, 8>(a, vec, blocks, s); break;
             case 8: blocks = logit_blocks(n, 1); launch_loglik<8, 1, 8>(a, vec, blocks, s); break;
             default: {      // p > 1024 with more than 4 columns: two passes of 4 columns
-                int rc = dlsa_loglik_f64(X, ldx, y, n, p, par, ldpar, 4, out, ws, ws_bytes, stream);
+                int rc = loglik_impl(X, ldx, y, n, p, par, ldpar, 4, out, ws, ws_bytes, stream, intercept);
                 if (rc) return rc;
-                return dlsa_loglik_f64(X, ldx, y, n, p, par + 4, ldpar, c - 4, out + 4, ws, ws_bytes, stream);
+                return loglik_impl(X, ldx, y, n, p, par + 4, ldpar, c - 4, out + 4, ws, ws_bytes, stream, intercept);
             }
         }
         hipLaunchKernelGGL((loglik_finish_kernel<8>), dim3(1), dim3(64 * 8), 0, s, (const double*)a.llpart, blocks, c, out);
@@ -734,24 +764,35 @@ int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, in
     return DLSA_OK;
 }
 
-// N3: g = X'v (p values) and vv = v'v (1 value, nullable) in one read of X -- the linear-model map
-// step's X'y (no DLSA implementation in the reference; README.md:6 claims the method).
-int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv,
-                 void* ws, size_t ws_bytes, void* stream) {
-    using namespace dlsa;
-    DLSA_REQUIRE(X && v && g, "xtv: null argument");
+int dlsa_loglik_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
+                    int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream) {
+    return loglik_impl(X, ldx, y, n, p, par, ldpar, c, out, ws, ws_bytes, stream, 0);
+}
+int dlsa_loglik_icpt_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
+                         int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream) {
+    return loglik_impl(X, ldx, y, n, p, par, ldpar, c, out, ws, ws_bytes, stream, 1);
+}
+
+}  // extern "C"
+
+namespace dlsa {
+// g = X'v (p values), vv = v'v, sv = sum v (both nullable) in one read of X; v == nullptr stands for the all-ones vector
+int xtv_impl(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv, double* sv,
+             void* ws, size_t ws_bytes, hipStream_t s) {
+    DLSA_REQUIRE(X && g, "xtv: null argument");
     DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "xtv: bad shape n=%lld p=%d", (long long)n, p);
     const int nc = logit_nc(p);
     if (!ws || ws_bytes < logit_workspace_bytes_impl(n, p) || ((uintptr_t)ws & 255)) {
         set_error("xtv: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     LogitArgs a;
     a.X = X; a.y = v; a.beta = nullptr; a.w_out = nullptr; a.ldx = ldx; a.n = n; a.p = p;
     a.gpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double));
     a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    a.s0part = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
+    a.beta0 = nullptr;
     const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {
@@ -761,9 +802,21 @@ int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p
         case 8: blocks = logit_blocks(n, 2); launch_xtv<8, 2>(a, vec, blocks, s); break;
         default: blocks = logit_blocks(n, 1); launch_xtv<16, 1>(a, vec, blocks, s); break;
     }
-    logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv, s);
+    logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, g, vv, s,
+                        (const double*)a.s0part, sv);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
+}
+}  // namespace dlsa
+
+extern "C" {
+
+// N3: g = X'v (p values) and vv = v'v (1 value, nullable) in one read of X -- the linear-model map
+// step's X'y (no DLSA implementation in the reference; README.md:6 claims the method).
+int dlsa_xtv_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv,
+                 void* ws, size_t ws_bytes, void* stream) {
+    DLSA_REQUIRE(v, "xtv: null argument");
+    return dlsa::xtv_impl(X, ldx, v, n, p, g, vv, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int dlsa_xtv_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, float* g, float* vv,
@@ -808,7 +861,13 @@ size_t dlsa_logit_workspace_bytes(int64_t n, int p) {
 int dlsa_logit_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n,
                         int p, double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes,
                         void* stream) {
-    return dlsa::logit_pass_impl(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, (hipStream_t)stream);
+    return dlsa::logit_pass_impl(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, (hipStream_t)stream, 0);
+}
+
+int dlsa_logit_pass_icpt_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n,
+                             int p, double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes,
+                             void* stream) {
+    return dlsa::logit_pass_impl(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, (hipStream_t)stream, 1);
 }
 
 }  // extern "C"

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
 
 // g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b] in a fixed order: the dense pass's finish kernel (logit.hip)
 void logit_finish_launch(const double* gpart, const double* llpart, int nblocks, int pitch, int p, double* g,
-                         double* loglik, hipStream_t stream);
+                         double* loglik, hipStream_t stream, const double* s0part, double* s0);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
@@ -379,7 +379,7 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
                        ldc, y, beta, n, w_out, gpart, llpart, nrep);
     DLSA_HIP_CHECK(hipGetLastError());
     if (g || loglik) {
-        logit_finish_launch((const double*)gpart, (const double*)llpart, nb, ds.p, ds.p, g, loglik, s);
+        logit_finish_launch((const double*)gpart, (const double*)llpart, nb, ds.p, ds.p, g, loglik, s, nullptr, nullptr);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;

@@ -175,41 +175,60 @@ def gram(X, w=None, out=None, accumulate=False):
     return H
 
 
-def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True):
-    """One fused pass: w = mu(1-mu), g = X'(y-mu), loglik.  Returns (w, g, loglik) tensors."""
+def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True, fit_intercept=False):
+    """One fused pass: w = mu(1-mu), g = X'(y-mu), loglik.  Returns (w, g, loglik) tensors.  fit_intercept: the ones
+    column is implicit -- beta and g have p + 1 entries, intercept first."""
     lib = _lib.load()
     _require_gpu(X, y, beta)
     _f64(X, "X"); _f64(y, "y"); _f64(beta, "beta")
     n, p = X.shape
-    if y.numel() != n or beta.numel() != p:
-        raise ValueError("logit_pass: y must have n = %d and beta p = %d elements" % (n, p))
+    pe = p + (1 if fit_intercept else 0)
+    if y.numel() != n or beta.numel() != pe:
+        raise ValueError("logit_pass: y must have n = %d and beta %d elements" % (n, pe))
     ldx = _rowmajor(X)
     w = torch.empty((n,), dtype=torch.float64, device=X.device) if want_w else None
-    g = torch.empty((p,), dtype=torch.float64, device=X.device) if want_g else None
+    g = torch.empty((pe,), dtype=torch.float64, device=X.device) if want_g else None
     ll = torch.empty((1,), dtype=torch.float64, device=X.device) if want_loglik else None
     nb = lib.dlsa_logit_workspace_bytes(n, p)
     ws = _workspace(nb, X.device)
-    check(lib.dlsa_logit_pass_f64(_ptr(X), ldx, _ptr(y), _ptr(beta), n, p, _ptr(w), _ptr(g), _ptr(ll),
-                                  _ptr(ws), ws.numel(), _stream()))
+    fn = lib.dlsa_logit_pass_icpt_f64 if fit_intercept else lib.dlsa_logit_pass_f64
+    check(fn(_ptr(X), ldx, _ptr(y), _ptr(beta), n, p, _ptr(w), _ptr(g), _ptr(ll), _ptr(ws), ws.numel(), _stream()))
     return w, g, ll
 
 
-def loglik(X, y, par):
-    """Log-likelihood of each column of par [p, c] (dlsa/models.py:217-222)."""
+def gram_icpt(X, w=None, out=None):
+    """H = [1 | X]' diag(w) [1 | X], (p + 1) x (p + 1), without materialising the ones column (models.py:121-130)."""
+    lib = _lib.load()
+    _require_gpu(X, w, out)
+    _f64(X, "X"); _f64(w, "w"); _f64(out, "out")
+    n, p = X.shape
+    if w is not None and w.numel() != n:
+        raise ValueError("gram_icpt: w must have n elements")
+    H = out if out is not None else torch.empty((p + 1, p + 1), dtype=torch.float64, device=X.device)
+    if tuple(H.shape) != (p + 1, p + 1):
+        raise ValueError("gram_icpt: out must be (p + 1) x (p + 1)")
+    ws = _workspace(lib.dlsa_gram_icpt_workspace_bytes(n, p), X.device)
+    check(lib.dlsa_gram_icpt_f64(_ptr(X), _rowmajor(X), _ptr(w), n, p, _ptr(H), _rowmajor(H), _ptr(ws), ws.numel(), _stream()))
+    return H
+
+
+def loglik(X, y, par, fit_intercept=False):
+    """Log-likelihood of each column of par [p, c] (dlsa/models.py:217-222).  fit_intercept: par has p + 1 rows, the
+    first one the intercepts; the ones column is implicit."""
     lib = _lib.load()
     _require_gpu(X, y, par)
     _f64(X, "X"); _f64(y, "y")
     n, p = X.shape
     par = par.contiguous()
     _f64(par, "par")
-    if par.dim() != 2 or par.shape[0] != p or y.numel() != n:
-        raise ValueError("loglik: par must be [p, c] and y [n]")
+    if par.dim() != 2 or par.shape[0] != p + (1 if fit_intercept else 0) or y.numel() != n:
+        raise ValueError("loglik: par must be [p (+1), c] and y [n]")
     c = par.shape[1]
     out = torch.empty((c,), dtype=torch.float64, device=X.device)
     nb = lib.dlsa_logit_workspace_bytes(n, p)
     ws = _workspace(nb, X.device)
-    check(lib.dlsa_loglik_f64(_ptr(X), _rowmajor(X), _ptr(y), n, p, _ptr(par), par.stride(0), c, _ptr(out),
-                              _ptr(ws), ws.numel(), _stream()))
+    fn = lib.dlsa_loglik_icpt_f64 if fit_intercept else lib.dlsa_loglik_f64
+    check(fn(_ptr(X), _rowmajor(X), _ptr(y), n, p, _ptr(par), par.stride(0), c, _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
 
 
@@ -235,6 +254,41 @@ def xtv(X, v):
     check(lib.dlsa_xtv_f64(_ptr(X), _rowmajor(X), _ptr(v.contiguous()), n, p, _ptr(g), _ptr(vv),
                            _ptr(ws), ws.numel(), _stream()))
     return g, vv
+
+
+def irls_fit_ex(X, y, part_first, part_rows, row_step=1, fit_intercept=False, tol=1e-13, max_iter=100):
+    """irls_fit without copies of the shard: partition k = rows part_first[k] + j * row_step, j < part_rows[k] (a strided
+    view: partition_id = i % K is part_first = 0..K-1, row_step = K), and an IMPLICIT intercept column (fit_intercept:
+    results have p + 1 columns, intercept first).  Same result dict as irls_fit."""
+    lib = _lib.load()
+    _require_gpu(X, y)
+    _f64(X, "X"); _f64(y, "y")
+    n, p = X.shape
+    if y.numel() != n:
+        raise ValueError("irls_fit_ex: y must have n = %d elements" % n)
+    first = [int(v) for v in part_first]
+    rows = [int(v) for v in part_rows]
+    K, step = len(first), int(row_step)
+    if len(rows) != K or K == 0 or step < 1:
+        raise ValueError("irls_fit_ex: part_first / part_rows must have K >= 1 entries each, row_step >= 1")
+    for f, r in zip(first, rows):
+        if f < 0 or r < 0 or (r > 0 and f + (r - 1) * step >= n):
+            raise ValueError("irls_fit_ex: partition outside the %d rows of X" % n)
+    pe = p + (1 if fit_intercept else 0)
+    dev = X.device
+    coef = torch.empty((K, pe), dtype=torch.float64, device=dev)
+    smc = torch.empty((K, pe), dtype=torch.float64, device=dev)
+    sig = torch.empty((K, pe, pe), dtype=torch.float64, device=dev)
+    ws = _workspace(lib.dlsa_irls_ex_workspace_bytes(max(rows), p, 1 if fit_intercept else 0, step), dev)
+    c_first, c_rows = (ctypes.c_int64 * K)(*first), (ctypes.c_int64 * K)(*rows)
+    n_iter, status, ll = (ctypes.c_int * K)(), (ctypes.c_int * K)(), (ctypes.c_double * K)()
+    rc = lib.dlsa_irls_fit_ex_f64(_ptr(X), _rowmajor(X), _ptr(y), c_first, c_rows, step, K, p, 1 if fit_intercept else 0,
+                                  tol, max_iter, _ptr(coef), _ptr(sig), _ptr(smc), n_iter, status, ll, _ptr(ws), ws.numel(),
+                                  _stream())
+    if rc not in (0, 4, 5, 6):     # per-partition soft failures are reported through `status`
+        check(rc)
+    return {"coef": coef, "Sig_invMcoef": smc, "Sig_inv": sig, "n_iter": list(n_iter), "status": list(status),
+            "loglik": list(ll), "rc": rc}
 
 
 def irls_fit(X, y, part_offsets, tol=1e-13, max_iter=100):

@@ -33,8 +33,6 @@ def logistic_model_eval_sdf(data_sdf, par, fit_intercept, Y_name, dummy_info=[],
 def loglik_partitions(X, y, par, fit_intercept=False):
     """Tensor fast path: X [n, p(-1)] device-resident shard, y [n], par [p, c] (frame, array or tensor).  One read of X for
     all c columns (dlsa_loglik_f64), summed over the ranks.  Returns a device tensor [c]."""
-    if fit_intercept:
-        X = engine.with_ones_column(X)
     if isinstance(par, pd.DataFrame):
         par = par.to_numpy(dtype=np.float64)
     if not torch.is_tensor(par):
@@ -42,5 +40,6 @@ def loglik_partitions(X, y, par, fit_intercept=False):
     par = par.to(device=X.device, dtype=torch.float64)
     out = torch.zeros(par.shape[1], dtype=torch.float64, device=X.device)
     for c0 in range(0, par.shape[1], 8):                 # dlsa_loglik_f64 takes up to 8 columns per pass
-        out[c0:c0 + 8] = engine.loglik(engine.row_major(X), y.to(torch.float64).contiguous(), par[:, c0:c0 + 8].contiguous())
+        out[c0:c0 + 8] = engine.loglik(engine.row_major(X), y.to(torch.float64).contiguous(), par[:, c0:c0 + 8].contiguous(),
+                                       fit_intercept=fit_intercept)      # implicit ones column: no copy of the shard
     return distributed.allreduce_message(out)

@@ -134,9 +134,10 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
 
     X [n, p] fp64 row-major on the GPU, y [n].  Either `part_offsets` (K+1 ints: partition k is the
     contiguous row range [off[k], off[k+1]) -- the layout `repartition(K, "partition_id")` gives,
-    logistic_dlsa.py:295) or `partition_num` (systematic partition_id = i % K, models.py:33; the
-    rows are gathered into contiguous partitions on the device first).  With fit_intercept a
-    leading ones column is materialised (models.py:121-122).  Returns MappedBlocks."""
+    logistic_dlsa.py:295) or `partition_num` (systematic partition_id = i % K, models.py:33: partition k is
+    the strided view X[k::K], nothing is gathered).  With fit_intercept the leading ones column of
+    models.py:121-122 is implicit in the kernels (results have p + 1 columns, `intercept` first).
+    Returns MappedBlocks."""
     if not X.is_cuda:
         raise RuntimeError("fit_logistic_partitions runs on the GPU only (no CPU fallback)")
     if X.dtype != torch.float64:
@@ -144,22 +145,22 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
                         "fit_linear_partitions takes fp32 rows), got %s" % X.dtype)
     y = y.to(torch.float64)                 # labels may arrive as integers / bools / fp32
     n, p = X.shape
-    if part_offsets is None:
-        K = int(partition_num) if partition_num else 1
-        if K > 1:
-            idx = torch.arange(n, device=X.device)
-            order = torch.argsort(idx % K, stable=True)
-            X, y = X[order], y[order]
-            counts = torch.bincount(idx % K, minlength=K).cpu().tolist()
-        else:
-            counts = [n]
-        part_offsets = np.concatenate([[0], np.cumsum(counts)])
-    if fit_intercept:
-        X = engine.with_ones_column(X)
     if names is None:
         names = ["x" + str(i) for i in range(p)]
     names = (["intercept"] if fit_intercept else []) + list(names)
-    r = engine.irls_fit(engine.row_major(X), y.contiguous(), part_offsets, tol=tol, max_iter=max_iter)
+    # No copy of the shard either way: partition_id = i % K is the strided view rows k, k + K, ... (row pitch ldx K), and the
+    # intercept's ones column (models.py:121-122) is implicit in the kernels.  At config-3 scale (2.5e7 x 500 fp64 = 100 GB
+    # of a 288 GB part) a gathered copy plus a [1 | X] copy would not fit.
+    if part_offsets is None:
+        K = int(partition_num) if partition_num else 1
+        first = list(range(K))
+        rows = [len(range(k, n, K)) for k in range(K)]
+        step = K
+    else:
+        offs = [int(v) for v in part_offsets]
+        first, rows, step = offs[:-1], [offs[k + 1] - offs[k] for k in range(len(offs) - 1)], 1
+    r = engine.irls_fit_ex(engine.row_major(X), y.contiguous(), first, rows, row_step=step, fit_intercept=fit_intercept,
+                           tol=tol, max_iter=max_iter)
     return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], names, r["status"], r["n_iter"], r["loglik"],
                         sample_size=n)
 

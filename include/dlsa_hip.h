@@ -113,6 +113,29 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y,
                       int* n_iter_host, int* status_host, double* loglik_host,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the same stages WITHOUT copies of the shard (config-3 scale: 2.5e7 x 500 fp64 = 100 GB per GPU) --------------------
+ * (1) Implicit intercept.  The reference prepends a ones column for the Hessian (models.py:121-122) and lets sklearn fit the
+ *     intercept (models.py:110-113); materialising [1 | X] would be a second 100 GB.  The *_icpt entries take X with its p
+ *     columns and treat the intercept as column 0 of a (p + 1)-column design: beta / g / coef have p + 1 entries, H is
+ *     (p + 1) x (p + 1), par has p + 1 rows -- intercept first, as in the reference's output frames (models.py:136-142).
+ *     The Hessian's border (sum w, X'w) comes from one extra streaming pass.
+ * (2) Strided partitions.  partition_id = i % K (models.py:33) makes partition k the rows k, k + K, k + 2K, ...: a strided
+ *     view of the shard (row pitch ldx * K), not a gather.  dlsa_irls_fit_ex_f64 takes, per partition, its first row and
+ *     row count (host arrays) and one common row_step (1 = contiguous partitions as dlsa_irls_fit_f64); the partition's
+ *     labels are gathered into the workspace (8 bytes per row).  Outputs as dlsa_irls_fit_f64 with p + intercept columns. */
+int dlsa_logit_pass_icpt_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
+                             double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, void* stream);
+int dlsa_loglik_icpt_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
+                         int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream);
+size_t dlsa_gram_icpt_workspace_bytes(int64_t n, int p);
+int dlsa_gram_icpt_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
+                       void* ws, size_t ws_bytes, void* stream);
+size_t dlsa_irls_ex_workspace_bytes(int64_t max_rows_per_partition, int p, int intercept, int64_t row_step);
+int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_first_host,
+                         const int64_t* part_rows_host, int64_t row_step, int K, int p, int intercept, double tol, int max_iter,
+                         double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+                         double* loglik_host, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a9: local sum of partition blocks before the one-round all-reduce (dlsa.py:30-34) -
  * out = [ sum_k Sig_inv (p*p) | sum_k Sig_invMcoef (p) | sum_k coef (p) ] contiguous,
  * the message a rank contributes to the RCCL all-reduce.  Blocks whose status is not OK may
