@@ -8,7 +8,7 @@ OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
 SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
-         $(CSRC)/irls.hip $(CSRC)/lars.hip
+         $(CSRC)/irls.hip $(CSRC)/irls_small.hip $(CSRC)/lars.hip
 OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
 # -Wno-inline-asm: the narrow Gram kernel names AGPRs beyond a127 in kernels bounded to two waves per SIMD; hipcc calls them
 # "reserved" but allocates them (accum_offset + AGPRs <= 256 is checked in the kernel descriptors)

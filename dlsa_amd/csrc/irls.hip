@@ -34,6 +34,13 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
                     double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept);
 int xtv_impl(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv, double* sv,
              void* ws, size_t ws_bytes, hipStream_t s);
+// irls_small.hip: all partitions in ONE launch, a workgroup each (many small partitions)
+bool irls_small_eligible(const int64_t* rows_host, int K, int pe);
+size_t irls_small_workspace_bytes(int K);
+int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host,
+                   int64_t step, int K, int p, int intercept, double tol, int max_iter, double* coef, double* Sig_inv,
+                   double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host, void* ws, size_t ws_bytes,
+                   hipStream_t s);
 int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const double* rhs, int64_t stride_rhs,
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor);
@@ -777,6 +784,14 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     DLSA_REQUIRE(X && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "irls_fit: null argument");
     DLSA_REQUIRE(K > 0 && p > 0 && p <= 2048 && ldx >= p, "irls_fit: bad shape K=%d p=%d ldx=%lld", K, p, (long long)ldx);
     DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit: bad tol/max_iter");
+    {
+        std::vector<int64_t> rows((size_t)K);
+        bool mono = true;
+        for (int k = 0; k < K; ++k) { rows[(size_t)k] = part_offsets_host[k + 1] - part_offsets_host[k]; mono &= rows[(size_t)k] >= 0; }
+        if (mono && K <= 8192 && irls_small_eligible(rows.data(), K, p) && ws && ws_bytes >= irls_small_workspace_bytes(K) && !((uintptr_t)ws & 255))
+            return irls_small_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
+                                  n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
+    }
     auto make_data = [=](int, int64_t r0) {
         const double* Xk = X + r0 * ldx;
         const double* yk = y + r0;
@@ -798,7 +813,7 @@ size_t dlsa_irls_ex_workspace_bytes(int64_t max_rows_per_partition, int p, int i
     const int pe = p + (intercept ? 1 : 0);
     const size_t ybuf = row_step > 1 ? dlsa::align_up((size_t)std::max<int64_t>(max_rows_per_partition, 1) * sizeof(double), 256) : 0;
     return ybuf + dlsa::irls_layout(max_rows_per_partition, pe, std::max(dlsa::dense_pass_bytes(max_rows_per_partition, p),
-                                                                         dlsa::dense_pass_bytes(max_rows_per_partition, pe))).total;
+                                                                         dlsa::dense_pass_bytes(max_rows_per_partition, pe))).total + (1 << 20);
 }
 
 int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_first_host,
@@ -823,6 +838,9 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         set_error("irls_fit_ex: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
+    if (irls_small_eligible(part_rows_host, K, pe))
+        return irls_small_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv,
+                              Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
     const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
     double* ybuf = (double*)ws;
     const int64_t pitch = ldx * row_step;                     // rows first, first + step, ...: a strided view, no copy of X

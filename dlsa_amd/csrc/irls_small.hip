@@ -1,0 +1,290 @@
+// The map step for MANY SMALL partitions (dlsa/models.py:110-131 per partition; config 1: 20 partitions of 5 000 x 50 rows,
+// projects/logistic_dlsa.py:89-92).
+//
+// irls.hip drives one partition at a time from the host: a Newton iteration is a dozen launches and one host round trip,
+// ~0.1 ms, whatever the partition's size -- 0.6 ms per 5 000-row partition whose arithmetic takes microseconds.  Partitions
+// are independent, so here ONE launch fits them all: a workgroup per partition runs the whole Newton iteration to
+// convergence on the device -- no host synchronisation, no inter-workgroup communication.
+//   per iteration:  rows -> eta, mu, w, residual, loglik (each wave takes every fourth 4-row k-step; the 16 lanes of a row
+//                   reduce eta with DPP);  g += residual x;  H += x' w x on v_mfma_f64_16x16x4_f64 (upper-triangle tiles,
+//                   fragments loaded straight from global memory: the partition lives in L2 / Infinity Cache after the
+//                   first pass);  the four waves' partials meet in LDS in a fixed order (deterministic);
+//                   wave 0: Cholesky of H in LDS (lane = row), two triangular solves, step, stopping rule.
+// Stopping rule, step halving and the returned (coef, H at coef) are the oracle's / irls.hip's: |delta|_inf <= tol max(1, |beta|_inf).
+// Width: p + intercept <= 64 columns (4 tiles per side, 10 accumulator tiles per wave); the implicit intercept is the LAST
+// column inside the kernel and the FIRST one in the outputs (models.py:136-142).
+#include "common.h"
+#include <algorithm>
+#include <math.h>
+#include <vector>
+
+namespace dlsa {
+
+constexpr int SM_MAXP = 64;
+constexpr int SM_LD = SM_MAXP + 1;            // LDS row pitch of the p x p matrices
+constexpr int SM_THREADS = 256;
+
+struct SmallArgs {
+    const double* X;
+    const double* y;
+    const int64_t* first;     // [K] device: first row of partition k
+    const int64_t* rows;      // [K] device: rows of partition k
+    int64_t ldx, step;
+    int p, icpt, pe, max_iter;
+    double tol;
+    double* coef;             // [K][pe]
+    double* sig;              // [K][pe][pe]
+    double* smc;              // [K][pe]
+    int* n_iter;              // [K] device
+    int* status;              // [K] device
+    double* loglik;           // [K] device
+};
+
+__device__ __forceinline__ double row16_sum(double v) {      // sum over the 16 lanes of a row group
+    v += dpp_xor_f64<1>(v);
+    v += dpp_xor_f64<2>(v);
+    v += dpp_xor_f64<4>(v);
+    v += dpp_xor_f64<8>(v);
+    return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
+    constexpr int NTRI = NT * (NT + 1) / 2;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    __shared__ double Hs[SM_MAXP * SM_LD];      // the Hessian (full, symmetric)
+    __shared__ double Ls[SM_MAXP * SM_LD];      // its Cholesky factor (lower)
+    __shared__ double gs[SM_MAXP], beta[SM_MAXP], prev[SM_MAXP], stepv[SM_MAXP], bs[SM_MAXP];
+    __shared__ double sc[4];                    // [0] loglik  [1] loop state  [2] status
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;
+    const int pe = a.pe, p = a.p;
+    const int64_t nk = a.rows[k], r0 = a.first[k], pitch = a.ldx * a.step;
+    const double* __restrict__ Xk = a.X + r0 * a.ldx;
+    const double* __restrict__ yk = a.y + r0;
+    const int kg = lane >> 4, cl = lane & 15;
+
+    if (nk == 0) {      // empty partition: the reference's zero block (models.py:84-91)
+        for (int e = tid; e < pe * pe; e += SM_THREADS) a.sig[(int64_t)k * pe * pe + e] = 0.0;
+        for (int e = tid; e < pe; e += SM_THREADS) { a.coef[(int64_t)k * pe + e] = 0.0; a.smc[(int64_t)k * pe + e] = 0.0; }
+        if (tid == 0) { a.n_iter[k] = 0; a.status[k] = DLSA_PART_EMPTY; a.loglik[k] = 0.0; }
+        return;
+    }
+    for (int e = tid; e < SM_MAXP; e += SM_THREADS) { beta[e] = 0.0; prev[e] = 0.0; stepv[e] = 0.0; }
+    __syncthreads();
+
+    double ll_prev = -INFINITY;
+    bool have_prev = false, last_pass = false;
+    int halvings = 0, iters = 0, evals = 0, status = DLSA_PART_NOT_CONVERGED;
+    double ll = 0.0;
+    for (;;) {
+        ++evals;
+        // ---- one pass over the rows at the current beta
+        double bl[NT], g[NT];
+        acc_t acc[NTRI];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { bl[t] = beta[16 * t + cl]; g[t] = 0.0; }
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        double llw = 0.0;
+        const int64_t nks = (nk + 3) / 4;
+        for (int64_t ks = wave; ks < nks; ks += 4) {
+            const int64_t r = ks * 4 + kg;
+            const bool valid = r < nk;
+            const double* rowp = Xk + (valid ? r : 0) * pitch;
+            double x[NT];
+            double part = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 16 * t + cl;
+                double v = 0.0;
+                if (valid) { if (col < p) v = rowp[col]; else if (a.icpt && col == p) v = 1.0; }
+                x[t] = v;
+                part = fma(v, bl[t], part);
+            }
+            const double eta = row16_sum(part);
+            const double yv = valid ? yk[r * a.step] : 0.0;
+            const double e = exp(-fabs(eta));
+            const double inv = 1.0 / (1.0 + e);
+            const double mu = eta >= 0.0 ? inv : e * inv;
+            const double wv = valid ? e * inv * inv : 0.0;
+            const double resid = valid ? yv - mu : 0.0;
+            if (valid && cl == 0) llw += yv * eta - (fmax(eta, 0.0) + log1p(e));     // y eta - softplus(eta)
+            double bw[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { g[t] = fma(resid, x[t], g[t]); bw[t] = x[t] * wv; }
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int ti = 0; ti <= tj; ++ti)
+                    acc[tj * (tj + 1) / 2 + ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], bw[tj], acc[tj * (tj + 1) / 2 + ti], 0, 0, 0);
+        }
+        // ---- the four waves meet in LDS, one after the other (fixed order)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { g[t] += __shfl_xor(g[t], 16, 64); g[t] += __shfl_xor(g[t], 32, 64); }
+        llw = wave_allreduce_sum(llw);
+        for (int wv2 = 0; wv2 < 4; ++wv2) {
+            if (wave == wv2) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti <= tj; ++ti)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {      // C/D register q of lane l = C[4q + (l >> 4)][l & 15]
+                            double* d = Hs + (16 * ti + 4 * q + kg) * SM_LD + 16 * tj + cl;
+                            const double v = acc[tj * (tj + 1) / 2 + ti][q];
+                            if (wv2 == 0) *d = v; else *d += v;
+                        }
+                if (kg == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { if (wv2 == 0) gs[16 * t + cl] = g[t]; else gs[16 * t + cl] += g[t]; }
+                }
+                if (lane == 0) { if (wv2 == 0) sc[0] = llw; else sc[0] += llw; }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < pe * pe; e += SM_THREADS) {          // mirror: the lower triangle is the transpose of the upper
+            const int i = e / pe, j = e - i * pe;
+            if (i > j) Hs[i * SM_LD + j] = Hs[j * SM_LD + i];
+        }
+        __syncthreads();
+        ll = sc[0];
+        if (last_pass) break;                               // max_iter reached: H, loglik are those of the last iterate
+        // ---- wave 0: safeguard, Cholesky, solve, step, stopping rule
+        if (wave == 0) {
+            const int j = lane;
+            int state = 0;                                  // 0 continue, 1 converged, 2 failed (status in sc[2]), 3 step halved
+            if (!isfinite(ll)) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NAN; }
+            else if (have_prev && ll < ll_prev - 1e-12 * fabs(ll_prev) && halvings < 30) {
+                // the previous step overshot: halve it and evaluate again (oracle irls_logistic / irls.hip)
+                if (j < pe) { stepv[j] *= 0.5; beta[j] = prev[j] + stepv[j]; }
+                state = 3;
+            } else {
+                for (int c = 0; c < pe; ++c) if (j < pe && c <= j) Ls[j * SM_LD + c] = Hs[j * SM_LD + c];
+                bool ok = true;
+                for (int c = 0; c < pe; ++c) {
+                    const double d = Ls[c * SM_LD + c];
+                    if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+                    const double s = sqrt(d);
+                    if (j >= c && j < pe) Ls[j * SM_LD + c] = (j == c) ? s : Ls[j * SM_LD + c] / s;
+                    if (j > c && j < pe) {
+                        const double ljc = Ls[j * SM_LD + c];
+                        for (int m = c + 1; m <= j; ++m) Ls[j * SM_LD + m] -= ljc * Ls[m * SM_LD + c];
+                    }
+                }
+                if (!ok) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NOT_SPD; }
+                else {
+                    if (j < pe) bs[j] = gs[j];
+                    for (int c = 0; c < pe; ++c) {          // L z = g
+                        const double z = bs[c] / Ls[c * SM_LD + c];
+                        if (j == c) bs[c] = z;
+                        if (j > c && j < pe) bs[j] -= Ls[j * SM_LD + c] * z;
+                    }
+                    for (int c = pe - 1; c >= 0; --c) {     // L' delta = z
+                        const double z = bs[c] / Ls[c * SM_LD + c];
+                        if (j == c) bs[c] = z;
+                        if (j < c) bs[j] -= Ls[c * SM_LD + j] * z;
+                    }
+                    const double dj = j < pe ? bs[j] : 0.0, bj = j < pe ? beta[j] : 0.0;
+                    const double dmax = wave_allreduce_max(fabs(dj)), bmax = wave_allreduce_max(fabs(bj));
+                    if (!isfinite(dmax)) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NAN; }
+                    else if (dmax <= a.tol * fmax(1.0, bmax)) state = 1;
+                    else if (j < pe) { prev[j] = bj; stepv[j] = dj; beta[j] = bj + dj; }
+                }
+            }
+            if (lane == 0) sc[1] = (double)state;
+        }
+        __syncthreads();
+        const int state = (int)sc[1];
+        if (state == 3) {                                   // re-evaluate at the halved step (not a new iteration)
+            ++halvings;
+            if (evals > 2 * a.max_iter + 64) break;
+            continue;
+        }
+        ++iters;
+        if (state == 1) { status = DLSA_PART_OK; break; }
+        if (state == 2) { status = (int)sc[2]; break; }
+        ll_prev = ll; have_prev = true; halvings = 0;
+        if (iters >= a.max_iter) last_pass = true;
+    }
+    // outputs: intercept first (models.py:136-142)
+    auto omap = [&](int o) { return a.icpt ? (o == 0 ? pe - 1 : o - 1) : o; };
+    for (int e = tid; e < pe * pe; e += SM_THREADS) {
+        const int i = e / pe, j = e - i * pe;
+        a.sig[(int64_t)k * pe * pe + e] = Hs[omap(i) * SM_LD + omap(j)];
+    }
+    for (int o = tid; o < pe; o += SM_THREADS) {
+        const int i = omap(o);
+        a.coef[(int64_t)k * pe + o] = beta[i];
+        double s = 0.0;
+        for (int j = 0; j < pe; ++j) s = fma(Hs[i * SM_LD + j], beta[j], s);      // Sig_inv . coef (models.py:131)
+        a.smc[(int64_t)k * pe + o] = s;
+    }
+    if (tid == 0) { a.n_iter[k] = iters; a.status[k] = status; a.loglik[k] = ll; }
+}
+
+bool irls_small_enabled() {
+    const char* e = getenv("DLSA_IRLS_SMALL");       // 0: always the host-driven path (valid results, A/B runs)
+    return e ? atoi(e) != 0 : true;
+}
+
+// every partition small enough for one workgroup each?  (rows x columns bounded so that a partition's pass stays short)
+bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
+    if (!irls_small_enabled() || pe > SM_MAXP || K < 2) return false;
+    for (int k = 0; k < K; ++k)
+        if (rows_host[k] > 65536) return false;
+    return true;
+}
+
+size_t irls_small_workspace_bytes(int K) { return align_up((size_t)K * (2 * sizeof(int64_t) + 2 * sizeof(int) + sizeof(double)), 256) + 256; }
+
+int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host,
+                   int64_t step, int K, int p, int intercept, double tol, int max_iter, double* coef, double* Sig_inv,
+                   double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host, void* ws, size_t ws_bytes,
+                   hipStream_t s) {
+    if (!ws || ws_bytes < irls_small_workspace_bytes(K) || ((uintptr_t)ws & 255)) {
+        set_error("irls_fit: workspace %zu bytes needed (256-aligned), got %zu", irls_small_workspace_bytes(K), ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    char* base = (char*)ws;
+    int64_t* d_first = (int64_t*)base;
+    int64_t* d_rows = d_first + K;
+    double* d_ll = (double*)(d_rows + K);
+    int* d_iter = (int*)(d_ll + K);
+    int* d_status = d_iter + K;
+    DLSA_HIP_CHECK(hipMemcpyAsync(d_first, first_host, (size_t)K * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    DLSA_HIP_CHECK(hipMemcpyAsync(d_rows, rows_host, (size_t)K * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    SmallArgs a;
+    a.X = X; a.y = y; a.first = d_first; a.rows = d_rows; a.ldx = ldx; a.step = step; a.p = p; a.icpt = intercept ? 1 : 0;
+    a.pe = p + a.icpt; a.max_iter = max_iter; a.tol = tol; a.coef = coef; a.sig = Sig_inv; a.smc = Sig_invMcoef;
+    a.n_iter = d_iter; a.status = d_status; a.loglik = d_ll;
+    const int nt = (a.pe + 15) / 16;
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(irls_small_kernel<1>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(irls_small_kernel<2>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(irls_small_kernel<3>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
+        default: hipLaunchKernelGGL(irls_small_kernel<4>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
+    }
+    DLSA_HIP_CHECK(hipGetLastError());
+    std::vector<int> hi((size_t)K), hs((size_t)K);
+    std::vector<double> hl((size_t)K);
+    DLSA_HIP_CHECK(hipMemcpyAsync(hi.data(), d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, s));
+    DLSA_HIP_CHECK(hipMemcpyAsync(hs.data(), d_status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, s));
+    DLSA_HIP_CHECK(hipMemcpyAsync(hl.data(), d_ll, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, s));
+    DLSA_HIP_CHECK(hipStreamSynchronize(s));
+    int overall = DLSA_OK;
+    for (int k = 0; k < K; ++k) {
+        if (n_iter_host) n_iter_host[k] = hi[k];
+        if (status_host) status_host[k] = hs[k];
+        if (loglik_host) loglik_host[k] = hl[k];
+        if (hs[k] == DLSA_PART_NOT_CONVERGED && overall == DLSA_OK) overall = DLSA_ERR_NOT_CONVERGED;
+        if (hs[k] == DLSA_PART_NOT_SPD && overall == DLSA_OK) overall = DLSA_ERR_NOT_SPD;
+        if (hs[k] == DLSA_PART_NAN && overall == DLSA_OK) overall = DLSA_ERR_NAN;
+    }
+    if (overall == DLSA_ERR_NOT_CONVERGED) set_error("irls_fit: at least one partition hit max_iter");
+    if (overall == DLSA_ERR_NOT_SPD) set_error("irls_fit: a partition's Hessian is not positive definite");
+    if (overall == DLSA_ERR_NAN) set_error("irls_fit: NaN/Inf in a partition's fit");
+    return overall;
+}
+
+}  // namespace dlsa

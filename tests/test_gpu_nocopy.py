@@ -108,3 +108,46 @@ def test_config3_scale_fit_without_copies_stays_under_130GB(eng):
     # the combined estimate recovers the generating coefficients (intercept 0, first 200 slopes 1)
     truth = np.concatenate([[0.0], np.ones(200), np.zeros(300)])
     assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.02
+
+
+@pytest.mark.parametrize("K,nk,p,icpt", [(20, 5000, 50, False), (20, 5000, 50, True), (6, 3001, 63, True), (3, 700, 5, False),
+                                         (40, 1000, 16, True), (2, 65536, 64, False)])
+def test_many_small_partitions_one_launch_matches_oracle(eng, orc, monkeypatch, K, nk, p, icpt):
+    """Config 1's shape (20 partitions of 5 000 x 50, projects/logistic_dlsa.py:89-92) and relatives: every partition is
+    fitted by its own workgroup in ONE launch (irls_small.hip).  Same exact MLE / Hessian as the oracle, and as the
+    host-driven path (DLSA_IRLS_SMALL=0)."""
+    import dlsa_amd
+    n = K * nk
+    X, y = orc.synth_logistic(61 + p, 0, n, p)
+    mb = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K, fit_intercept=icpt)
+    assert mb.status == [0] * K
+    parts = orc.partition_rows(n, K)
+    for k in range(0, K, max(1, K // 5)):
+        c, smc, sig = orc.logistic_model_block(X[parts[k]], y[parts[k]], icpt)
+        assert rel_inf(mb.coef[k].cpu().numpy(), c) < TOL_MLE
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), sig) < TOL_MLE
+        assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), smc) < TOL_MLE
+    assert max(mb.n_iter) <= 12 and min(mb.n_iter) >= 3
+    monkeypatch.setenv("DLSA_IRLS_SMALL", "0")
+    ref = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K, fit_intercept=icpt)
+    assert float((ref.coef - mb.coef).abs().max()) < 1e-11 * float(ref.coef.abs().max())
+    assert float((ref.Sig_inv - mb.Sig_inv).abs().max()) < 1e-11 * float(ref.Sig_inv.abs().max())
+    assert np.allclose(ref.loglik, mb.loglik, rtol=1e-10)
+
+
+def test_small_partition_kernel_soft_failures(eng, orc):
+    """Empty, collinear, NaN and separable partitions in one launch: per-partition statuses as the host-driven path reports them."""
+    X, y = orc.synth_logistic(71, 0, 4000, 6)
+    X = X.copy(); y = y.copy()
+    X[1000:2000, 5] = X[1000:2000, 0]                 # partition 1: duplicated column -> singular Hessian
+    X[2500, 2] = np.nan                               # partition 2: a NaN row
+    r = eng.irls_fit(dev(X), dev(y), [0, 1000, 2000, 3000, 3000, 4000])
+    assert r["status"][0] == 0 and r["status"][3] == 4 and r["status"][4] == 0
+    assert r["status"][1] in (2, 3) and r["status"][2] == 3
+    c0, _, s0 = orc.logistic_model_block(X[:1000], y[:1000])
+    assert rel_inf(r["coef"][0].cpu().numpy(), c0) < TOL_MLE and rel_inf(r["Sig_inv"][0].cpu().numpy(), s0) < TOL_MLE
+    assert float(r["Sig_inv"][3].abs().max()) == 0.0
+    Xs = np.tile(np.array([[-2.0], [-1.0], [1.0], [2.0]]), (16, 1))
+    ys = (Xs[:, 0] > 0).astype(np.float64)
+    r = eng.irls_fit(dev(Xs), dev(ys), [0, 32, 64], max_iter=25)
+    assert all(s in (1, 2, 3) for s in r["status"])  # perfectly separable: no finite MLE, must not claim OK
