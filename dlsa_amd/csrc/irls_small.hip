@@ -5,10 +5,11 @@
 // ~0.1 ms, whatever the partition's size -- 0.6 ms per 5 000-row partition whose arithmetic takes microseconds.  Partitions
 // are independent, so here ONE launch fits them all: a workgroup per partition runs the whole Newton iteration to
 // convergence on the device -- no host synchronisation, no inter-workgroup communication.
-//   per iteration:  rows -> eta, mu, w, residual, loglik (each wave takes every fourth 4-row k-step; the 16 lanes of a row
+//   per iteration:  rows -> eta, mu, w, residual, loglik (the 8 waves deal the 4-row k-steps, 4 at a time with all their loads
+//                   in flight first -- a 2 MB partition's pass is latency-bound: 0.78 -> 0.1 ms; the 16 lanes of a row
 //                   reduce eta with DPP);  g += residual x;  H += x' w x on v_mfma_f64_16x16x4_f64 (upper-triangle tiles,
 //                   fragments loaded straight from global memory: the partition lives in L2 / Infinity Cache after the
-//                   first pass);  the four waves' partials meet in LDS in a fixed order (deterministic);
+//                   first pass);  the waves' partials meet in LDS in a fixed order (deterministic);
 //                   wave 0: Cholesky of H in LDS (lane = row), two triangular solves, step, stopping rule.
 // Stopping rule, step halving and the returned (coef, H at coef) are the oracle's / irls.hip's: |delta|_inf <= tol max(1, |beta|_inf).
 // Width: p + intercept <= 64 columns (4 tiles per side, 10 accumulator tiles per wave); the implicit intercept is the LAST
@@ -22,7 +23,9 @@ namespace dlsa {
 
 constexpr int SM_MAXP = 64;
 constexpr int SM_LD = SM_MAXP + 1;            // LDS row pitch of the p x p matrices
-constexpr int SM_THREADS = 256;
+constexpr int SM_THREADS = 512;               // 8 waves: two per SIMD, 256 registers each
+constexpr int SM_WAVES = SM_THREADS / 64;
+constexpr int SM_U = 4;                       // k-steps per batch: their loads are in flight together, their 16 rows' transcendentals run once
 
 struct SmallArgs {
     const double* X;
@@ -88,42 +91,67 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
         for (int t = 0; t < NTRI; ++t) acc[t] = acc_t{0, 0, 0, 0};
         double llw = 0.0;
         const int64_t nks = (nk + 3) / 4;
-        for (int64_t ks = wave; ks < nks; ks += 4) {
-            const int64_t r = ks * 4 + kg;
-            const bool valid = r < nk;
-            const double* rowp = Xk + (valid ? r : 0) * pitch;
-            double x[NT];
-            double part = 0.0;
+        for (int64_t ks0 = (int64_t)wave * SM_U; ks0 < nks; ks0 += (int64_t)SM_WAVES * SM_U) {
+            // all loads of SM_U k-steps first (a k-step = 4 rows x 16 NT columns in the MFMA fragment layout), then the arithmetic
+            double xs[SM_U][NT], ys[SM_U];
+            bool vs[SM_U];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = 16 * t + cl;
-                double v = 0.0;
-                if (valid) { if (col < p) v = rowp[col]; else if (a.icpt && col == p) v = 1.0; }
-                x[t] = v;
-                part = fma(v, bl[t], part);
+            for (int u = 0; u < SM_U; ++u) {
+                const int64_t r = (ks0 + u) * 4 + kg;
+                vs[u] = r < nk;
+                const double* rowp = Xk + (vs[u] ? r : 0) * pitch;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = 16 * t + cl;
+                    xs[u][t] = rowp[col < p ? col : 0];                 // clamped, masked below: the load stays unconditional
+                }
+                ys[u] = yk[(vs[u] ? r : 0) * a.step];
             }
-            const double eta = row16_sum(part);
-            const double yv = valid ? yk[r * a.step] : 0.0;
-            const double e = exp(-fabs(eta));
+            // eta of the batch's 4 SM_U rows, then the transcendentals ONCE per row: lane (kg, cl = u) evaluates row (u, kg) -- every
+            // lane of a row group would otherwise run the same exp / log1p sequence for the same four rows
+            double eta_u[SM_U];
+#pragma unroll
+            for (int u = 0; u < SM_U; ++u) {
+                double part = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = 16 * t + cl;
+                    const double v = !vs[u] ? 0.0 : (col < p ? xs[u][t] : ((a.icpt && col == p) ? 1.0 : 0.0));
+                    xs[u][t] = v;
+                    part = fma(v, bl[t], part);
+                }
+                eta_u[u] = row16_sum(part);
+            }
+            double my_eta = eta_u[0], my_y = ys[0];
+            bool my_valid = vs[0];
+#pragma unroll
+            for (int u = 1; u < SM_U; ++u)
+                if ((cl & (SM_U - 1)) == u) { my_eta = eta_u[u]; my_y = ys[u]; my_valid = vs[u]; }
+            const double e = exp(-fabs(my_eta));
             const double inv = 1.0 / (1.0 + e);
-            const double mu = eta >= 0.0 ? inv : e * inv;
-            const double wv = valid ? e * inv * inv : 0.0;
-            const double resid = valid ? yv - mu : 0.0;
-            if (valid && cl == 0) llw += yv * eta - (fmax(eta, 0.0) + log1p(e));     // y eta - softplus(eta)
-            double bw[NT];
+            const double my_mu = my_eta >= 0.0 ? inv : e * inv;
+            const double my_w = my_valid ? e * inv * inv : 0.0;
+            const double my_res = my_valid ? my_y - my_mu : 0.0;
+            if (my_valid && cl < SM_U) llw += my_y * my_eta - (fmax(my_eta, 0.0) + log1p(e));     // y eta - softplus(eta), once per row
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { g[t] = fma(resid, x[t], g[t]); bw[t] = x[t] * wv; }
+            for (int u = 0; u < SM_U; ++u) {
+                const int src = (lane & 48) | u;                    // the lane of this row group that evaluated row u
+                const double wv = __shfl(my_w, src, 64), resid = __shfl(my_res, src, 64);
+                double bw[NT];
 #pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
+                for (int t = 0; t < NT; ++t) { g[t] = fma(resid, xs[u][t], g[t]); bw[t] = xs[u][t] * wv; }
 #pragma unroll
-                for (int ti = 0; ti <= tj; ++ti)
-                    acc[tj * (tj + 1) / 2 + ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], bw[tj], acc[tj * (tj + 1) / 2 + ti], 0, 0, 0);
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti <= tj; ++ti)
+                        acc[tj * (tj + 1) / 2 + ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[u][ti], bw[tj], acc[tj * (tj + 1) / 2 + ti], 0, 0, 0);
+            }
         }
-        // ---- the four waves meet in LDS, one after the other (fixed order)
+        // ---- the waves meet in LDS, one after the other (fixed order)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { g[t] += __shfl_xor(g[t], 16, 64); g[t] += __shfl_xor(g[t], 32, 64); }
         llw = wave_allreduce_sum(llw);
-        for (int wv2 = 0; wv2 < 4; ++wv2) {
+        for (int wv2 = 0; wv2 < SM_WAVES; ++wv2) {
             if (wave == wv2) {
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj)
@@ -228,12 +256,18 @@ bool irls_small_enabled() {
     return e ? atoi(e) != 0 : true;
 }
 
-// every partition small enough for one workgroup each?  (rows x columns bounded so that a partition's pass stays short)
+// One launch with a workgroup per partition, or the host-driven path that gives every partition the whole GPU in turn?
+// Measured (ms, p ~ 50): this kernel 1.0 + 1.9e-4 n_k whatever K (up to one workgroup per CU), the host-driven path 0.55 K
+// (per-iteration launch + synchronisation latency): K = 20 x 5 000 rows 1.9 vs 12.9, K = 200 x 5 000 2.6 vs 125,
+// K = 20 x 50 000 10.5 vs 11.3, K = 8 x 20 000 5.4 vs 5.4, K = 4 x 60 000 7.1 vs 2.3.
 bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     if (!irls_small_enabled() || pe > SM_MAXP || K < 2) return false;
-    for (int k = 0; k < K; ++k)
-        if (rows_host[k] > 65536) return false;
-    return true;
+    int64_t nmax = 0;
+    for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
+    if (nmax > 65536) return false;
+    const double rounds = (double)((K + kNumCU - 1) / kNumCU);
+    const double t_small = (1.0 + 1.9e-4 * (double)nmax * std::max(0.5, pe / 50.0)) * rounds, t_host = 0.55 * K;
+    return t_small < t_host;
 }
 
 size_t irls_small_workspace_bytes(int K) { return align_up((size_t)K * (2 * sizeof(int64_t) + 2 * sizeof(int) + sizeof(double)), 256) + 256; }
