@@ -100,22 +100,33 @@ def _sha16(path):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+GRAM_SOURCES = ("gram.hip", "gram_cyclic.hip", "gram_cyclic_asm.inc", "common.h")      # what the p = 500 Gram launch is built from
+
+
+def gram_sources_sha16():
+    h = hashlib.sha256()
+    for f in GRAM_SOURCES:
+        with open(os.path.join(ROOT, "dlsa_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profile(p, R):
     """HBM-side bytes per Gram launch from the committed PMC passes (profiles/pmc_latest.json: FETCH_SIZE x2, the
     gfx950 correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE, both in KB), scaled to R rows.  The profile
-    records the hash of the kernel source it was taken from: a profile of a different gram.hip gives null."""
+    records the hash of the kernel sources it was taken from: a profile of different sources gives null."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if prof.get("p", 500) != p:
             return None, "profiles/pmc_latest.json is for p=%s" % prof.get("p")
-        have = _sha16(os.path.join(ROOT, "dlsa_amd", "csrc", "gram.hip"))
+        have = gram_sources_sha16()
         if prof.get("gram_hip_sha16") != have:
-            return None, "stale: profiles/pmc_latest.json was taken from gram.hip %s, the tree has %s" % (
+            return None, "stale: profiles/pmc_latest.json was taken from Gram sources %s, the tree has %s" % (
                 prof.get("gram_hip_sha16"), have)
-        kk = [k for k in prof["kernels"] if "gram_kernel<double" in k][0]
+        kk = [k for k in prof["kernels"] if ("gram_cyclic_kernel" in k or "gram_kernel<double" in k) and "FETCH_SIZE" in prof["kernels"][k]][0]
         per_row = (2.0 * prof["kernels"][kk]["FETCH_SIZE"] + prof["kernels"][kk]["WRITE_SIZE"]) * 1024.0 / prof["rows_per_gpu"]
         return per_row * R, ("profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in KB; FETCH x2 per "
-                             "MI355X_MICROARCH.md; gram.hip %s)" % have)
+                             "MI355X_MICROARCH.md; Gram sources %s)" % have)
     except Exception as e:
         return None, "unavailable: %r" % (e,)
 
@@ -254,7 +265,8 @@ def worker(args):
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": R * bytes_row,
-                         "kernel": "dlsa::gram_kernel<double,true,2,0> (+gram_reduce_kernel, ~0.1 ms)", "kernel_ms": kern_ms,
+                         "kernel": "dlsa::gram_cyclic_kernel<true,1> (+gram_reduce_kernel, ~0.03 ms)" if 481 <= p <= 508 else
+                                   "dlsa::gram_kernel / gram_narrow_kernel (+gram_reduce_kernel)", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_row": flops_row, "algorithmic_bytes_per_row": bytes_row,
                          "hbm_GBps_algorithmic": R * bytes_row / (kern_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": R * bytes_row / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

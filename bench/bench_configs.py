@@ -122,7 +122,7 @@ def main():
         def append(self, r):
             print(json.dumps(r), flush=True)
     rows = _P()
-    sel = set(sys.argv[1:]) or {"C1", "C2", "C2b", "C3", "C3b", "C4", "C5"}
+    sel = set(sys.argv[1:]) or {"C1", "C2", "C2b", "C3", "C3b", "C3c", "C4", "C5"}
     if "C1" in sel:
         rows.append(logistic_config("C1 n=1e5 p=50 K=20 (uniform, reference simulated_pdf)", 100_000, 50, 20, kind=engine.SYNTH_UNIFORM))
     if "C2" in sel:
@@ -133,6 +133,20 @@ def main():
         rows.append(logistic_config("C3 shard n=2.5e7 p=500 K=1 (one shard per GPU)", 25_000_000, 500, 1))
     if "C3b" in sel:
         rows.append(logistic_config("C3 shard n=2.5e7 p=500 K=25 (1e6 rows per partition)", 25_000_000, 500, 25))
+    if "C3c" in sel:
+        # the reference-faithful call at config-3 scale: partition_id = i % 25 (models.py:33) and fit_intercept (logistic_dlsa.py:80),
+        # on the shard as it lies: strided partition views + implicit intercept column, no copy
+        n, p, K = 25_000_000, 500, 25
+        X, y = engine.synth(20260101, 0, n, p, kind=engine.SYNTH_GAUSSIAN)
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        t_fit, mb = timed(lambda: dlsa_amd.fit_logistic_partitions(X, y, partition_num=K, fit_intercept=True), reps=2)
+        t_all, _ = timed(lambda: dlsa_amd.dlsa(*(lambda o: (o.iloc[:, 2:], o["beta_byOLS"]))(dlsa_amd.dlsa_mapred(
+            dlsa_amd.fit_logistic_partitions(X, y, partition_num=K, fit_intercept=True))), n, fit_intercept=True), reps=2)
+        rows.append({"config": "C3 shard n=2.5e7 p=500 K=25 as i %% 25 strided views + implicit intercept (no copy of the shard)", "n": n, "p": p + 1,
+                     "K": K, "dtype": "f64", "map_fit_s": t_fit, "map_reduce_lars_s": t_all, "irls_iters": mb.n_iter[:3],
+                     "status_ok": all(v == 0 for v in mb.status), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9})
+        del X, y, mb
+        torch.cuda.empty_cache()
     if "C4" in sel:
         n4 = 14_000_000
         rows.append(logistic_config("C4 shard airline-shaped synthetic n=1.4e7 (113.9M/8) p=260 (7 numeric + 5 factors one-hot on device) K=14", n4, 0, 14, Xy=airline_shaped(n4)))

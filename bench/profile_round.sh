@@ -17,19 +17,24 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- p
 pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py --steps 2 --warmup 1 --rows-per-gpu $ROWS --no-cpu-baseline > $OUT/$name.log 2>&1; }
 pmc pmc_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 pmc pmc_sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD
+pmc pmc_grbm GRBM_GUI_ACTIVE
 pmc pmc_tcc1 TCC_HIT_sum TCC_MISS_sum
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 python3 - <<PY
 import csv, collections, glob, json, os
-out = {"rows_per_gpu": $ROWS, "p": 500, "kernels": {}}
+import hashlib
+h = hashlib.sha256()
+for fsrc in ("gram.hip", "gram_cyclic.hip", "gram_cyclic_asm.inc", "common.h"):
+    h.update(open("dlsa_amd/csrc/" + fsrc, "rb").read())
+out = {"rows_per_gpu": $ROWS, "p": 500, "gram_hip_sha16": h.hexdigest()[:16], "kernels": {}}
 for f in sorted(glob.glob("$OUT/pmc_*/*_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0]
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
     for k, d in agg.items():
-        if any(s in k for s in ('gram_kernel', 'logit_kernel', 'gram_reduce')):
+        if any(s in k for s in ('gram_kernel', 'gram_cyclic_kernel', 'logit_kernel', 'gram_reduce')):
             for c, v in d.items():
                 out["kernels"].setdefault(k, {})[c] = v / cnt[(k, c)]
 # kernel durations from the stats run

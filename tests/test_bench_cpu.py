@@ -66,7 +66,7 @@ def test_traffic_is_null_for_a_profile_of_another_kernel_source(monkeypatch, tmp
     bench = _load_bench()
     t, src = bench.traffic_from_profile(500, 1000)
     prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-    have = bench._sha16(os.path.join(ROOT, "dlsa_amd", "csrc", "gram.hip"))
+    have = bench.gram_sources_sha16()
     if prof.get("gram_hip_sha16") == have:
         assert t is not None and t > 0 and have in src
     else:
