@@ -7,7 +7,7 @@ CSRC  := dlsa_amd/csrc
 OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
-SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
+SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/gram_mid.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
          $(CSRC)/irls.hip $(CSRC)/irls_small.hip $(CSRC)/lars.hip
 OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
 # -Wno-inline-asm: the narrow Gram kernel names AGPRs beyond a127 in kernels bounded to two waves per SIMD; hipcc calls them
