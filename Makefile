@@ -7,18 +7,34 @@ CSRC  := dlsa_amd/csrc
 OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
-SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/gram_mid.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
+SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/gram_mid.hip $(CSRC)/gram_plan.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
          $(CSRC)/irls.hip $(CSRC)/irls_small.hip $(CSRC)/lars.hip
-OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS))
+# the plan-driven fp64 Gram kernel: one translation unit per range of widths (C_LO_HI = CUs per slab group, full tiles),
+# each compiled from gram_plan_unit.hip with the plans tools/gen_gram_plan_asm.py writes into $(BUILD)/gen at build time
+PLAN_UNITS := 1_8_17 2_18_24 4_25_28 4_29_32 4_33_35
+GEN   := $(BUILD)/gen
+OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS)) $(patsubst %,$(BUILD)/gram_plan_unit_%.o,$(PLAN_UNITS))
 # -Wno-inline-asm: the narrow Gram kernel names AGPRs beyond a127 in kernels bounded to two waves per SIMD; hipcc calls them
 # "reserved" but allocates them (accum_offset + AGPRs <= 256 is checked in the kernel descriptors)
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function -Wno-inline-asm $(EXTRA)
 
 all: $(OUT)
 
-$(BUILD)/%.o: $(CSRC)/% $(CSRC)/common.h $(wildcard $(CSRC)/*.inc) include/dlsa_hip.h
+$(BUILD)/%.o: $(CSRC)/% $(CSRC)/common.h $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.h) include/dlsa_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
+
+$(GEN)/gram_plan_common.inc: tools/gen_gram_plan_asm.py
+	@mkdir -p $(GEN)
+	python3 $< common > $@
+
+$(GEN)/gram_plan_%.inc: tools/gen_gram_plan_asm.py
+	@mkdir -p $(GEN)
+	python3 $< plans $(subst _, ,$*) > $@
+
+.SECONDARY: $(patsubst %,$(GEN)/gram_plan_%.inc,$(PLAN_UNITS))
+$(BUILD)/gram_plan_unit_%.o: $(CSRC)/gram_plan_unit.hip $(GEN)/gram_plan_%.inc $(GEN)/gram_plan_common.inc $(CSRC)/gram_plan_kernel.inc $(CSRC)/gram_plan.h $(CSRC)/common.h
+	$(HIPCC) $(FLAGS) -I$(GEN) -DPLAN_LO=$(word 2,$(subst _, ,$*)) -DPLAN_HI=$(word 3,$(subst _, ,$*)) -DPLAN_INC='"gram_plan_$*.inc"' -x hip -c $< -o $@
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@

@@ -102,13 +102,13 @@ __device__ __forceinline__ double wave_allreduce_min(double s) { return wave_all
 // Timing-experiment knobs that produce WRONG RESULTS (DLSA_GRAM_DBG bits 1 / 16 / 128, DLSA_OH_DBG) exist only in
 // builds made with -DDLSA_DEBUG_KNOBS (bench/ experiment builds; never `make`): in the shipped library the tests
 // below are the constant 0 and the environment cannot change a result.  The valid-result A/B switches
-// (DLSA_GRAM_DBG 2 / 4 / 32 / 64, DLSA_GRAM_NOWIDE, DLSA_IRLS_*, DLSA_LARS_WGS) stay runtime switches.
+// (DLSA_GRAM_DBG 2 / 4 / 8 / 32 / 64 / 256, DLSA_GRAM_NOWIDE, DLSA_IRLS_*, DLSA_LARS_WGS) stay runtime switches.
 #ifdef DLSA_DEBUG_KNOBS
 #define DLSA_DBG_WRONG(mask, bit) ((mask) & (bit))
 #else
 #define DLSA_DBG_WRONG(mask, bit) 0
 #endif
-constexpr int kGramDbgValidBits = 2 | 4 | 8 | 32 | 64;
+constexpr int kGramDbgValidBits = 2 | 4 | 8 | 32 | 64 | 256;
 static inline int gram_dbg_env() {
     const char* e = getenv("DLSA_GRAM_DBG");
     const int v = e ? atoi(e) : 0;
