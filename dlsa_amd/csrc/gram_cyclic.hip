@@ -23,6 +23,9 @@
 // Same-box timings per 2.5e7 rows (gram.hip's panel kernel / this one): p = 496 99.9 / 90.8 ms (68.0 TF), p = 500 100.0 /
 // 94.9 ms (66.1 TF = 84 % of the 78.6 TF fp64 MFMA peak), p = 504 100.0 / 96.7 ms.
 #include "common.h"
+#ifndef DLSA_CYC_SPLIT
+#define DLSA_CYC_SPLIT 1
+#endif
 #include <algorithm>
 
 namespace dlsa {
@@ -207,10 +210,37 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
         for (int u = 0; u < 4; ++u) {                        // chunk c4 + u sits in stage u
             load_frags(u, 1, fr1);                               // (c, 1), while (c, 0) computes
             __builtin_amdgcn_sched_barrier(0);
+#if DLSA_CYC_SPLIT
+            // The two waves of a SIMD (db = 0 / 1) meet the chunk barrier half an MFMA block apart: the db = 1 wave after its
+            // first tile row, the db = 0 wave after the whole k-step.  At the same program point both would run their
+            // post-barrier reads and DMA issue with the matrix pipe idle; offset, each covers the other (gram_plan_kernel.inc).
+            {
+                double aw[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) aw[r] = HASW ? fr0.fa[r] * fr0.wv : fr0.fa[r];
+                cyc_row<0>(aw[0], fr0.fb[0], fr0.fb[1], fr0.fb[2], fr0.fb[3], fr0.fb[4], fr0.fb[5], fr0.fb[6], fr0.fb[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (db) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                if (G > 0 || two_rows)
+                    cyc_row<1>(aw[1], fr0.fb[1], fr0.fb[2], fr0.fb[3], fr0.fb[4], fr0.fb[5], fr0.fb[6], fr0.fb[7], fr0.fb[8]);
+                if constexpr (G > 0) {
+                    if (tails) cyc_tail_a<RW, G>(aw, fr0.bt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!db) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");  // chunk c + 1 has landed (c + 2 may be in flight)
+                    asm volatile("s_barrier" ::: "memory");
+                }
+            }
+#else
             kstep(fr0, 0, 0, false);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed (c + 2 may be in flight)
             asm volatile("s_barrier" ::: "memory");
+#endif
             load_frags((u + 1) & 3, 0, fr0);                     // (c + 1, 0), while (c, 1) computes
             __builtin_amdgcn_sched_barrier(0);
             kstep(fr1, c4 + u + 3, (u + 3) & 3, true);
