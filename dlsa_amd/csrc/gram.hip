@@ -747,12 +747,6 @@ bool gram_plan_eligible(const double* X, int64_t ldx, const double* w, int64_t n
 size_t gram_plan_ws_bytes(int64_t n, int p);
 int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
-// gram_mid.hip: the generated per-wave tile plans for 125 <= p <= 284 (fp64)
-bool gram_mid_shape_ok(int64_t n, int p);
-bool gram_mid_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p);
-size_t gram_mid_ws_bytes(int64_t n, int p);
-int gram_mid_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
-                 int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
 static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     const int ntile = (p + TILE - 1) / TILE;
@@ -768,7 +762,6 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     if (elem_bytes == 8 && gram_narrow_shape_ok(n, p)) bytes = std::max(bytes, gram_narrow_ws_bytes(n, p));
     if (elem_bytes == 8 && gram_plan_shape_ok(n, p)) bytes = std::max(bytes, gram_plan_ws_bytes(n, p));
     if (elem_bytes == 8 && gram_cyclic_shape_ok(n, p)) bytes = std::max(bytes, gram_cyclic_ws_bytes(n, p));
-    if (elem_bytes == 8 && gram_mid_shape_ok(n, p)) bytes = std::max(bytes, gram_mid_ws_bytes(n, p));
     return bytes;
 }
 
@@ -788,8 +781,6 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
             return gram_cyclic_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
         if (gram_plan_eligible(X, ldx, w, n, p))
             return gram_plan_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
-        if (gram_mid_eligible(X, ldx, w, n, p))
-            return gram_mid_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
     }
     GramPlan pl;
     int rc = get_plan(p, pl);

@@ -1,5 +1,5 @@
-"""GPU: the mid-width Gram kernel (gram_mid.hip: generated per-wave tile plans, 125 <= p <= 284) against the oracle over the
-whole width range (every NT / tail-group combination), with and without weights, odd p, padded NaN pitches."""
+"""GPU: the fp64 Gram at config 4's dense widths (125 <= p <= 284: the single-CU plans of gram_plan.hip) against an fp64
+matmul over the whole range (every tile count / tail-group combination), with and without weights, odd p, padded NaN pitches."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,7 @@ def eng():
 
 
 @pytest.mark.parametrize("p", list(range(125, 285, 7)) + [128, 144, 256, 260, 272, 276, 280, 284, 129, 259])
-def test_gram_mid_matches_fp64_matmul(eng, p):
+def test_gram_midwidth_matches_fp64_matmul(eng, p):
     n = 40000 + p
     gen = torch.Generator(device="cuda"); gen.manual_seed(p)
     ld = p + (p & 1) + (2 if p % 3 == 0 else 0)               # even row pitch (DMA path), sometimes with padding columns
@@ -36,7 +36,7 @@ def test_gram_mid_matches_fp64_matmul(eng, p):
         assert float((H - ref).abs().max()) < 1e-12 * float(ref.abs().max()), (p, wt is None)
 
 
-def test_gram_mid_asymmetric_columns_and_linearity(eng):
+def test_gram_midwidth_asymmetric_columns_and_linearity(eng):
     """Distinct column scales catch a transposed / misplaced tile; two row blocks must add up."""
     n, p = 50000, 260
     X = torch.randn((n, p), dtype=torch.float64, device="cuda") * torch.arange(1, p + 1, dtype=torch.float64, device="cuda")
