@@ -34,7 +34,7 @@ for f in sorted(glob.glob("$OUT/pmc_*/*_counter_collection.csv")):
         k = r['Kernel_Name'].split('(')[0]
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
     for k, d in agg.items():
-        if any(s in k for s in ('gram_kernel', 'gram_cyclic_kernel', 'logit_kernel', 'gram_reduce')):
+        if any(s in k for s in ('gram_kernel', 'gram_cyclic_kernel', 'gram_plan_kernel', 'logit_kernel', 'gram_reduce')):
             for c, v in d.items():
                 out["kernels"].setdefault(k, {})[c] = v / cnt[(k, c)]
 # kernel durations from the stats run
