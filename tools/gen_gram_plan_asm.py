@@ -17,6 +17,7 @@ or both); with NT odd the last full tile, and always the tail tile, are plain 16
 usage: gen_gram_plan_asm.py common            > gram_plan_common.inc
        gen_gram_plan_asm.py plans C LO HI     > plans for NT = LO .. HI on C-workgroup groups
        gen_gram_plan_asm.py stats             (table of the plans)"""
+import os
 import sys
 
 MAXG, BAND, MAX_AGPR = 3, 4, 184
@@ -126,6 +127,18 @@ def emit(nt, g, C, out):
     nw = 8 * C
     maxf = max(len(r["frags"]) for r in roles)
     maxs = max(len(r["a_set"]) if r["scale_a"] else len(r["b_set"]) for r in roles)
+    # GP_LEVEL=1 (timing experiment): every role is given the LDS reads and multiplications of the heaviest one
+    level = os.environ.get("GP_LEVEL") == "1"
+    nmul = lambda r: (len(r["a_set"]) if r["scale_a"] else len(r["b_set"]) + (g if r["tails"] else 0))
+    top_reads = max(len(loads_of(nt, r)) for r in roles)
+    top_muls = max(nmul(r) for r in roles)
+    for r in roles:
+        r["xreads"] = top_reads - len(loads_of(nt, r)) if level else 0
+        r["xmuls"] = top_muls - nmul(r) if level else 0
+    maxx = max(max(r["xreads"], r["xmuls"]) for r in roles)
+    maxf_real, maxs_real = maxf, maxs
+    maxf += maxx
+    maxs += maxx
     nreg = max(role_regs(r) for r in roles)
     assert nreg <= MAX_AGPR, (nt, g, C, nreg)
     ga = max(g, 1)
@@ -133,7 +146,10 @@ def emit(nt, g, C, out):
         nt, g, C, [len(r["tiles"]) for r in roles], [len(r["tails"]) for r in roles], [len(r["frags"]) for r in roles],
         [len(loads_of(nt, r)) for r in roles]))
     out.append("template <> struct GPlan<%d, %d> {" % (nt, g))
-    out.append("    static constexpr int C = %d, MAXF = %d, MAXS = %d, NREG = %d;" % (C, maxf, maxs, nreg))
+    ntc = nt + (1 if g else 0)
+    npq = (32 * ((ntc + 1) // 2) * 8 + 1023) // 1024             # 1 KB DMA pieces per row: gram_plan.h plan_pitch()
+    nseg = npq + 1
+    out.append("    static constexpr int C = %d, MAXF = %d, MAXS = %d, NREG = %d, NSEG = %d;" % (C, maxf, maxs, nreg, nseg))
     out.append("    template <int R, typename L2, typename L1, typename LP> static __device__ __forceinline__ void load(L2&& ld2, L1&& ld1, LP&& ldp, double (&f)[MAXF]) {")
     for w, r in enumerate(roles):
         stm = []
@@ -144,6 +160,9 @@ def emit(nt, g, C, out):
                 stm.append("f[%d] = ld1(%d);" % (idx[0], imm))
             else:
                 stm.append("f[%d] = ldp(%d);" % (idx[0], imm))
+        first = loads_of(nt, r)[0]
+        for k in range(max(r["xreads"], r["xmuls"])):
+            stm.append("f[%d] = %s(%d);" % (maxf_real + k, "ld1" if first[0] != "pl" else "ldp", first[1] + 16 * (k + 1)))
         out.append("        %sif constexpr (R == %d) { %s }" % ("" if w == 0 else "else ", w, " ".join(stm)))
     out.append("    }")
     out.append("    template <int R> static constexpr bool has_tails() { constexpr bool n[%d] = {%s}; return n[R]; }" % (
@@ -155,6 +174,8 @@ def emit(nt, g, C, out):
         stm = ["s[%d] = HASW ? f[%d] * w : f[%d];" % (k, r["frags"].index(t), r["frags"].index(t)) for k, t in enumerate(side)]
         if not r["scale_a"] and r["tails"]:
             stm += ["if (HASW) bt[%d] *= w;" % gi for gi in range(g)]
+        for k in range(max(r["xreads"], r["xmuls"])):
+            stm.append("s[%d] = f[%d] * w;" % (maxs_real + k, maxf_real + k) if k < r["xmuls"] else "s[%d] = f[%d];" % (maxs_real + k, maxf_real + k))
         out.append("        %sif constexpr (R == %d) { %s }" % ("" if w == 0 else "else ", w, " ".join(stm)))
     out.append("    }")
     # PART 0 = the whole k-step, 1 / 2 = its first / second half (the second wave of a SIMD meets the chunk barrier in the
@@ -190,12 +211,22 @@ def emit(nt, g, C, out):
             top += 2
         clob = ", ".join('"a%d"' % q for q in range(max(top, 1)))
         half = len(r["tiles"]) // 2
+        for k in range(max(r["xreads"], r["xmuls"])):
+            op("s[%d]" % (maxs_real + k))
         opstr = ", ".join('"v"(%s)' % e for e in ops)
         parts = [["s_nop 1"] + body, ["s_nop 1"] + body[:half], body[half:]]
+        # PART 10 + k: segment k of NSEG consecutive near-equal segments (the second k-step of a chunk issues one DMA piece of
+        # the chunk three ahead behind each segment)
+        for k in range(nseg):
+            seg = body[(len(body) * k) // nseg:(len(body) * (k + 1)) // nseg]
+            parts.append((["s_nop 1"] if k == 0 else []) + seg)
         out.append("        %sif constexpr (R == %d) {" % ("" if w == 0 else "else ", w))
         for part, lines in enumerate(parts):
+            pid = part if part < 3 else 10 + part - 3
+            if not lines:
+                lines = ["s_nop 0"]
             out.append('            %sif constexpr (PART == %d) asm volatile("%s" :: %s : %s);' % (
-                "" if part == 0 else "else ", part, "\\n\\t".join(lines), opstr, clob))
+                "" if part == 0 else "else ", pid, "\\n\\t".join(lines), opstr, clob))
         out.append("        }")
     out.append("    }")
     out.append("    template <int R> static __device__ __forceinline__ void store(int lane, double* __restrict__ P, int PP) {")
