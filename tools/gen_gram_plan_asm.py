@@ -142,13 +142,13 @@ def emit(nt, g, C, out):
     nreg = max(role_regs(r) for r in roles)
     assert nreg <= MAX_AGPR, (nt, g, C, nreg)
     ga = max(g, 1)
+    ntc = nt + (1 if g else 0)
+    npq = (32 * ((ntc + 1) // 2) * 8 + 1023) // 1024             # 1 KB DMA pieces per row: gram_plan.h plan_pitch()
+    nseg = npq + 1
     out.append("// ---- NT = %d, G = %d, C = %d: tiles %s tails %s frags %s LDS reads %s" % (
         nt, g, C, [len(r["tiles"]) for r in roles], [len(r["tails"]) for r in roles], [len(r["frags"]) for r in roles],
         [len(loads_of(nt, r)) for r in roles]))
     out.append("template <> struct GPlan<%d, %d> {" % (nt, g))
-    ntc = nt + (1 if g else 0)
-    npq = (32 * ((ntc + 1) // 2) * 8 + 1023) // 1024             # 1 KB DMA pieces per row: gram_plan.h plan_pitch()
-    nseg = npq + 1
     out.append("    static constexpr int C = %d, MAXF = %d, MAXS = %d, NREG = %d, NSEG = %d;" % (C, maxf, maxs, nreg, nseg))
     out.append("    template <int R, typename L2, typename L1, typename LP> static __device__ __forceinline__ void load(L2&& ld2, L1&& ld1, LP&& ldp, double (&f)[MAXF]) {")
     for w, r in enumerate(roles):
@@ -164,6 +164,24 @@ def emit(nt, g, C, out):
         for k in range(max(r["xreads"], r["xmuls"])):
             stm.append("f[%d] = %s(%d);" % (maxf_real + k, "ld1" if first[0] != "pl" else "ldp", first[1] + 16 * (k + 1)))
         out.append("        %sif constexpr (R == %d) { %s }" % ("" if w == 0 else "else ", w, " ".join(stm)))
+    out.append("    }")
+    # the same loads in NSEG parts (part q holds the reads q, q + NSEG, ...): the second k-step of a chunk issues part q of
+    # the NEXT k-step's fragment reads behind segment q of its MFMA block
+    out.append("    template <int R, int Q, typename L2, typename L1, typename LP> static __device__ __forceinline__ void load_part(L2&& ld2, L1&& ld1, LP&& ldp, double (&f)[MAXF]) {")
+    for w, r in enumerate(roles):
+        out.append("        %sif constexpr (R == %d) {" % ("" if w == 0 else "else ", w))
+        lds = loads_of(nt, r)
+        for q in range(nseg):
+            stm = []
+            for kind, imm, idx in lds[q::nseg]:
+                if kind == "p2":
+                    stm.append("{ const dlsa_d2 q2 = ld2(%d); f[%d] = q2.x; f[%d] = q2.y; }" % (imm, idx[0], idx[1]))
+                elif kind == "p1":
+                    stm.append("f[%d] = ld1(%d);" % (idx[0], imm))
+                else:
+                    stm.append("f[%d] = ldp(%d);" % (idx[0], imm))
+            out.append("            %sif constexpr (Q == %d) { %s }" % ("" if q == 0 else "else ", q, " ".join(stm)))
+        out.append("        }")
     out.append("    }")
     out.append("    template <int R> static constexpr bool has_tails() { constexpr bool n[%d] = {%s}; return n[R]; }" % (
         nw, ", ".join("true" if r["tails"] else "false" for r in roles)))
