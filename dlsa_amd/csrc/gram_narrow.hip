@@ -34,6 +34,9 @@ namespace dlsa {
 template <typename T>
 void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream);
 
+#ifndef DLSA_NARROW_SPREAD
+#define DLSA_NARROW_SPREAD 1          // 1: the DMA two chunks ahead is issued in parts behind the segments of the first k-step's MFMA block
+#endif
 #ifndef DLSA_NARROW_KC
 #define DLSA_NARROW_KC 32
 #endif
@@ -60,6 +63,19 @@ constexpr int narrow_buf_elems(int nt, int kc) { return kc * narrow_pitch(nt) + 
 // and copies all of them into AGPRs and back around every k-step (448 v_accvgpr moves per 28 MFMAs: measured no
 // faster than the tile-list kernel).  Named registers stay where the MFMAs want them.
 #include "gram_narrow_asm.inc"
+
+// segments SEG .. NARROW_NSEG - 1 of a k-step's MFMA block, with between(q) issued behind segment q
+template <int NT, int G, int SEG, typename F>
+__device__ __forceinline__ void narrow_kstep_spread(const double (&f)[NT + (G > 0 ? 1 : 0)], const double (&g)[NT],
+                                                    const double (&bt)[G > 0 ? G : 1], F&& between) {
+    if constexpr (SEG < NARROW_NSEG) {
+        narrow_kstep_seg<NT, G, SEG>(f, g, bt);
+        __builtin_amdgcn_sched_barrier(0);
+        between(SEG);
+        __builtin_amdgcn_sched_barrier(0);
+        narrow_kstep_spread<NT, G, SEG + 1>(f, g, bt, between);
+    }
+}
 
 // fn(t, v) for the local tiles t in [T, TEND) with v = this lane's four doubles of tile t (AGPRs a[8t : 8t + 7])
 template <int T, int TEND, typename F>
@@ -197,6 +213,23 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + KC * LDP), 16, lane * 16, chunk * KC * 8, 0, 0);
     };
 
+    // the same DMA in five parts: rows wave + 4 ps for ps in [q RQ, (q + 1) RQ), q < 4; then w
+    constexpr int RQ = KC / NWAVES / 4;
+    static_assert(RQ * 4 * NWAVES == KC, "rows per wave and chunk in four groups");
+    auto stage_rows = [&](int chunk, int buf, int q) {
+        double* base = lds + buf * BUF;
+#pragma unroll
+        for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
+            const int row = wave + NWAVES * ps;
+            const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, 0);
+        }
+    };
+    auto stage_w = [&](int chunk, int buf) {
+        if (HASW && lane < KC / 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(lds + buf * BUF + KC * LDP), 16, lane * 16, chunk * KC * 8, 0, 0);
+    };
+
     narrow_acc_zero<narrow_nreg(NT, G)>();
 
     stage(0, 0);
@@ -208,7 +241,9 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);      // the 4 tail columns, broadcast to the 4 blocks
     int cur = 0, nxt2 = 2;                               // ring positions of chunk c and chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
+#if !DLSA_NARROW_SPREAD
         if (!DLSA_DBG_WRONG(a.dbg, 1)) stage(c + 2, nxt2);            // past the slab end: bounds-checked zeros, no traffic
+#endif
         const double* base = lds + cur * BUF;
         // all of this wave's fragments of the chunk are requested up front: only the first k-step waits for LDS
         double f[KC / 16][NTC], wv[KC / 16], bt[KC / 16][GA];
@@ -230,6 +265,18 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
 #pragma unroll
             for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? (HASW ? bt[kk][gi] * wv[kk] : bt[kk][gi]) : 0.0;
             // tile (ti, tj) += f[ti] (x) g[tj] for all ti <= tj < NT;  tail (t, gi) += blockdiag(f[t] (x) btw[gi]) for t <= NT
+#if DLSA_NARROW_SPREAD
+            // the DMA of chunk c + 2 (past the slab end: bounds-checked zeros, no traffic) goes out in five parts BEHIND the five
+            // segments of the chunk's first k-step (four row groups, then w): as a burst in front of the block it kept the wave
+            // out of MFMAs for its whole issue time (gram_plan_kernel.inc)
+            if (kk == 0 && !DLSA_DBG_WRONG(a.dbg, 128)) {
+                narrow_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](int q) {
+                    if (DLSA_DBG_WRONG(a.dbg, 1)) return;
+                    if (q < 4) stage_rows(c + 2, nxt2, q); else stage_w(c + 2, nxt2);
+                });
+                continue;
+            }
+#endif
             if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT, G>(f[kk], g, btw);
             else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]), "v"(btw[0]));
         }

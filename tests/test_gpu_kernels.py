@@ -131,6 +131,26 @@ def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
     assert rel_inf(H.cpu().numpy(), Hl.cpu().numpy()) < 1e-12
 
 
+@pytest.mark.parametrize("p", list(range(49, 113)))
+def test_gram_narrow_every_width(eng, p):
+    """Every width of the row-split kernel (all tile counts x tail groups, one and two k-steps per chunk), weighted and not,
+    against an fp64 matmul.  The weighted case is the one that exposes an operand hazard at the head of the kernel's
+    inline-assembly MFMA block: the scaled fragments are VALU results the compiler may place one instruction earlier."""
+    n = 16384 + 3 * p
+    gen = torch.Generator(device="cuda"); gen.manual_seed(p)
+    ld = p + (p & 1)
+    buf = torch.full((n, ld), float("nan"), dtype=torch.float64, device="cuda")
+    buf[:, :p] = torch.randn((n, p), dtype=torch.float64, device="cuda", generator=gen)
+    X = buf[:, :p]
+    w = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    Xc = X.contiguous()
+    for wt in (w, None):
+        H = eng.gram(X, wt)
+        ref = Xc.T @ (Xc if wt is None else Xc * wt[:, None])
+        d = ref.diagonal().sqrt()
+        assert float(((H - ref).abs() / (d[:, None] * d[None, :])).max()) < 1e-12, (p, wt is None)
+
+
 @pytest.mark.parametrize("n,p,ld", [(9001, 51, 52), (30000, 101, 102), (8192, 111, 112), (4000, 501, 502), (5000, 37, 38),
                                     (12000, 129, 136), (2000, 1, 2), (700, 255, 256)])
 def test_gram_odd_p_in_even_row_pitch(eng, orc, n, p, ld):
