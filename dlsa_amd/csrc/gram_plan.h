@@ -13,11 +13,12 @@ constexpr int64_t PLAN_MIN_ROWS = 32768;
 #define PLAN_AHEAD_CHUNKS 8
 #endif
 constexpr int PLAN_AHEAD = PLAN_AHEAD_CHUNKS;                     // chunks a workgroup may run ahead of the slowest of its group
-constexpr int PLAN_PACE_SPINS = 4096;             // x ~2 us: then the workgroup stops waiting for partners that are not running
+constexpr int PLAN_PACE_SPINS = 512;              // pacing sleeps (~2 us each) per launch and workgroup: 512 + chunks / 4, then it runs on unpaced
 
 struct PlanArgs {
     const double* X;
-    const double* w;
+    const double* w;      // the row weights, or PLAN_KC ones when w_step == 0 (unweighted Gram)
+    int w_step;           // 1: w advances with the rows; 0: every chunk reads the same PLAN_KC doubles
     double* partial;      // [nslab][PP][PP]
     int* progress;        // [nslab][4] chunk counts of the workgroups of a slab group, zero at launch (C > 1)
     int64_t ldx, n, rows_per_slab;

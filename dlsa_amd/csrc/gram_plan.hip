@@ -65,8 +65,10 @@ size_t gram_plan_ws_bytes(int64_t n, int p) {
     plan_shape(p + (p & 1), nt, g);
     int64_t rps;
     const int ns = plan_slabs(n, plan_group(nt), rps);
-    return align_up((size_t)ns * plan_pp(p) * plan_pp(p) * 8, 256) + (size_t)ns * 16;
+    return align_up((size_t)ns * plan_pp(p) * plan_pp(p) * 8, 256) + align_up((size_t)ns * 16, 256) + 256;    // partials, pacing counts, ones
 }
+
+__global__ void plan_ones_kernel(double* ones) { ones[threadIdx.x] = 1.0; }
 
 int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -77,13 +79,19 @@ int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
     int nt, g;
     plan_shape(a.p, nt, g);
     const int nslab = plan_slabs(n, plan_group(nt), a.rows_per_slab);
-    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), need = part + (size_t)nslab * 16;
+    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), prog = align_up((size_t)nslab * 16, 256), need = part + prog + 256;
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
     a.progress = (int*)((char*)ws + part);
     if (plan_group(nt) > 1) DLSA_HIP_CHECK(hipMemsetAsync(a.progress, 0, (size_t)nslab * 16, stream));
+    a.w_step = w ? 1 : 0;
+    if (!w) {                // unweighted: the kernel multiplies by a streamed block of ones (gram_plan_kernel.inc plan_launch_g)
+        double* ones = (double*)((char*)ws + part + prog);
+        hipLaunchKernelGGL(plan_ones_kernel, dim3(1), dim3(PLAN_KC), 0, stream, ones);
+        a.w = ones;
+    }
     int rc;
     if (nt <= 17) rc = gram_plan_launch_8(a, nt, g, nslab, stream);
     else if (nt <= 24) rc = gram_plan_launch_18(a, nt, g, nslab, stream);
