@@ -449,36 +449,50 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
 // H[i][j] = H[j][i] = (accumulate ? H[i][j] : 0) + sum_s partial[s][i][j]  for i <= j  (fixed order).  Only the upper
 // triangle is read -- coalesced along j -- and each sum is written to both triangles (the mirrored write is the
 // uncoalesced one, but it is p^2/2 elements once instead of nslab strided reads per element).
+// H (+)= sum over slabs of the partial upper triangles, mirrored.  One element = 16 threads (a quarter wave's rows of the
+// block): thread kg sums slabs kg, kg + 16, ... in two chains, the 16 sums meet in LDS and are added in a FIXED order
+// (bit-reproducible).  With one thread per element the 512 slabs of the narrow kernel were 128 dependent loads deep: 62 us
+// at p = 100, 3 % of the whole Gram of 1e7 rows and a third of a 1e6-row partition's.
+constexpr int RED_J = 16, RED_K = 16;
 template <typename T>
-__global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int PP, int p,
-                                   T* __restrict__ H, int64_t ldh, int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(RED_J * RED_K) void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int PP, int p,
+                                                                      T* __restrict__ H, int64_t ldh, int accumulate) {
+    __shared__ T part[RED_K][RED_J + 1];
+    const int jl = threadIdx.x % RED_J, kg = threadIdx.x / RED_J;
+    const int j = blockIdx.x * RED_J + jl;
     const int i = blockIdx.y;
-    if (j >= p || j < i) return;
-    const T* src = partial + (int64_t)i * PP + j;
-    T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
-    const int64_t stride = (int64_t)PP * PP;
-    int k = 0;
-    for (; k + 3 < nslab; k += 4) {      // 4 independent chains, combined in a fixed order
-        s0 += src[(k + 0) * stride];
-        s1 += src[(k + 1) * stride];
-        s2 += src[(k + 2) * stride];
-        s3 += src[(k + 3) * stride];
+    if (blockIdx.x * RED_J + RED_J - 1 < i) return;           // the whole block lies below the diagonal
+    const bool live = j < p && j >= i;
+    T s0 = T(0), s1 = T(0);
+    if (live) {
+        const T* src = partial + (int64_t)i * PP + j;
+        const int64_t stride = (int64_t)PP * PP;
+        int k = kg;
+        for (; k + RED_K < nslab; k += 2 * RED_K) {
+            s0 += src[k * stride];
+            s1 += src[(k + RED_K) * stride];
+        }
+        if (k < nslab) s0 += src[k * stride];
     }
-    for (; k < nslab; ++k) s0 += src[k * stride];
-    const T s = (s0 + s1) + (s2 + s3);
-    T* dst = H + (int64_t)i * ldh + j;
-    *dst = accumulate ? (*dst + s) : s;
-    if (i != j) {
-        T* mir = H + (int64_t)j * ldh + i;
-        *mir = accumulate ? (*mir + s) : s;
+    part[kg][jl] = s0 + s1;
+    __syncthreads();
+    if (kg == 0 && live) {
+        T s = part[0][jl];
+#pragma unroll
+        for (int g = 1; g < RED_K; ++g) s += part[g][jl];
+        T* dst = H + (int64_t)i * ldh + j;
+        *dst = accumulate ? (*dst + s) : s;
+        if (i != j) {
+            T* mir = H + (int64_t)j * ldh + i;
+            *mir = accumulate ? (*mir + s) : s;
+        }
     }
 }
 
 template <typename T>
 void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream) {
-    dim3 rg((p + 127) / 128, p);
-    hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(128), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
+    dim3 rg((p + RED_J - 1) / RED_J, p);
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(RED_J * RED_K), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
 }
 template void gram_reduce_launch<double>(const double*, int, int, int, double*, int64_t, int, hipStream_t);
 template void gram_reduce_launch<float>(const float*, int, int, int, float*, int64_t, int, hipStream_t);

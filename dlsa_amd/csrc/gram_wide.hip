@@ -206,8 +206,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
 }
 
 template <typename T>
-__global__ void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int PP, int p,
-                                   T* __restrict__ H, int64_t ldh, int accumulate);
+void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream);   // gram.hip
 
 // -------------------------------------------------------------------------------------------------
 // host: plan
@@ -360,8 +359,7 @@ int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
     if (w) hipLaunchKernelGGL((gram_wide_f32_kernel<true>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
     else hipLaunchKernelGGL((gram_wide_f32_kernel<false>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
     DLSA_HIP_CHECK(hipGetLastError());
-    dim3 rg((p + 127) / 128, p);
-    hipLaunchKernelGGL((gram_reduce_kernel<float>), rg, dim3(128), 0, stream, (const float*)ws, nslab, pl.PP, p, H, ldh, accumulate);
+    gram_reduce_launch<float>((const float*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
