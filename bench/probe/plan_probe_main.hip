@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     fill<<<1024, 256>>>(X, (size_t)rows * p, 1u); fill<<<256, 256>>>(w, rows, 7u);
     dlsa::PlanArgs a;
     a.X = X; a.w = w; a.w_step = 1; a.partial = part; a.progress = prog; a.ldx = p; a.n = rows; a.p = p; a.PP = PP;
-    a.rows_per_slab = ((rows + nslab - 1) / nslab + 7) / 8 * 8;
+    a.rows_per_slab = ((rows + nslab - 1) / nslab + 15) / 16 * 16;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> ts;
     for (int r = 0; r < reps + 1; ++r) {

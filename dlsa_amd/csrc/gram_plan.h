@@ -7,7 +7,9 @@ namespace dlsa {
 typedef double dlsa_d2 __attribute__((ext_vector_type(2)));
 
 constexpr int PLAN_NT_MIN = 8, PLAN_NT_MAX = 35;
-constexpr int PLAN_KC = 8, PLAN_NST = 4;          // rows per chunk (two k-steps of 4), LDS ring stages
+constexpr int PLAN_KC = 8, PLAN_NST = 4;          // rows per chunk in multi-CU groups (two k-steps of 4), LDS ring stages
+constexpr int PLAN_KC1 = 16;                      // rows per chunk of the single-CU plans (four k-steps per barrier: their ring fits)
+constexpr int plan_kc(int C) { return C == 1 ? PLAN_KC1 : PLAN_KC; }
 constexpr int64_t PLAN_MIN_ROWS = 32768;
 #ifndef PLAN_AHEAD_CHUNKS
 #define PLAN_AHEAD_CHUNKS 8
@@ -29,7 +31,7 @@ struct PlanArgs {
 // LDS row pitch in doubles: the tile columns rounded up to whole 32-column groups (a multiple of 256 bytes keeps the two rows
 // a ds_read_b128 lane group spans on disjoint banks)
 constexpr int plan_pitch(int ntc) { return 32 * ((ntc + 1) / 2); }
-constexpr int plan_buf(int ntc) { return PLAN_KC * plan_pitch(ntc) + PLAN_KC; }          // a chunk + its w
+constexpr int plan_buf(int ntc, int kc) { return kc * plan_pitch(ntc) + kc; }             // a chunk + its w
 
 // workgroups (CUs of one XCD) that share a slab, by the number of full tiles; tools/gen_gram_plan_asm.py groups_for()
 constexpr int plan_group(int nt) { return nt <= 17 ? 1 : nt <= 24 ? 2 : 4; }

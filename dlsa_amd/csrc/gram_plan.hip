@@ -35,8 +35,8 @@ static void plan_shape(int p, int& nt, int& g) {
 
 static int plan_slabs(int64_t n, int C, int64_t& rows_per_slab) {
     int64_t ns = kNumCU / C;
-    while (ns > kNumXCD && n / ns < 4 * PLAN_KC) ns -= kNumXCD;
-    rows_per_slab = ((n + ns - 1) / ns + PLAN_KC - 1) / PLAN_KC * PLAN_KC;
+    while (ns > kNumXCD && n / ns < 4 * PLAN_KC1) ns -= kNumXCD;
+    rows_per_slab = ((n + ns - 1) / ns + PLAN_KC1 - 1) / PLAN_KC1 * PLAN_KC1;       // whole chunks of either plan class
     return (int)ns;
 }
 
@@ -55,7 +55,7 @@ bool gram_plan_eligible(const double* X, int64_t ldx, const double* w, int64_t n
     int64_t rps;
     plan_slabs(n, plan_group(nt), rps);
     return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && (!w || ((uintptr_t)w % 16) == 0) &&
-           (double)(rps + 8 * PLAN_KC) * (double)ldx * 8.0 < 2.0e9;            // 32-bit DMA offsets
+           (double)(rps + 8 * PLAN_KC1) * (double)ldx * 8.0 < 2.0e9;            // 32-bit DMA offsets
 }
 
 static int plan_pp(int p) { return ((p + 15) / 16 * 16 + 63) / 64 * 64; }
@@ -89,7 +89,7 @@ int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
     a.w_step = w ? 1 : 0;
     if (!w) {                // unweighted: the kernel multiplies by a streamed block of ones (gram_plan_kernel.inc plan_launch_g)
         double* ones = (double*)((char*)ws + part + prog);
-        hipLaunchKernelGGL(plan_ones_kernel, dim3(1), dim3(PLAN_KC), 0, stream, ones);
+        hipLaunchKernelGGL(plan_ones_kernel, dim3(1), dim3(PLAN_KC1), 0, stream, ones);
         a.w = ones;
     }
     int rc;

@@ -144,7 +144,8 @@ def emit(nt, g, C, out):
     ga = max(g, 1)
     ntc = nt + (1 if g else 0)
     npq = (32 * ((ntc + 1) // 2) * 8 + 1023) // 1024             # 1 KB DMA pieces per row: gram_plan.h plan_pitch()
-    nseg = npq + 1
+    rpw = 2 if C == 1 else 1                                     # rows per wave and chunk: gram_plan.h plan_kc() / 8
+    nseg = rpw * npq + 1
     out.append("// ---- NT = %d, G = %d, C = %d: tiles %s tails %s frags %s LDS reads %s" % (
         nt, g, C, [len(r["tiles"]) for r in roles], [len(r["tails"]) for r in roles], [len(r["frags"]) for r in roles],
         [len(loads_of(nt, r)) for r in roles]))
