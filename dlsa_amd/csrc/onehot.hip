@@ -12,8 +12,9 @@
 //
 // One thread owns one row (64 distinct rows per wave: the transcendentals are not replicated).  Histograms are
 // accumulated with LDS atomics in per-workgroup tables and flushed to per-workgroup partials that a second kernel
-// sums in a fixed order; the order of the LDS atomic adds inside a workgroup is not fixed, so -- unlike the dense
-// kernels -- results can differ in the last bits from run to run.  The factor-pair tables of the Gram are dealt to
+// sums in a fixed order.  The waves of a workgroup add to its tables in a fixed order as well (OhDesc::ordered, the
+// default: turn-taking in the logit pass, a systolic wave-by-unit schedule in the Gram), so results are bit-identical
+// from run to run like those of the dense kernels; DLSA_OH_ORDERED=0 lets all waves add at once (faster Gram, last bits vary).  The factor-pair tables of the Gram are dealt to
 // workgroup ROLES so that each role's tables fit in LDS (every role streams all rows; they are cheap).
 #include "common.h"
 #include <vector>
@@ -64,6 +65,8 @@ struct OhDesc {                       // device-visible description of the desig
     int lvl_off[OH_MAXF + 1];         // factor t's levels occupy [lvl_off[t], lvl_off[t+1]) of level_col
     int nlev_total;
     int dbg;                          // DLSA_OH_DBG (timing experiments only, wrong results): 1 = no dense x level atomics, 2 = no pair-table atomics
+    int ordered;                      // 1 (default): the waves of a workgroup add to its LDS tables one after another in wave order --
+                                      // bit-reproducible; 0 (DLSA_OH_ORDERED=0): all waves at once, last bits vary from run to run
 };
 
 }  // namespace dlsa
@@ -145,7 +148,14 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
 #pragma unroll
     for (int a = 0; a < OH_MAXD; ++a) gd[a] = 0.0;
     double ll = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // every thread runs the same number of rounds (the ordered mode has barriers inside): rows past n are clamped and masked
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (n - (int64_t)blockIdx.x * blockDim.x + stride - 1) / stride;
+    const int mywave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + rd * stride;
+        const bool valid = i0 < n;
+        const int64_t i = valid ? i0 : n - 1;
         double d[OH_MAXD];
         oh_dense_row(ds, num, ldn, i, d);
         double eta = 0.0;
@@ -169,14 +179,25 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
         inv = fma(fma(-(1.0 + e), inv, 1.0), inv, inv);
         inv = fma(fma(-(1.0 + e), inv, 1.0), inv, inv);
         const double mu = eta >= 0.0 ? inv : e * inv;
-        if (w_out) w_out[i] = e * inv * inv;
-        const double r = yv - mu;
-        ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
+        if (w_out && valid) w_out[i] = e * inv * inv;
+        const double r = valid ? yv - mu : 0.0;
+        if (valid) ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
 #pragma unroll
         for (int a = 0; a < OH_MAXD; ++a) gd[a] = fma(r, d[a], gd[a]);
+        if (ds.ordered) {                           // one wave at a time, in wave order: a fixed order of the LDS adds
+            for (int turn = 0; turn < nwaves; ++turn) {
+                if (turn == mywave && valid) {
 #pragma unroll
-        for (int t = 0; t < OH_MAXF; ++t)
-            if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg_mine[cols[t]], r);
+                    for (int t = 0; t < OH_MAXF; ++t)
+                        if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg_mine[cols[t]], r);
+                }
+                __syncthreads();
+            }
+        } else if (valid) {
+#pragma unroll
+            for (int t = 0; t < OH_MAXF; ++t)
+                if (t < ds.f && cols[t] >= 0) unsafeAtomicAdd(&sg_mine[cols[t]], r);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -223,8 +244,14 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
 #pragma unroll
     for (int k = 0; k < OH_MAXD * (OH_MAXD + 1) / 2; ++k) hdd[k] = 0.0;
     const bool dense = role.with_dense != 0;
-    for (int64_t i = (int64_t)bl * blockDim.x + threadIdx.x; i < n; i += (int64_t)blocks_per_role * blockDim.x) {
-        const double wi = w ? w[i] : 1.0;
+    const int64_t stride = (int64_t)blocks_per_role * blockDim.x;
+    const int64_t rounds = (n - (int64_t)bl * blockDim.x + stride - 1) / stride;
+    const int mywave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t i0 = (int64_t)bl * blockDim.x + threadIdx.x + rd * stride;
+        const bool valid = i0 < n;
+        const int64_t i = valid ? i0 : n - 1;
+        const double wi = valid ? (w ? w[i] : 1.0) : 0.0;
         int lv[OH_MAXF];
 #pragma unroll
         for (int t = 0; t < OH_MAXF; ++t) {
@@ -234,29 +261,49 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
                 if (code >= 0 && code < ds.lvl_off[t + 1] - ds.lvl_off[t]) lv[t] = code;
             }
         }
+        double d[OH_MAXD];
         if (dense) {
-            double d[OH_MAXD];
             oh_dense_row(ds, num, ldn, i, d);
             int k = 0;
 #pragma unroll
             for (int a = 0; a < OH_MAXD; ++a)
 #pragma unroll
                 for (int b = a; b < OH_MAXD; ++b, ++k) hdd[k] = fma(wi * d[a], d[b], hdd[k]);
-#pragma unroll
-            for (int t = 0; t < OH_MAXF; ++t)
-                if (t < ds.f && lv[t] >= 0) {
-                    double* dst = dense_tab + (ds.lvl_off[t] + lv[t]) * OH_MAXD;
-#pragma unroll
-                    for (int a = 0; a < OH_MAXD; ++a)
-                        if (a < ds.D && !DLSA_DBG_WRONG(ds.dbg, 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
-                }
         }
-        for (int q = 0; q < role.ntab; ++q) {
-            const OhTable tb = role.tab[q];
-            const int lt = lv[tb.t], lu = lv[tb.u];
-            if (lt < 0 || lu < 0 || DLSA_DBG_WRONG(ds.dbg, 2)) continue;
-            if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
-            else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
+        // the row's LDS adds, one UNIT at a time: unit t < nd = the dense x level block of factor t (D adds), unit nd + q = pair table q
+        // (single-add units would level the systolic schedule below, but the run-time column select they need costs more: measured)
+        const int nd = dense ? ds.f : 0, nunit = nd + role.ntab;
+        auto unit = [&](int u) {
+            if (u < nd) {
+                int l = -1;
+#pragma unroll
+                for (int t = 0; t < OH_MAXF; ++t) l = (t == u) ? lv[t] : l;
+                if (l < 0) return;
+                double* dst = dense_tab + (ds.lvl_off[u] + l) * OH_MAXD;
+#pragma unroll
+                for (int a = 0; a < OH_MAXD; ++a)
+                    if (a < ds.D && !DLSA_DBG_WRONG(ds.dbg, 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
+            } else {
+                const OhTable tb = role.tab[u - nd];
+                int lt = -1, lu = -1;
+#pragma unroll
+                for (int t = 0; t < OH_MAXF; ++t) { lt = (t == tb.t) ? lv[t] : lt; lu = (t == tb.u) ? lv[t] : lu; }
+                if (lt < 0 || lu < 0 || DLSA_DBG_WRONG(ds.dbg, 2)) return;
+                if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
+                else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
+            }
+        };
+        if (ds.ordered) {
+            // Ordered mode: wave k works on unit (step - k) -- a systolic schedule with a barrier between steps.  Every unit has
+            // its own cells, and the waves reach a unit one after another in wave order, so the adds to any cell happen in a
+            // fixed order (bit-reproducible) while all waves keep the LDS atomic pipeline busy on different units.
+            for (int step = 0; step < nunit + nwaves - 1; ++step) {
+                const int u = step - mywave;
+                if (valid && u >= 0 && u < nunit) unit(u);
+                __syncthreads();
+            }
+        } else if (valid) {
+            for (int u = 0; u < nunit; ++u) unit(u);
         }
     }
     __syncthreads();
@@ -364,7 +411,8 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
                            void* ws, size_t ws_bytes, hipStream_t s) {
     DLSA_REQUIRE(pl && y && beta && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot logit pass: null argument");
-    const OhDesc& ds = pl->desc;
+    OhDesc ds = pl->desc;
+    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot logit pass: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -394,6 +442,7 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
 #ifdef DLSA_DEBUG_KNOBS
     { const char* e = getenv("DLSA_OH_DBG"); ds.dbg = e ? atoi(e) : 0; }
 #endif
+    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;

@@ -88,6 +88,33 @@ def test_onehot_passes_match_dense_oracle(api, orc, n, q, nlevels):
         assert plan.roles >= 2                                  # the 110 x 110 table gets a role of its own
 
 
+def test_onehot_passes_are_bit_reproducible(api):
+    """Ordered accumulation (the default): the waves of a workgroup add to its LDS tables in a fixed order, so the
+    gradient, the Hessian and a whole structured fit come out bit-identical run after run -- with skewed levels (many lanes
+    on one address), several table roles and enough rows for every workgroup to run many rounds."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(2026)
+    n, q, nlevels = 600000, 7, (11, 6, 20, 110, 110)
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, q, nlevels)
+    for t, L in enumerate(nlevels):                             # Zipf-like levels: hot cells
+        pr = 1.0 / np.arange(1, L + 1); pr /= pr.sum()
+        codes[:, t] = rng.choice(L, size=n, p=pr)
+    plan = _plan(api, p, desc, nl, level_col)
+    beta = rng.normal(size=p) * 0.2
+    y = (rng.random(n) < 0.4).astype(np.float64)
+    dn, dc, dy, db = dev(num), dev(codes), dev(y), dev(beta)
+    w0, g0, ll0 = engine.onehot_logit_pass(plan, dn, dc, dy, db)
+    H0 = engine.onehot_gram(plan, dn, dc, w0)
+    for _ in range(6):
+        w, g, ll = engine.onehot_logit_pass(plan, dn, dc, dy, db)
+        assert torch.equal(g, g0) and torch.equal(w, w0) and ll.item() == ll0.item()
+        assert torch.equal(engine.onehot_gram(plan, dn, dc, w0), H0)
+    offs = [0, n // 3, n]
+    r0 = engine.onehot_irls_fit(plan, dn, dc, dy, offs)
+    r1 = engine.onehot_irls_fit(plan, dn, dc, dy, offs)
+    assert torch.equal(r0["coef"], r1["coef"]) and torch.equal(r0["Sig_inv"], r1["Sig_inv"])
+
+
 def test_onehot_plan_refuses_tables_beyond_lds(api):
     from dlsa_amd import engine, _lib
     rng = np.random.default_rng(0)
