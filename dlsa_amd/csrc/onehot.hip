@@ -270,8 +270,9 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
 #pragma unroll
                 for (int b = a; b < OH_MAXD; ++b, ++k) hdd[k] = fma(wi * d[a], d[b], hdd[k]);
         }
-        // the row's LDS adds, one UNIT at a time: unit t < nd = the dense x level block of factor t (D adds), unit nd + q = pair table q
-        // (single-add units would level the systolic schedule below, but the run-time column select they need costs more: measured)
+        // the row's LDS adds, one UNIT at a time: unit t < nd = the dense x level block of factor t (D adds), unit nd + q = pair table q.
+        // Units own disjoint cells.  (Measured on config 4's shard, ordered Gram: these 20 units 2.65 ms; the dense blocks in
+        // halves 2.71; one fat unit per factor 3.62; single-add units with a run-time column select 3.30.)
         const int nd = dense ? ds.f : 0, nunit = nd + role.ntab;
         auto unit = [&](int u) {
             if (u < nd) {
