@@ -25,6 +25,7 @@ SIGNATURES = {
     "dlsa_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "dlsa_gram_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "dlsa_gram_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_gram_last_kernel": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_u64)]),
     "dlsa_logit_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dlsa_logit_pass_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_loglik_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),

@@ -10,6 +10,11 @@
 namespace dlsa {
 
 void set_error(const char* fmt, ...);
+// Which Gram kernel the calling thread's last Gram call dispatched (dlsa_gram_last_kernel), and where that launch's clock
+// probe lands in device memory: wave 0 of workgroup 0 stores its s_memtime delta (shader cycles from its first to its last
+// instruction) there; null for kernels without the probe.
+void note_gram_kernel(const void* clk_dev, hipStream_t stream, const char* fmt, ...);
+constexpr size_t kGramProbeBytes = 256;       // the probe's slot at the end of a Gram workspace
 
 #define DLSA_HIP_CHECK(expr)                                                              \
     do {                                                                                  \

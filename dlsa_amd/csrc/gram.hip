@@ -847,6 +847,8 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
 #undef DLSA_LAUNCH_GRAM
 #undef DLSA_LAUNCH_GRAM_NT
     DLSA_HIP_CHECK(hipGetLastError());
+    note_gram_kernel(nullptr, stream, "gram_kernel<%s,%s,%d,%d> (panel kernel%s)", sizeof(T) == 8 ? "double" : "float", w ? "true" : "false",
+                     mode, mode == 0 ? 0 : nt_list, nt_list ? ", tile-list plan" : "");
     gram_reduce_launch<T>((const T*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;

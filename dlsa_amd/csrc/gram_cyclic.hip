@@ -51,6 +51,7 @@ struct CycArgs {
     int64_t ldx, n, rows_per_slab;
     int p;                // columns loaded (even)
     int nslab;
+    unsigned long long* clk;   // clock probe: wave 0 of workgroup 0 stores its s_memtime delta (dlsa_gram_last_kernel)
 };
 
 #include "gram_cyclic_asm.inc"
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool probe = blockIdx.x == 0 && wave == 0;     // wave-uniform
+    const unsigned long long t_begin = probe ? __builtin_readcyclecounter() : 0ull;
     // block -> (slab, member): the four workgroups of a slab sit on one XCD (blocks b, b + 8, b + 16, b + 24 of a 32-block round)
     const int b = blockIdx.x, xcd = b % kNumXCD, jb = b / kNumXCD;
     const int slab = (jb / CYC_GROUP) * kNumXCD + xcd, member = jb % CYC_GROUP;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
             P[(int64_t)row * CYC_PP + col] = v;
         });
     }
+    if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
 }
 
 static int cyc_slabs(int64_t n, int64_t& rows_per_slab) {
@@ -295,7 +299,7 @@ bool gram_cyclic_eligible(const double* X, int64_t ldx, const double* w, int64_t
 
 size_t gram_cyclic_ws_bytes(int64_t n, int p) {
     int64_t rps;
-    return align_up((size_t)cyc_slabs(n, rps) * CYC_PP * CYC_PP * 8, 256);
+    return align_up((size_t)cyc_slabs(n, rps) * CYC_PP * CYC_PP * 8, 256) + kGramProbeBytes;
 }
 
 int gram_cyclic_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
@@ -304,7 +308,8 @@ int gram_cyclic_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
     a.X = X; a.w = w; a.partial = (double*)ws; a.ldx = ldx; a.n = n;
     a.p = p + (p & 1);       // odd p in an even row pitch: the pad column only reaches row / column p of H, which nobody reads
     a.nslab = cyc_slabs(n, a.rows_per_slab);
-    const size_t need = (size_t)a.nslab * CYC_PP * CYC_PP * 8;
+    const size_t need = align_up((size_t)a.nslab * CYC_PP * CYC_PP * 8, 256) + kGramProbeBytes;
+    a.clk = (unsigned long long*)((char*)ws + need - kGramProbeBytes);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -321,6 +326,7 @@ int gram_cyclic_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
         case 2: DLSA_LAUNCH_CYC(HW, 2); break; default: DLSA_LAUNCH_CYC(HW, 3); break; } } while (0)
     if (w) DLSA_LAUNCH_CYC_G(true);
     else DLSA_LAUNCH_CYC_G(false);
+    note_gram_kernel(a.clk, stream, "gram_cyclic_kernel<%s,%d>", w ? "true" : "false", g > 3 ? 3 : g);
 #undef DLSA_LAUNCH_CYC_G
 #undef DLSA_LAUNCH_CYC
     DLSA_HIP_CHECK(hipGetLastError());

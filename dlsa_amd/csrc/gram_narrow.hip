@@ -52,6 +52,7 @@ struct NarrowArgs {
     int64_t ldx, n, rows_per_slab;
     int p, PP;
     int dbg;              // DLSA_GRAM_DBG (timing experiments only, wrong results): 1 = no DMA after the prologue, 128 = no MFMAs
+    unsigned long long* clk;   // clock probe: wave 0 of workgroup 0 stores its s_memtime delta (dlsa_gram_last_kernel)
 };
 
 // LDS row pitch in elements: a k-step's fragment read is 4 rows x 16 columns of 8 bytes; 32 lanes (two rows) are
@@ -184,6 +185,8 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool probe = blockIdx.x == 0 && wave == 0;     // wave-uniform
+    const unsigned long long t_begin = probe ? __builtin_readcyclecounter() : 0ull;
     const int slab = blockIdx.x;
     const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
     const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     narrow_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+    if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
 }
 
 // p columns = NT full tiles + G tail groups of 4 (G <= 3; a fourth group makes a full tile)
@@ -327,7 +331,7 @@ size_t gram_narrow_ws_bytes(int64_t n, int p) {
     int64_t rps;
     const int ns = narrow_slabs(n, p, rps);
     const size_t PP = ((size_t)(p + 15) / 16 * 16 + 63) / 64 * 64;
-    return align_up((size_t)ns * PP * PP * 8, 256);
+    return align_up((size_t)ns * PP * PP * 8, 256) + kGramProbeBytes;
 }
 
 int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
@@ -341,7 +345,8 @@ int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
     gram_narrow_shape(a.p, nt, g);
     a.PP = ((p + 15) / 16 * 16 + 63) / 64 * 64;
     const int nslab = narrow_slabs(n, p, a.rows_per_slab);
-    const size_t need = (size_t)nslab * a.PP * a.PP * 8;
+    const size_t need = align_up((size_t)nslab * a.PP * a.PP * 8, 256) + kGramProbeBytes;
+    a.clk = (unsigned long long*)((char*)ws + need - kGramProbeBytes);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -360,6 +365,7 @@ int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
         default: DLSA_LAUNCH_NARROW(HW, 7, 0); break; } } while (0)
     if (w) DLSA_LAUNCH_NARROW_NT(true);
     else DLSA_LAUNCH_NARROW_NT(false);
+    note_gram_kernel(a.clk, stream, "gram_narrow_kernel<%s,%d,%d>", w ? "true" : "false", nt > 6 ? 7 : (nt < 3 ? 3 : nt), nt > 6 ? 0 : g);
 #undef DLSA_LAUNCH_NARROW_G
 #undef DLSA_LAUNCH_NARROW_NT
 #undef DLSA_LAUNCH_NARROW

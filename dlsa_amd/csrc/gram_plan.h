@@ -26,6 +26,7 @@ struct PlanArgs {
     int64_t ldx, n, rows_per_slab;
     int p;                // columns loaded (even)
     int PP;
+    unsigned long long* clk;   // clock probe: wave 0 of workgroup 0 stores its s_memtime delta (dlsa_gram_last_kernel)
 };
 
 // LDS row pitch in doubles: the tile columns rounded up to whole 32-column groups (a multiple of 256 bytes keeps the two rows

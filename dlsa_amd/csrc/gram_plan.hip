@@ -65,7 +65,7 @@ size_t gram_plan_ws_bytes(int64_t n, int p) {
     plan_shape(p + (p & 1), nt, g);
     int64_t rps;
     const int ns = plan_slabs(n, plan_group(nt), rps);
-    return align_up((size_t)ns * plan_pp(p) * plan_pp(p) * 8, 256) + align_up((size_t)ns * 16, 256) + 256;    // partials, pacing counts, ones
+    return align_up((size_t)ns * plan_pp(p) * plan_pp(p) * 8, 256) + align_up((size_t)ns * 16, 256) + 256 + kGramProbeBytes;    // partials, pacing counts, ones, clock probe
 }
 
 __global__ void plan_ones_kernel(double* ones) { ones[threadIdx.x] = 1.0; }
@@ -79,7 +79,8 @@ int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
     int nt, g;
     plan_shape(a.p, nt, g);
     const int nslab = plan_slabs(n, plan_group(nt), a.rows_per_slab);
-    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), prog = align_up((size_t)nslab * 16, 256), need = part + prog + 256;
+    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), prog = align_up((size_t)nslab * 16, 256), need = part + prog + 256 + kGramProbeBytes;
+    a.clk = (unsigned long long*)((char*)ws + part + prog + 256);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("gram: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -100,6 +101,7 @@ int gram_plan_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
     else rc = gram_plan_launch_33(a, nt, g, nslab, stream);
     if (rc) return rc;
     DLSA_HIP_CHECK(hipGetLastError());
+    note_gram_kernel(a.clk, stream, "gram_plan_kernel<true,%d,%d>%s", nt, g, w ? "" : " (unweighted: a streamed block of ones)");
     gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;

@@ -358,6 +358,7 @@ int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
     const int blocks = pl.nitems * nslab;
     if (w) hipLaunchKernelGGL((gram_wide_f32_kernel<true>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
     else hipLaunchKernelGGL((gram_wide_f32_kernel<false>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
+    note_gram_kernel(nullptr, stream, "gram_wide_f32_kernel<%s>", w ? "true" : "false");
     DLSA_HIP_CHECK(hipGetLastError());
     gram_reduce_launch<float>((const float*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());

@@ -175,6 +175,17 @@ def gram(X, w=None, out=None, accumulate=False):
     return H
 
 
+def gram_last_kernel(want_cycles=False):
+    """(name, shader cycles) of the Gram kernel this thread's last Gram launch dispatched (dlsa_gram_last_kernel):
+    which of the kernels of DESIGN.md section 4.1 ran, and -- want_cycles, which synchronises -- the s_memtime delta of
+    wave 0 of workgroup 0 (0 for kernels without the probe).  cycles / kernel time = the sustained shader clock."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(160)
+    cyc = ctypes.c_uint64(0)
+    check(lib.dlsa_gram_last_kernel(buf, 160, ctypes.byref(cyc) if want_cycles else None))
+    return buf.value.decode(), int(cyc.value)
+
+
 def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True, fit_intercept=False):
     """One fused pass: w = mu(1-mu), g = X'(y-mu), loglik.  Returns (w, g, loglik) tensors.  fit_intercept: the ones
     column is implicit -- beta and g have p + 1 entries, intercept first."""

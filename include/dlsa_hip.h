@@ -71,6 +71,13 @@ int dlsa_gram_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
                   double* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int dlsa_gram_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
                   float* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* Measurement hook (no reference counterpart; bench.py's `roofline.kernel` and `shader_clock_GHz`, and the tests that
+ * must know which kernel variant they exercised): name of the Gram kernel the calling thread's last Gram launch
+ * dispatched, e.g. "gram_cyclic_kernel<true,1>", and -- nullable -- the shader cycles wave 0 of workgroup 0 spent in
+ * that launch (its s_memtime delta; 0 for kernels without the probe).  Asking for the cycles waits for the launch's
+ * stream and reads 8 bytes back.  cycles / kernel time = the clock the chip held (DVFS), which is what turns a
+ * box-to-box difference in rows/s into an attributable one. */
+int dlsa_gram_last_kernel(char* name, int len, uint64_t* shader_cycles);
 
 /* ---- K1/K2: fused logit pass over the rows (dlsa/models.py:113-114 inner products) ----
  * eta = X beta, mu = sigmoid(eta); writes w_out[i] = mu(1-mu) (nullable), g = X'(y-mu)

@@ -116,10 +116,9 @@ def test_predicted_convergence_agrees_with_confirmed_run_at_config3_scale(eng, m
     """the predicted-convergence exit skips the confirming logit pass.  At BASELINE config 3's per-GPU
     size (2.5e7 x 500) the result must agree with the confirmed run (DLSA_IRLS_PREDICT=0) to 1e-11 -- coef, Sig_inv and
     Sig_invMcoef -- for one shard-sized partition and for 25 partitions of 1e6 rows (logistic_dlsa.py:170)."""
-    free, _ = torch.cuda.mem_get_info()
+    from conftest import need_hbm
     n, p = 25_000_000, 500
-    if free < 130e9:
-        n = int(free * 0.6 / (p * 8))
+    need_hbm(115e9)            # asserted, never shrunk
     X, y = eng.synth(20260101, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
     for K in (1, 25):
         offs = [int(n * k / K) for k in range(K + 1)]

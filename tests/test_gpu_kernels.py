@@ -481,10 +481,9 @@ def test_full_size_properties_p500(eng):
     """BASELINE config 3's per-GPU shard (2.5e7 x 500 fp64 = 100 GB): size-independent checks.
     linearity over row blocks, exact symmetry, and trace(H) = sum_i w_i |x_i|^2 computed by an
     independent (torch elementwise) path in chunks."""
-    free, _ = torch.cuda.mem_get_info()
+    from conftest import need_hbm
     n, p = 25_000_000, 500
-    if free < 130e9:
-        n = int(free * 0.6 / (p * 8))
+    need_hbm(115e9)            # the 100 GB shard + w + chunk temporaries: asserted, never shrunk
     X, _ = eng.synth(20260101, 0, n, p, kind=eng.SYNTH_GAUSSIAN, labels=False)
     w = torch.rand(n, dtype=torch.float64, device="cuda") * 0.25
     H = eng.gram(X, w)
