@@ -51,6 +51,11 @@ def parse(argv=None):
     ap.add_argument("--e2e", action="store_true",
                     help="also time the end-to-end fit (IRLS + combine + LARS); off by default so that every\n"
                          "gram_kernel launch of the default command has the benchmark's size (rocprof averages)")
+    ap.add_argument("--scaling", choices=("weak", "strong", "both"), default="both",
+                    help="N > 1: `value` is always the weak-scaling figure (fixed rows per GPU); `strong` adds a leg with the\n"
+                         "TOTAL rows fixed at --rows-per-gpu, split evenly over the ranks (SURVEY 8(d) scaling report)")
+    ap.add_argument("--e2e-partitions", type=int, default=25,
+                    help="partitions per rank of the end-to-end fit (25 x 1e6 rows: logistic_dlsa.py:170 on config 3's shard)")
     ap.add_argument("--cpu-rows-per-partition", type=int, default=0, help="0 = sized by oracle/cpu_baseline.py")
     ap.add_argument("--cpu-gram-rows", type=int, default=400_000)
     return ap.parse_args(argv)
@@ -144,9 +149,17 @@ def worker(args):
     # the GPU, and it does not share the host with the GPU timing below
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import cpu_baseline
-        cpu = cpu_baseline.run(p, args.seed, rows_per_partition=args.cpu_rows_per_partition or None,
-                               gram_rows=args.cpu_gram_rows)
+        # a REPORTED reference point: its failure (a worker, the pool's barrier, a missing gcc / liboracle_synth, host memory)
+        # must not cost the primary GPU line
+        try:
+            from oracle import cpu_baseline
+            cpu = cpu_baseline.run(p, args.seed, rows_per_partition=args.cpu_rows_per_partition or None,
+                                   gram_rows=args.cpu_gram_rows)
+        except BaseException as e:      # incl. SystemExit / BrokenBarrierError from the pool
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            print("[bench] cpu_baseline failed: %r" % (e,), file=sys.stderr)
+            cpu = {"error": repr(e)}
 
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -197,33 +210,66 @@ def worker(args):
     msg = torch.zeros(p * p + 2 * p, dtype=torch.float64, device="cuda")
     H = msg[: p * p].view(p, p)
     mk = lambda: torch.cuda.Event(enable_timing=True)
-    ev = [(mk(), mk(), mk()) for _ in range(args.steps)]
 
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        engine.gram(X, w, out=H)
-        if i is not None:
-            ev[i][1].record()
+    def timed_steps(Xs, ws, steps, warmup):
+        """W untimed + K timed steps of (Gram pass over Xs + the all-reduce), bracketed by barrier + synchronize on both
+        sides; returns (max-over-ranks wall seconds, mean Gram ms, mean all-reduce ms, this rank's last Gram ms)."""
+        ev = [(mk(), mk(), mk()) for _ in range(steps)]
+
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record()
+            engine.gram(Xs, ws, out=H)
+            if i is not None:
+                ev[i][1].record()
+            if dist is not None:
+                dist.all_reduce(msg)
+            if i is not None:
+                ev[i][2].record()
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        el = time.perf_counter() - t0
+        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
         if dist is not None:
-            dist.all_reduce(msg)
-        if i is not None:
-            ev[i][2].record()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return (float(tmax.item()), sum(a.elapsed_time(b) for a, b, _ in ev) / steps,
+                sum(b.elapsed_time(c) for _, b, c in ev) / steps, ev[-1][0].elapsed_time(ev[-1][1]))
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
-    comm_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
+    def per_rank(v):
+        """min / max / mean over the ranks of a per-rank scalar (skew between the GPUs)."""
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        if dist is None:
+            return {"min": v, "max": v, "mean": v}
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        vals = [float(x.item()) for x in allv]
+        return {"min": min(vals), "max": max(vals), "mean": sum(vals) / len(vals), "per_rank": vals}
+
+    elapsed, kern_ms, comm_ms, last_ms = timed_steps(X, w, args.steps, args.warmup)
+    # what the library dispatched, and the clock the chip held in the last timed launch: shader cycles of wave 0 of
+    # workgroup 0 (s_memtime delta written by the kernel) / that launch's HIP-event time
+    kernel_name, cycles = engine.gram_last_kernel(want_cycles=True)
+    clock_ghz = cycles / (last_ms * 1e-3) / 1e9 if cycles else None
+    kern_ranks = per_rank(kern_ms)
+    clock_ranks = per_rank(clock_ghz or 0.0)
+
+    # ---- strong scaling leg (N > 1): the SAME total rows as one GPU's shard, split evenly over the ranks
+    strong = None
+    if dist is not None and args.scaling in ("strong", "both"):
+        Rs = R // world
+        s_el, s_kern, s_comm, _ = timed_steps(X[:Rs], w[:Rs], args.steps, args.warmup)
+        s_name, _ = engine.gram_last_kernel()
+        strong = {"scaling": "strong", "total_rows": Rs * world, "rows_per_gpu": Rs, "value": Rs * world * args.steps / s_el,
+                  "unit": "rows/s", "ms_per_step": s_el / args.steps * 1e3, "kernel_ms": per_rank(s_kern),
+                  "allreduce_ms_in_step": s_comm, "kernel": s_name,
+                  "note": "every rank takes the first total_rows / N rows of its own resident shard (same distribution, "
+                          "same seeded stream); speed-up vs N=1 = value / the N=1 run's value"}
 
     # ---- the collective on its own (all ranks): 20 back-to-back all-reduces of the message
     allreduce = None
@@ -265,17 +311,23 @@ def worker(args):
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TF, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": R * bytes_row,
-                         "kernel": "dlsa::gram_cyclic_kernel<true,1> (+gram_reduce_kernel, ~0.03 ms)" if 481 <= p <= 508 else
-                                   "dlsa::gram_kernel / gram_narrow_kernel (+gram_reduce_kernel)", "kernel_ms": kern_ms,
+                         # what the library dispatched in the timed launches (dlsa_gram_last_kernel), not a guess from p
+                         "kernel": "dlsa::%s (+gram_reduce_kernel, ~0.03 ms)" % kernel_name, "kernel_ms": kern_ms,
+                         "kernel_ms_over_ranks": kern_ranks,
+                         # the clock the chip held (DVFS): shader cycles of wave 0 of workgroup 0 in the last timed launch /
+                         # that launch's HIP-event time; the peak assumes 2.4 GHz, so frac <= clock / 2.4
+                         "shader_clock_GHz": clock_ghz, "shader_clock_GHz_over_ranks": clock_ranks if world > 1 else None,
+                         "frac_at_sustained_clock": (ach_tf / (FP64_MFMA_PEAK_TF * clock_ghz / 2.4)) if clock_ghz else None,
                          "algorithmic_flops_per_row": flops_row, "algorithmic_bytes_per_row": bytes_row,
                          "hbm_GBps_algorithmic": R * bytes_row / (kern_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": R * bytes_row / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "allreduce": allreduce,
+            "strong_scaling": strong,
         }
 
-    # ---- extras (rank 0, N=1 only): HBM-bound logit pass, end-to-end fit
+    # ---- extras: the HBM-bound logit pass (rank 0, N = 1), the end-to-end fit (--e2e; every rank takes part when N > 1)
+    extra = {"gen_seconds": t_gen}
     if rank == 0 and world == 1 and not args.no_extra:
-        extra = {"gen_seconds": t_gen}
         e0, e1 = mk(), mk()
         engine.logit_pass(X, y, beta_true)
         torch.cuda.synchronize()
@@ -288,22 +340,40 @@ def worker(args):
         extra["logit_pass"] = {"ms": ms, "rows_per_s": R / (ms * 1e-3),
                                "hbm_GBps": R * 8 * (p + 2) / (ms * 1e-3) / 1e9,
                                "hbm_frac_of_8TBps": R * 8 * (p + 2) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if args.e2e:
-            t1 = time.perf_counter()
-            fit = engine.irls_fit(X, y, [0, R])
-            msgv = engine.sum_blocks(fit["coef"], fit["Sig_invMcoef"], fit["Sig_inv"])
-            S = msgv[: p * p].view(p, p)
-            theta = engine.spd_solve(S, msgv[p * p: p * p + p])
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            path = engine.lars_path(S, theta, False, float(R))
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            extra["end_to_end_fit"] = {"irls_iters": fit["n_iter"][0], "status": fit["status"][0],
-                                       "map_plus_combine_s": t2 - t1, "lars_s": t3 - t2,
-                                       "rows_per_s_whole_fit": R / (t3 - t1),
-                                       "theta_err_vs_truth_linf": float((theta - beta_true).abs().max())}
-            del fit, path
+    if args.e2e and not args.no_extra:
+        # The whole path on every rank's shard (the C3 geometry of logistic_dlsa.py:170: partitions of 1e6 rows): per-partition
+        # exact-MLE fits + Hessians -> local block sum -> ONE all-reduce of p^2 + 2p + 1 doubles -> WLS solve + LARS on every
+        # rank (redundant: cheaper than a broadcast).  Wall time = max over ranks, barrier-bracketed.
+        Kp = max(1, min(args.e2e_partitions, R // 1000))
+        offs = [int(R * k / Kp) for k in range(Kp + 1)]
+        barrier()
+        t1 = time.perf_counter()
+        fit = engine.irls_fit(X, y, offs)
+        msgv = torch.cat([engine.sum_blocks(fit["coef"], fit["Sig_invMcoef"], fit["Sig_inv"]),
+                          torch.tensor([float(Kp)], dtype=torch.float64, device="cuda")])
+        torch.cuda.synchronize()
+        t_map = time.perf_counter()
+        if dist is not None:
+            dist.all_reduce(msgv)
+        S = msgv[: p * p].view(p, p)
+        theta, wls_rank = engine.wls_solve(S, msgv[p * p: p * p + p].contiguous())
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        path = engine.lars_path(S, theta, False, float(R * world))
+        barrier()
+        t3 = time.perf_counter()
+        tt = torch.tensor([t_map - t1, t2 - t_map, t3 - t2, t3 - t1], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = [float(v) for v in tt.tolist()]
+        extra["end_to_end_fit"] = {"ranks": world, "partitions_per_rank": Kp, "partitions_total": int(round(float(msgv[-1].item()))),
+                                   "irls_iters_rank0": fit["n_iter"], "status_ok": all(v == 0 for v in fit["status"]),
+                                   "map_s": tt[0], "reduce_plus_wls_s": tt[1], "lars_s": tt[2], "total_s": tt[3],
+                                   "rows_per_s_whole_fit": R * world / tt[3], "wls_rank": wls_rank,
+                                   "lars_steps": int(path["beta"].shape[0]) - 1,
+                                   "theta_err_vs_truth_linf": float((theta - beta_true).abs().max())}
+        del fit, path
+    if rank == 0:
         out["extra"] = extra
     if rank == 0:
         out["cpu_baseline"] = cpu

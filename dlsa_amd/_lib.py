@@ -22,9 +22,15 @@ SIGNATURES = {
     "dlsa_last_error": (c_int, [ctypes.c_char_p, c_int]),
     "dlsa_synth_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dlsa_synth_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dlsa_synth_response_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_dbl, c_vp, c_vp]),
+    "dlsa_synth_response_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_dbl, c_vp, c_vp]),
     "dlsa_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "dlsa_gram_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "dlsa_gram_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_gram_f32_acc64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_xtv_stats_workspace_bytes": (c_sz, [c_int, c_int]),
+    "dlsa_xtv_stats_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "dlsa_xtv_stats_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
     "dlsa_gram_last_kernel": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_u64)]),
     "dlsa_logit_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dlsa_logit_pass_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

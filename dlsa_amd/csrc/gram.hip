@@ -454,8 +454,10 @@ __global__ __launch_bounds__(GRAM_THREADS, DLSA_GRAM_OCC) void gram_kernel(GramA
 // (bit-reproducible).  With one thread per element the 512 slabs of the narrow kernel were 128 dependent loads deep: 62 us
 // at p = 100, 3 % of the whole Gram of 1e7 rows and a third of a 1e6-row partition's.
 constexpr int RED_J = 16, RED_K = 16;
-template <typename T>
-__global__ __launch_bounds__(RED_J * RED_K) void gram_reduce_kernel(const T* __restrict__ partial, int nslab, int PP, int p,
+// TO = the output / summation type: the slab partials' own type, or double for fp32 partials whose sum goes on into an
+// fp64 accumulator (dlsa_gram_f32_acc64: a streaming map step adds chunk after chunk without fp32 cancellation across chunks)
+template <typename TP, typename T>
+__global__ __launch_bounds__(RED_J * RED_K) void gram_reduce_kernel(const TP* __restrict__ partial, int nslab, int PP, int p,
                                                                       T* __restrict__ H, int64_t ldh, int accumulate) {
     __shared__ T part[RED_K][RED_J + 1];
     const int jl = threadIdx.x % RED_J, kg = threadIdx.x / RED_J;
@@ -465,14 +467,14 @@ __global__ __launch_bounds__(RED_J * RED_K) void gram_reduce_kernel(const T* __r
     const bool live = j < p && j >= i;
     T s0 = T(0), s1 = T(0);
     if (live) {
-        const T* src = partial + (int64_t)i * PP + j;
+        const TP* src = partial + (int64_t)i * PP + j;
         const int64_t stride = (int64_t)PP * PP;
         int k = kg;
         for (; k + RED_K < nslab; k += 2 * RED_K) {
-            s0 += src[k * stride];
-            s1 += src[(k + RED_K) * stride];
+            s0 += (T)src[k * stride];
+            s1 += (T)src[(k + RED_K) * stride];
         }
-        if (k < nslab) s0 += src[k * stride];
+        if (k < nslab) s0 += (T)src[k * stride];
     }
     part[kg][jl] = s0 + s1;
     __syncthreads();
@@ -492,7 +494,11 @@ __global__ __launch_bounds__(RED_J * RED_K) void gram_reduce_kernel(const T* __r
 template <typename T>
 void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream) {
     dim3 rg((p + RED_J - 1) / RED_J, p);
-    hipLaunchKernelGGL((gram_reduce_kernel<T>), rg, dim3(RED_J * RED_K), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
+    hipLaunchKernelGGL((gram_reduce_kernel<T, T>), rg, dim3(RED_J * RED_K), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
+}
+void gram_reduce_launch_f32_to_f64(const float* partial, int nslab, int PP, int p, double* H, int64_t ldh, int accumulate, hipStream_t stream) {
+    dim3 rg((p + RED_J - 1) / RED_J, p);
+    hipLaunchKernelGGL((gram_reduce_kernel<float, double>), rg, dim3(RED_J * RED_K), 0, stream, partial, nslab, PP, p, H, ldh, accumulate);
 }
 template void gram_reduce_launch<double>(const double*, int, int, int, double*, int64_t, int, hipStream_t);
 template void gram_reduce_launch<float>(const float*, int, int, int, float*, int64_t, int, hipStream_t);
@@ -739,7 +745,7 @@ bool gram_wide_f32_shape_ok(int64_t n, int p);
 bool gram_wide_f32_eligible(const float* X, int64_t ldx, const float* w, int64_t n, int p);
 size_t gram_wide_f32_ws_bytes(int64_t n, int p);
 int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H, int64_t ldh,
-                  int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t stream, double* H64 = nullptr);
 
 // gram_narrow.hip: the row-split fp64 kernel for 49 <= p <= 112
 bool gram_narrow_shape_ok(int64_t n, int p);
@@ -779,15 +785,16 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     return bytes;
 }
 
+// H64 (fp32 rows only): the slab partials are summed in fp64 and go to / into this fp64 matrix instead of H
 template <typename T>
 int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64_t ldh,
-              int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
-    DLSA_REQUIRE((X || n == 0) && H, "gram: null X or H");      // an empty row block (n == 0) gives H = 0
+              int accumulate, void* ws, size_t ws_bytes, hipStream_t stream, double* H64 = nullptr) {
+    DLSA_REQUIRE((X || n == 0) && (H || H64), "gram: null X or H");      // an empty row block (n == 0) gives H = 0
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p && ldh >= p, "gram: bad shape n=%lld p=%d ldx=%lld ldh=%lld",
                  (long long)n, p, (long long)ldx, (long long)ldh);
     if constexpr (sizeof(T) == 4) {
         if (gram_wide_f32_eligible(X, ldx, w, n, p))
-            return gram_wide_f32(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
+            return gram_wide_f32(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream, H64);
     } else {
         if (gram_narrow_eligible(X, ldx, w, n, p))
             return gram_narrow_f64(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, stream);
@@ -849,13 +856,18 @@ int gram_impl(const T* X, int64_t ldx, const T* w, int64_t n, int p, T* H, int64
     DLSA_HIP_CHECK(hipGetLastError());
     note_gram_kernel(nullptr, stream, "gram_kernel<%s,%s,%d,%d> (panel kernel%s)", sizeof(T) == 8 ? "double" : "float", w ? "true" : "false",
                      mode, mode == 0 ? 0 : nt_list, nt_list ? ", tile-list plan" : "");
-    gram_reduce_launch<T>((const T*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
+    if constexpr (sizeof(T) == 4) {
+        if (H64) gram_reduce_launch_f32_to_f64((const float*)ws, nslab, pl.PP, p, H64, ldh, accumulate, stream);
+        else gram_reduce_launch<T>((const T*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
+    } else {
+        gram_reduce_launch<T>((const T*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
+    }
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
 
-template int gram_impl<double>(const double*, int64_t, const double*, int64_t, int, double*, int64_t, int, void*, size_t, hipStream_t);
-template int gram_impl<float>(const float*, int64_t, const float*, int64_t, int, float*, int64_t, int, void*, size_t, hipStream_t);
+template int gram_impl<double>(const double*, int64_t, const double*, int64_t, int, double*, int64_t, int, void*, size_t, hipStream_t, double*);
+template int gram_impl<float>(const float*, int64_t, const float*, int64_t, int, float*, int64_t, int, void*, size_t, hipStream_t, double*);
 
 size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes) { return gram_ws_bytes(n, p, elem_bytes); }
 
@@ -943,6 +955,12 @@ int dlsa_gram_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
 int dlsa_gram_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H,
                   int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     return dlsa::gram_impl<float>(X, ldx, w, n, p, H, ldh, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int dlsa_gram_f32_acc64(const float* X, int64_t ldx, const float* w, int64_t n, int p, double* H64,
+                        int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    DLSA_REQUIRE(H64, "gram_f32_acc64: null H");
+    return dlsa::gram_impl<float>(X, ldx, w, n, p, nullptr, ldh, accumulate, ws, ws_bytes, (hipStream_t)stream, H64);
 }
 
 }  // extern "C"

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void gram_wide_f32_kernel(WideArgs a) 
 
 template <typename T>
 void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream);   // gram.hip
+void gram_reduce_launch_f32_to_f64(const float* partial, int nslab, int PP, int p, double* H, int64_t ldh, int accumulate, hipStream_t stream);
 
 // -------------------------------------------------------------------------------------------------
 // host: plan
@@ -339,7 +340,7 @@ size_t gram_wide_f32_ws_bytes(int64_t n, int p) {
 }
 
 int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H, int64_t ldh,
-                  int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t stream, double* H64) {
     WidePlan pl;
     int rc = get_wide_plan(p, pl);
     if (rc) return rc;
@@ -360,7 +361,8 @@ int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
     else hipLaunchKernelGGL((gram_wide_f32_kernel<false>), dim3(blocks), dim3(WTHREADS), 0, stream, a);
     note_gram_kernel(nullptr, stream, "gram_wide_f32_kernel<%s>", w ? "true" : "false");
     DLSA_HIP_CHECK(hipGetLastError());
-    gram_reduce_launch<float>((const float*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
+    if (H64) gram_reduce_launch_f32_to_f64((const float*)ws, nslab, pl.PP, p, H64, ldh, accumulate, stream);
+    else gram_reduce_launch<float>((const float*)ws, nslab, pl.PP, p, H, ldh, accumulate, stream);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

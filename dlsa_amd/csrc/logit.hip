@@ -694,6 +694,170 @@ __global__ __launch_bounds__(1024) void xtv_f32_finish_kernel(const double* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming linear-model statistics (config 5's map step, chunk by chunk): ONE read of X gives, in fp64 whatever the rows'
+// type,  g = X'v,  c = X'1 (the column sums: the intercept's border of [1 | X]'[1 | X], dlsa/models.py:121-122 -- the ones
+// column stays implicit),  v'v  and  sum v;  accumulate != 0 ADDS them to what the outputs hold (the previous chunks).
+// A wave owns two rows per trip (two sets of loads in flight); lane l holds columns CW c + E l + {0..E-1} (16-byte loads).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct XtvStatsArgs {
+    const T* X;
+    const T* v;
+    double* part;      // [nblocks][2 * NC * CW + 2]: g | colsum | v'v | sum v
+    int64_t ldx, n;
+    int p, want_colsum;
+};
+
+template <typename T, int NC, bool VEC>
+__global__ __launch_bounds__(LOGIT_THREADS) void xtv_stats_kernel(XtvStatsArgs<T> a) {
+    constexpr int E = 16 / (int)sizeof(T), CW = 64 * E;          // elements per lane and load, columns per wave pass
+    extern __shared__ double red_stats[];                        // [2 * NC * CW + 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double g[NC][E], cs[NC][E];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < E; ++e) { g[c][e] = 0.0; cs[c][e] = 0.0; }
+    double vv = 0.0, sv = 0.0;
+    auto load_row = [&](int64_t r, T (&x)[NC][E]) {
+        const T* src = a.X + r * a.ldx + E * lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * CW + E * lane;
+            if (VEC && col + E - 1 < a.p) {
+                typedef T vecT __attribute__((ext_vector_type(E)));
+                const vecT q = *reinterpret_cast<const vecT*>(src + c * CW);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[c][e] = q[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[c][e] = (col + e < a.p) ? src[c * CW + e] : T(0);
+            }
+        }
+    };
+    auto add_row = [&](double yv, const T (&x)[NC][E]) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                g[c][e] = fma(yv, (double)x[c][e], g[c][e]);
+                if (a.want_colsum) cs[c][e] += (double)x[c][e];
+            }
+    };
+    const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES * 2;
+    for (int64_t r = ((int64_t)blockIdx.x * LOGIT_WAVES + wave) * 2; r < a.n; r += stride) {
+        T x0[NC][E], x1[NC][E];
+        const bool two = r + 1 < a.n;
+        load_row(r, x0);
+        load_row(two ? r + 1 : r, x1);
+        const double y0 = (double)a.v[r], y1 = two ? (double)a.v[r + 1] : 0.0;
+        if (lane == 0) { vv = fma(y0, y0, vv); vv = fma(y1, y1, vv); sv += y0 + y1; }
+        add_row(y0, x0);
+        if (two) add_row(y1, x1);
+    }
+    vv = wave_allreduce_sum(vv);
+    sv = wave_allreduce_sum(sv);
+    constexpr int NG = NC * CW;
+    for (int wv = 0; wv < LOGIT_WAVES; ++wv) {                   // the waves meet in a fixed order: bit-reproducible
+        if (wave == wv) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int k = c * CW + E * lane + e;
+                    if (wv == 0) { red_stats[k] = g[c][e]; red_stats[NG + k] = cs[c][e]; }
+                    else { red_stats[k] += g[c][e]; red_stats[NG + k] += cs[c][e]; }
+                }
+            if (lane == 0) {
+                if (wv == 0) { red_stats[2 * NG] = vv; red_stats[2 * NG + 1] = sv; }
+                else { red_stats[2 * NG] += vv; red_stats[2 * NG + 1] += sv; }
+            }
+        }
+        __syncthreads();
+    }
+    double* gp = a.part + (int64_t)blockIdx.x * (2 * NG + 2);
+    for (int k = tid; k < 2 * NG + 2; k += LOGIT_THREADS) gp[k] = red_stats[k];
+}
+
+// sums the per-block partials in a fixed order; out = g [p] | colsum [p] (nullable) | stats[0] = v'v, stats[1] = sum v
+__global__ __launch_bounds__(1024) void xtv_stats_finish_kernel(const double* __restrict__ part, int nblocks, int pitch, int ng, int p,
+                                                                double* __restrict__ g, double* __restrict__ colsum,
+                                                                double* __restrict__ stats, int accumulate) {
+    __shared__ double red[16][65];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int which = blockIdx.y;                                // 0: g, 1: colsum, 2: the two scalars
+    if (which == 1 && !colsum) return;
+    int col = blockIdx.x * 64 + cx, src_col;
+    bool live;
+    if (which < 2) { live = col < p; src_col = which * ng + col; }
+    else { if (blockIdx.x) return; live = cx < 2; src_col = 2 * ng + cx; }
+    double s = 0.0;
+    if (live)
+        for (int b = ry; b < nblocks; b += 16) s += part[(int64_t)b * pitch + src_col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && live) {
+        double t = red[0][cx];
+        for (int k = 1; k < 16; ++k) t += red[k][cx];
+        double* dst = which == 0 ? g + col : which == 1 ? colsum + col : stats + cx;
+        *dst = accumulate ? *dst + t : t;
+    }
+}
+
+template <typename T>
+static size_t xtv_stats_ws_bytes(int p) {
+    constexpr int CW = 64 * (16 / (int)sizeof(T));
+    int nc = 1;
+    while (nc * CW < p) nc *= 2;
+    return align_up((size_t)LOGIT_MAX_BLOCKS * (2 * nc * CW + 2) * sizeof(double), 256);
+}
+
+template <typename T>
+int xtv_stats_impl(const T* X, int64_t ldx, const T* v, int64_t n, int p, double* g, double* colsum, double* stats,
+                   int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    constexpr int E = 16 / (int)sizeof(T), CW = 64 * E;
+    DLSA_REQUIRE((X || n == 0) && (v || n == 0) && g && stats, "xtv_stats: null argument");
+    DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p, "xtv_stats: bad shape n=%lld p=%d ldx=%lld", (long long)n, p, (long long)ldx);
+    const size_t need = xtv_stats_ws_bytes<T>(p);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("xtv_stats: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    int nc = 1;
+    while (nc * CW < p) nc *= 2;
+    XtvStatsArgs<T> a;
+    a.X = X; a.v = v; a.part = (double*)ws; a.ldx = ldx; a.n = n; a.p = p; a.want_colsum = colsum ? 1 : 0;
+    const bool vec = (ldx % E == 0) && (((uintptr_t)X & 15) == 0);
+    const int64_t blocks64 = (n + LOGIT_WAVES * 32 - 1) / (LOGIT_WAVES * 32);
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(blocks64, 1), LOGIT_MAX_BLOCKS);
+    const size_t shm = (size_t)(2 * nc * CW + 2) * sizeof(double);
+#define DLSA_XTV_STATS(NCV) do { \
+        if (shm > 48 * 1024) { \
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(xtv_stats_kernel<T, NCV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(xtv_stats_kernel<T, NCV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        } \
+        if (vec) hipLaunchKernelGGL((xtv_stats_kernel<T, NCV, true>), dim3(blocks), dim3(LOGIT_THREADS), shm, s, a); \
+        else hipLaunchKernelGGL((xtv_stats_kernel<T, NCV, false>), dim3(blocks), dim3(LOGIT_THREADS), shm, s, a); } while (0)
+    if (n > 0) {
+        switch (nc) {
+            case 1: DLSA_XTV_STATS(1); break;
+            case 2: DLSA_XTV_STATS(2); break;
+            case 4: DLSA_XTV_STATS(4); break;
+            case 8: DLSA_XTV_STATS(8); break;
+            default:
+                if constexpr (sizeof(T) == 8) { DLSA_XTV_STATS(16); }
+                else { set_error("xtv_stats: p too wide"); return DLSA_ERR_INVALID; }
+        }
+    }
+#undef DLSA_XTV_STATS
+    DLSA_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(xtv_stats_finish_kernel, dim3((p + 63) / 64, 3), dim3(1024), 0, s, (const double*)ws, n > 0 ? blocks : 0,
+                       2 * nc * CW + 2, nc * CW, p, g, colsum, stats, accumulate);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
 template <int NC>
 static void launch_xtv_f32(const XtvF32Args& a, bool vec, int blocks, hipStream_t s) {
     if (vec) hipLaunchKernelGGL((xtv_f32_kernel<NC, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
@@ -851,6 +1015,19 @@ int dlsa_xtv_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, 
                        (const double*)a.vvpart, blocks, nc * 256, p, g, vv);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
+}
+
+size_t dlsa_xtv_stats_workspace_bytes(int p, int elem_bytes) {
+    if (p <= 0 || p > 2048 || (elem_bytes != 4 && elem_bytes != 8)) return 0;
+    return elem_bytes == 8 ? dlsa::xtv_stats_ws_bytes<double>(p) : dlsa::xtv_stats_ws_bytes<float>(p);
+}
+int dlsa_xtv_stats_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* colsum,
+                       double* stats, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return dlsa::xtv_stats_impl<double>(X, ldx, v, n, p, g, colsum, stats, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+int dlsa_xtv_stats_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, double* g, double* colsum,
+                       double* stats, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return dlsa::xtv_stats_impl<float>(X, ldx, v, n, p, g, colsum, stats, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t dlsa_logit_workspace_bytes(int64_t n, int p) {

@@ -84,6 +84,48 @@ __global__ void synth_labels_kernel(unsigned long long seed, int64_t row0, int64
     }
 }
 
+// Linear-model response (y = X beta + N(0, sigma^2)): y_i = x_i . beta + sigma z_i, z_i standard normal
+// by Box-Muller on the uniforms of counter (i_lo, i_hi, 0, 2), key (seed+1, 0).  One wave per row; X already holds the features.
+template <typename T>
+__global__ void synth_response_kernel(unsigned long long seed, int64_t row0, int64_t n, int pcols,
+                                      const T* __restrict__ X, int64_t ldx, const T* __restrict__ beta,
+                                      int p_true_ones, int first_col, double sigma, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    double s = 0.0;
+    const T* row = X + r * ldx;
+    if (beta) {
+        for (int k = lane; k < pcols; k += 64) s += (double)row[k] * (double)beta[k];
+    } else {
+        for (int k = lane; k < p_true_ones; k += 64) s += (double)row[first_col + k];
+    }
+    s = wave_allreduce_sum(s);
+    if (lane == 0) {
+        const unsigned long long gi = (unsigned long long)(row0 + r);
+        u4 c; c.x = (unsigned)gi; c.y = (unsigned)(gi >> 32); c.z = 0u; c.w = 2u;
+        const u4 o = philox4x32_10(c, (unsigned)(seed + 1ull), 0u);
+        const double ua = u53(o.x, o.y), ub = u53(o.z, o.w);
+        const double z = sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586 * ub);
+        y[r] = (T)(s + sigma * z);
+    }
+}
+
+template <typename T>
+int synth_response_impl(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const T* X, int64_t ldx,
+                        const T* beta_true, double sigma, T* y, hipStream_t s) {
+    DLSA_REQUIRE(X && y, "synth_response: null X or y");
+    DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p + (ones_col ? 1 : 0) && sigma >= 0.0, "synth_response: bad shape n=%lld p=%d ldx=%lld",
+                 (long long)n, p, (long long)ldx);
+    if (n == 0) return DLSA_OK;
+    const int64_t lb = (n + 3) / 4;
+    DLSA_REQUIRE(lb < (1ll << 31), "synth_response: too many rows for one launch; generate in chunks");
+    hipLaunchKernelGGL((synth_response_kernel<T>), dim3((unsigned)lb), dim3(256), 0, s, (unsigned long long)seed, row0, n,
+                       p + (ones_col ? 1 : 0), X, ldx, beta_true, (int)(p * 0.4), ones_col ? 1 : 0, sigma, y);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
 template <typename T>
 int synth_impl(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col, T* X, int64_t ldx,
                T* y, const T* beta_true, hipStream_t s) {
@@ -120,5 +162,13 @@ int dlsa_synth_f64(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int 
 int dlsa_synth_f32(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col, float* X,
                    int64_t ldx, float* y, const float* beta_true, void* stream) {
     return dlsa::synth_impl<float>(seed, row0, n, p, kind, ones_col, X, ldx, y, beta_true, (hipStream_t)stream);
+}
+int dlsa_synth_response_f64(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const double* X, int64_t ldx,
+                            const double* beta_true, double sigma, double* y, void* stream) {
+    return dlsa::synth_response_impl<double>(seed, row0, n, p, ones_col, X, ldx, beta_true, sigma, y, (hipStream_t)stream);
+}
+int dlsa_synth_response_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const float* X, int64_t ldx,
+                            const float* beta_true, double sigma, float* y, void* stream) {
+    return dlsa::synth_response_impl<float>(seed, row0, n, p, ones_col, X, ldx, beta_true, sigma, y, (hipStream_t)stream);
 }
 }

@@ -63,9 +63,18 @@ def unpack_message(msg, p):
     return (msg[: p * p].view(p, p), msg[p * p: p * p + p], msg[p * p + p: p * p + 2 * p], float(msg[-1].item()))
 
 
-def allreduce_message(msg):
-    """The algorithm's one round of communication (in place; identity when not distributed)."""
-    if is_distributed():
+def allreduce_message(msg, comm=None):
+    """The algorithm's one round of communication (in place; identity when not distributed).
+
+    ONE reduce path with two carriers of the same RCCL collective: `comm` = an `engine.RcclComm` (the C ABI's
+    dlsa_allreduce_f64, for hosts that do not run torch.distributed), else the initialised torch.distributed group
+    (backend "nccl" IS RCCL; gloo in the CPU tests).  Both are a sum all-reduce of the same contiguous fp64 buffer;
+    tests/test_gpu_distributed.py checks that they return identical bits on the same message."""
+    if comm is not None:
+        if not hasattr(comm, "allreduce"):
+            raise TypeError("comm must be an engine.RcclComm (or offer .allreduce(msg)), got %r" % (type(comm),))
+        comm.allreduce(msg)
+    elif is_distributed():
         import torch.distributed as dist
         dist.all_reduce(msg, op=dist.ReduceOp.SUM)
     return msg

@@ -23,17 +23,29 @@ def _blocks_from_frame(pdf):
     cols = list(pdf.columns)
     names = cols[3:]
     p = len(names)
-    par_id = torch.from_numpy(pdf.iloc[:, 0].to_numpy(dtype=np.int64)).cuda()
-    vals = torch.from_numpy(np.ascontiguousarray(pdf.iloc[:, 1:].to_numpy(dtype=np.float64))).cuda()
+    par_id = pdf.iloc[:, 0].to_numpy(dtype=np.int64)
+    vals = np.ascontiguousarray(pdf.iloc[:, 1:].to_numpy(dtype=np.float64))
     if vals.shape[0] == 0:
         raise Exception("Zero-length grouped pandas DataFrame obtained, check the input.")   # dlsa.py:36-39
-    summed = torch.zeros((p, 2 + p), dtype=torch.float64, device="cuda").index_add_(0, par_id, vals)
+    # A stacked FRAME is host data: its blocks go to the device as they are ([K, p] / [K, p, p] when every par_id run is a
+    # whole block, the layout logistic_model emits) and dlsa_sum_blocks_f64 sums them; a frame in any other row order is
+    # grouped on the host first (numpy, the frame's own memory) and handed over as one block.  No torch arithmetic here:
+    # tensors are storage (north star).
+    K = vals.shape[0] // p if p else 0
+    whole = K >= 1 and vals.shape[0] == K * p and np.array_equal(par_id, np.tile(np.arange(p), K))
+    if not whole:
+        summed = np.zeros((p, 2 + p))
+        np.add.at(summed, par_id, vals)
+        vals, K = summed, 1
+    blk = vals.reshape(K, p, 2 + p)
+    coef = torch.from_numpy(np.ascontiguousarray(blk[:, :, 0])).cuda()
+    smc = torch.from_numpy(np.ascontiguousarray(blk[:, :, 1])).cuda()
+    sig = torch.from_numpy(np.ascontiguousarray(blk[:, :, 2:])).cuda()
     # message layout [Sig_inv (p*p) | Sig_invMcoef (p) | coef (p)]
-    msg = torch.cat([summed[:, 2:].reshape(-1), summed[:, 1], summed[:, 0]])
-    return msg, names, p
+    return engine.sum_blocks(coef, smc, sig), names, p
 
 
-def dlsa_mapred(model_mapped_sdf, num_partitions=None):
+def dlsa_mapred(model_mapped_sdf, num_partitions=None, comm=None):
     """MapReduce for partitioned data with a given model (dlsa.py:21-61).
 
     Accepts the device-resident `MappedBlocks` of `fit_logistic_partitions`, a pandas frame in the
@@ -42,7 +54,9 @@ def dlsa_mapred(model_mapped_sdf, num_partitions=None):
     one-shot mean and has the reference's meaning (dlsa.py:51-52: the number of partitions of the WHOLE
     job): given explicitly, or read from `.rdd.getNumPartitions()`, it is used as is on every rank.
     When it is not given the divisor is the number of blocks: this rank's count, summed over the ranks in
-    the same all-reduce as the blocks.  In a torch.distributed job every rank passes ITS blocks."""
+    the same all-reduce as the blocks.  In a torch.distributed job every rank passes ITS blocks; `comm` (an
+    `engine.RcclComm`) carries the all-reduce through the C ABI's dlsa_allreduce_f64 instead (hosts without
+    torch.distributed) -- the same RCCL collective on the same message either way."""
     if isinstance(model_mapped_sdf, MappedBlocks):
         mb = model_mapped_sdf
         names, p = mb.names, mb.coef.shape[1]
@@ -57,7 +71,7 @@ def dlsa_mapred(model_mapped_sdf, num_partitions=None):
         msg, names, p = _blocks_from_frame(pdf)
         nblocks = max(1, pdf.shape[0] // max(1, p))
     counts = torch.tensor([float(nblocks)], dtype=torch.float64, device=msg.device)
-    msg = distributed.allreduce_message(torch.cat([msg, counts]))
+    msg = distributed.allreduce_message(torch.cat([msg, counts]), comm=comm)
     K = float(msg[-1].item()) if num_partitions is None else float(num_partitions)
     Sig_inv_sum = msg[: p * p].view(p, p)
     Sig_invMcoef_sum = msg[p * p: p * p + p]

@@ -127,6 +127,28 @@ def synth(seed, row0, n, p, kind=SYNTH_UNIFORM, ones_col=False, labels=True, dty
     return X, y
 
 
+def synth_response(seed, row0, X, sigma=1.0, ones_col=False, beta_true=None, out=None):
+    """Linear-model response y = X beta* + sigma N(0,1) for rows `synth` wrote (config 5; dlsa_synth_response_*): the noise of
+    row i is a function of (seed, row0 + i) only.  X [n, p (+1 with ones_col)] fp64 / fp32 on the GPU; returns y [n]."""
+    lib = _lib.load()
+    _require_gpu(X, beta_true, out)
+    if X.dtype not in (torch.float64, torch.float32):
+        raise TypeError("synth_response: X must be float64 or float32")
+    _f64(X, "X", X.dtype); _f64(beta_true, "beta_true", X.dtype); _f64(out, "out", X.dtype)
+    n, cols = X.shape
+    p = cols - (1 if ones_col else 0)
+    y = out if out is not None else torch.empty((n,), dtype=X.dtype, device=X.device)
+    if y.numel() != n or (beta_true is not None and beta_true.numel() != cols):
+        raise ValueError("synth_response: y must have n and beta_true p (+1) elements")
+    fn = lib.dlsa_synth_response_f64 if X.dtype == torch.float64 else lib.dlsa_synth_response_f32
+    chunk = 1 << 30
+    ld = _rowmajor(X)
+    for r in range(0, n, chunk):
+        m = min(chunk, n - r)
+        check(fn(seed, row0 + r, m, p, 1 if ones_col else 0, _ptr(X[r:]), ld, _ptr(beta_true), float(sigma), _ptr(y[r:]), _stream()))
+    return y
+
+
 def design(num, codes, kind, src, level, shift, scale, dtype=torch.float64, out=None):
     """Dense design matrix from raw numeric columns + integer level codes (models.py:56-104,121-122).
     num [n,q] (dtype) or None, codes [n,f] int32 or None; kind/src/level int32 [p], shift/scale fp64 [p]
@@ -173,6 +195,53 @@ def gram(X, w=None, out=None, accumulate=False):
     check(fn(_ptr(X), ldx, _ptr(w), n, p, _ptr(H), _rowmajor(H), 1 if accumulate else 0,
              _ptr(ws), ws.numel(), _stream()))
     return H
+
+
+def gram_acc64(X, w=None, out=None, accumulate=False):
+    """fp32 rows, fp64 result (dlsa_gram_f32_acc64): the MFMA passes of gram() on fp32 rows with the slab partials summed in
+    fp64 and stored / added (accumulate) into the fp64 matrix `out` [p, p] (any row pitch: a sub-block view works).  The
+    streaming linear map step adds chunk after chunk this way."""
+    lib = _lib.load()
+    _require_gpu(X, w, out)
+    _f64(X, "X", torch.float32); _f64(w, "w", torch.float32); _f64(out, "out")
+    n, p = X.shape
+    H = out if out is not None else torch.empty((p, p), dtype=torch.float64, device=X.device)
+    if H.dim() != 2 or tuple(H.shape) != (p, p):
+        raise ValueError("gram_acc64: out must be p x p")
+    if w is not None and w.numel() != n:
+        raise ValueError("gram_acc64: w must have n elements")
+    ws = _workspace(lib.dlsa_gram_workspace_bytes(n, p, 4), X.device)
+    check(lib.dlsa_gram_f32_acc64(_ptr(X), _rowmajor(X), _ptr(w), n, p, _ptr(H), _rowmajor(H), 1 if accumulate else 0,
+                                  _ptr(ws), ws.numel(), _stream()))
+    return H
+
+
+def xtv_stats(X, v, g=None, colsum=None, stats=None, want_colsum=False, accumulate=False):
+    """One read of X: g = X'v, colsum = X'1 (optional: the implicit intercept's border), stats = [v'v, sum v], all fp64
+    whatever X's type (dlsa_xtv_stats_*); accumulate adds to the given outputs.  Returns (g, colsum or None, stats)."""
+    lib = _lib.load()
+    _require_gpu(X, v, g, colsum, stats)
+    if X.dtype not in (torch.float64, torch.float32):
+        raise TypeError("xtv_stats: X must be float64 or float32")
+    _f64(X, "X", X.dtype); _f64(v, "v", X.dtype); _f64(g, "g"); _f64(colsum, "colsum"); _f64(stats, "stats")
+    n, p = X.shape
+    if v.numel() != n:
+        raise ValueError("xtv_stats: v must have n = %d elements" % n)
+    dev = X.device
+    if accumulate and (g is None or stats is None or (want_colsum and colsum is None)):
+        raise ValueError("xtv_stats: accumulate needs the outputs to add to")
+    g = g if g is not None else torch.empty((p,), dtype=torch.float64, device=dev)
+    stats = stats if stats is not None else torch.empty((2,), dtype=torch.float64, device=dev)
+    if want_colsum and colsum is None:
+        colsum = torch.empty((p,), dtype=torch.float64, device=dev)
+    if g.numel() != p or stats.numel() != 2 or (colsum is not None and colsum.numel() != p):
+        raise ValueError("xtv_stats: g / colsum must have p and stats 2 elements")
+    es = X.element_size()
+    ws = _workspace(lib.dlsa_xtv_stats_workspace_bytes(p, es), dev)
+    fn = lib.dlsa_xtv_stats_f64 if es == 8 else lib.dlsa_xtv_stats_f32
+    check(fn(_ptr(X), _rowmajor(X), _ptr(v), n, p, _ptr(g), _ptr(colsum if want_colsum else None), _ptr(stats),
+             1 if accumulate else 0, _ptr(ws), ws.numel(), _stream()))
+    return g, (colsum if want_colsum else None), stats
 
 
 def gram_last_kernel(want_cycles=False):

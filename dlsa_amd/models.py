@@ -220,61 +220,139 @@ def logistic_model_eval(sample_df, Y_name, par, fit_intercept=False, dummy_info=
 #   coef = OLS estimate, Sig_inv = X'X, Sig_invMcoef = X'y (= X'X coef).
 # With these blocks the WLS combine of dlsa_mapred equals the global OLS estimate exactly.
 # ---------------------------------------------------------------------------------------------
+class _LinearBlock:
+    """Sufficient statistics of one partition of a linear model, accumulated chunk by chunk ON THE DEVICE by library
+    kernels only: H = [1 | X]'[1 | X] (fp64; the ones column of models.py:121-122 implicit), g = [1 | X]'y, y'y, n.
+    fp64 rows: dlsa_gram_f64 (accumulate) straight into H's X-block; fp32 rows: dlsa_gram_f32_acc64 (fp32 MFMA passes,
+    fp64 sum).  X'y, the column sums (the intercept's border), y'y and sum y: dlsa_xtv_stats_* -- one read of the chunk."""
+
+    def __init__(self, p, fit_intercept, sig_out, smc_out, device):
+        self.p, self.icpt = p, 1 if fit_intercept else 0
+        self.sig, self.smc = sig_out, smc_out                      # [pp, pp] / [pp] views of the result block (fp64)
+        self.HX = sig_out[self.icpt:, self.icpt:]                  # the X'X block, written in place (row pitch pp)
+        self.g = torch.zeros((p,), dtype=torch.float64, device=device)
+        self.colsum = torch.zeros((p,), dtype=torch.float64, device=device) if fit_intercept else None
+        self.stats = torch.zeros((2,), dtype=torch.float64, device=device)
+        self.rows = 0
+
+    def add(self, Xc, yc):
+        first = self.rows == 0
+        if Xc.dtype == torch.float32:
+            engine.gram_acc64(Xc, None, out=self.HX, accumulate=not first)
+        else:
+            engine.gram(Xc, None, out=self.HX, accumulate=not first)
+        engine.xtv_stats(Xc, yc, g=self.g, colsum=self.colsum, stats=self.stats, want_colsum=bool(self.icpt), accumulate=True)
+        self.rows += Xc.shape[0]
+
+    def finish(self):
+        """Borders of the implicit ones column, X'y into the block; returns y'y (host float)."""
+        st = self.stats.cpu().numpy()
+        self.smc[self.icpt:] = self.g
+        if self.icpt:
+            self.sig[0, 0] = float(self.rows)
+            self.sig[0, 1:] = self.colsum
+            self.sig[1:, 0] = self.colsum
+            self.smc[0] = float(st[1])
+        return float(st[0])
+
+
+def _linear_finish(blocks, coef, smc, sig, names, n):
+    status, rss = [], []
+    for k, blk in enumerate(blocks):
+        if blk is None or blk.rows == 0:
+            status.append(4); rss.append(0.0)
+            continue
+        yy = blk.finish()
+        try:
+            coef[k] = engine.spd_solve(sig[k], smc[k])
+            status.append(0)
+            rss.append(yy - float(np.dot(coef[k].cpu().numpy(), smc[k].cpu().numpy())))      # y'y - theta'X'y
+        except Exception:
+            status.append(2); rss.append(float("nan"))
+            warnings.warn("linear_model: X'X not positive definite (collinear design)")
+    return MappedBlocks(coef, smc, sig, names, status, [1] * len(blocks), rss, sample_size=n)
+
+
 def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_intercept=False, names=None):
-    """Tensor fast path: one Gram pass X'X + one X'y pass per partition.  Returns MappedBlocks whose
+    """Tensor fast path: one Gram pass X'X + one X'y pass per partition, no copy of the shard -- partition_id = i % K
+    (models.py:33) is the strided view X[k::K] (every kernel takes any row pitch), contiguous partitions are row ranges, and
+    the intercept's ones column (models.py:121-122) stays implicit (its border comes from the X'y pass).  fp32 rows
+    (config 5) run the fp32 MFMA Gram with fp64 slab sums; blocks are fp64 either way.  Returns MappedBlocks whose
     `loglik` slot carries the residual sum of squares of each partition."""
     if not X.is_cuda:
         raise RuntimeError("fit_linear_partitions runs on the GPU only (no CPU fallback)")
     if X.dtype not in (torch.float64, torch.float32):
         raise TypeError("fit_linear_partitions: X must be float64 or float32, got %s" % X.dtype)
+    X = engine.row_major(X)
     y = y.to(X.dtype)
     n, p = X.shape
     if part_offsets is None:
         K = int(partition_num) if partition_num else 1
-        if K > 1:
-            idx = torch.arange(n, device=X.device)
-            order = torch.argsort(idx % K, stable=True)
-            X, y = X[order], y[order]
-            counts = torch.bincount(idx % K, minlength=K).cpu().tolist()
-        else:
-            counts = [n]
-        part_offsets = np.concatenate([[0], np.cumsum(counts)])
-    if fit_intercept:
-        X = engine.with_ones_column(X)
-    X, y = engine.row_major(X), y.contiguous()
-    pp = X.shape[1]
+        views = [(X[k::K], y[k::K].contiguous() if K > 1 else y.contiguous()) for k in range(K)]
+    else:
+        offs = [int(v) for v in part_offsets]
+        K = len(offs) - 1
+        yc = y.contiguous()
+        views = [(X[offs[k]:offs[k + 1]], yc[offs[k]:offs[k + 1]]) for k in range(K)]
+    pp = p + (1 if fit_intercept else 0)
     if names is None:
         names = ["x" + str(i) for i in range(p)]
     names = (["intercept"] if fit_intercept else []) + list(names)
-    offs = [int(v) for v in part_offsets]
-    K = len(offs) - 1
     coef = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
     smc = torch.zeros((K, pp), dtype=torch.float64, device=X.device)
     sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=X.device)
-    f32 = X.dtype == torch.float32       # config 5: fp32 rows, fp32 Gram; the p x p blocks are kept in fp64
-    Hk = torch.empty((pp, pp), dtype=X.dtype, device=X.device) if f32 else None
-    status, rss = [], []
+    blocks = []
+    for k, (Xk, yk) in enumerate(views):
+        if Xk.shape[0] == 0:
+            blocks.append(None)
+            continue
+        blk = _LinearBlock(p, fit_intercept, sig[k], smc[k], X.device)
+        blk.add(Xk, yk)
+        blocks.append(blk)
+    return _linear_finish(blocks, coef, smc, sig, names, n)
+
+
+def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=20260101, row0=0, kind="gaussian", sigma=1.0,
+                         fit_intercept=False, dtype=torch.float32, names=None, device="cuda", on_chunk=None):
+    """The linear map step for a shard that does NOT fit HBM (BASELINE config 5: 6.25e7 x 2000 fp32 = 500 GB per GPU, SURVEY
+    8(d)): rows row0 .. row0 + n of the seeded stream are generated ON THE DEVICE chunk by chunk (dlsa_synth_*: a row is a
+    pure function of (seed, i); y = X beta* + sigma N(0,1) by dlsa_synth_response_*), each chunk goes once through the Gram
+    kernel (accumulating) and once through the X'y pass, and is overwritten by the next.  The K partitions are contiguous
+    row ranges of the stream (the layout repartition(K, "partition_id") gives, logistic_dlsa.py:295); chunks never straddle
+    a partition.  Peak memory = one chunk + K blocks.  Returns MappedBlocks (fp64 blocks)."""
+    K = int(partition_num)
+    n, p, chunk_rows = int(n), int(p), int(chunk_rows)
+    if K < 1 or n < 0 or chunk_rows < 1:
+        raise ValueError("fit_linear_streaming: need partition_num >= 1, n >= 0, chunk_rows >= 1")
+    kind_id = {"uniform": engine.SYNTH_UNIFORM, "gaussian": engine.SYNTH_GAUSSIAN}[kind] if isinstance(kind, str) else int(kind)
+    pp = p + (1 if fit_intercept else 0)
+    if names is None:
+        names = ["x" + str(i) for i in range(p)]
+    names = (["intercept"] if fit_intercept else []) + list(names)
+    coef = torch.zeros((K, pp), dtype=torch.float64, device=device)
+    smc = torch.zeros((K, pp), dtype=torch.float64, device=device)
+    sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=device)
+    offs = [int(n * k / K) for k in range(K + 1)]
+    rows_max = min(chunk_rows, max(1, max(offs[k + 1] - offs[k] for k in range(K))))
+    Xbuf = engine.empty_rows(rows_max, p, dtype, device)
+    ybuf = torch.empty((rows_max,), dtype=dtype, device=device)
+    blocks = []
     for k in range(K):
         lo, hi = offs[k], offs[k + 1]
         if hi <= lo:
-            status.append(4); rss.append(0.0)
+            blocks.append(None)
             continue
-        if f32:
-            engine.gram(X[lo:hi], None, out=Hk)
-            sig[k] = Hk.double()
-        else:
-            engine.gram(X[lo:hi], None, out=sig[k])
-        g, yy = engine.xtv(X[lo:hi], y[lo:hi])
-        g, yy = g.double(), yy.double()
-        smc[k] = g
-        try:
-            coef[k] = engine.spd_solve(sig[k], g)
-            status.append(0)
-            rss.append(float((yy - torch.dot(coef[k], g)).item()))       # y'y - theta'X'y
-        except Exception:
-            status.append(2); rss.append(float("nan"))
-            warnings.warn("linear_model: X'X not positive definite (collinear design)")
-    return MappedBlocks(coef, smc, sig, names, status, [1] * K, rss, sample_size=n)
+        blk = _LinearBlock(p, fit_intercept, sig[k], smc[k], device)
+        for r in range(lo, hi, rows_max):
+            m = min(rows_max, hi - r)
+            Xc, yc = Xbuf[:m], ybuf[:m]
+            engine.synth(seed, row0 + r, m, p, kind=kind_id, labels=False, dtype=dtype, out=Xc)
+            engine.synth_response(seed, row0 + r, Xc, sigma=sigma, out=yc)
+            blk.add(Xc, yc)
+            if on_chunk is not None:
+                on_chunk(k, r, m)
+        blocks.append(blk)
+    return _linear_finish(blocks, coef, smc, sig, names, n)
 
 
 def linear_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[], data_info=[]):

@@ -61,6 +61,14 @@ int dlsa_synth_f64(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int 
                    double* X, int64_t ldx, double* y, const double* beta_true, void* stream);
 int dlsa_synth_f32(uint64_t seed, int64_t row0, int64_t n, int p, int kind, int ones_col,
                    float* X, int64_t ldx, float* y, const float* beta_true, void* stream);
+/* Linear-model response for rows dlsa_synth_* has written (config 5 is "linear model y = X beta* + N(0,1)";
+ * the reference has no linear simulator -- README.md:6 only claims the method): y_i = x_i . beta_true + sigma z_i with
+ * z_i ~ N(0,1) from the row's own counter stream (counter (i_lo, i_hi, 0, 2), key (seed+1, 0)), so a chunk generated
+ * on the device inside a streaming map step is the same for every sharding and for the CPU oracle. */
+int dlsa_synth_response_f64(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const double* X, int64_t ldx,
+                            const double* beta_true, double sigma, double* y, void* stream);
+int dlsa_synth_response_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const float* X, int64_t ldx,
+                            const float* beta_true, double sigma, float* y, void* stream);
 
 /* ---- K3: weighted tall-skinny Gram  H = X' diag(w) X  (dlsa/models.py:130) ------------
  * X: n x p, w: n (NULL = all ones, the linear-model X'X), H: p x p (ldh >= p), both
@@ -71,6 +79,11 @@ int dlsa_gram_f64(const double* X, int64_t ldx, const double* w, int64_t n, int 
                   double* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int dlsa_gram_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p,
                   float* H, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* fp32 rows, fp64 result: the same MFMA passes as dlsa_gram_f32, but the slab partials are summed in fp64 and stored /
+ * added (accumulate != 0) into the fp64 matrix H64.  The streaming linear map step (config 5: 6.25e7 rows per GPU do not
+ * fit HBM) calls it chunk after chunk; fp32 rounding then stays inside a chunk's slabs. */
+int dlsa_gram_f32_acc64(const float* X, int64_t ldx, const float* w, int64_t n, int p,
+                        double* H64, int64_t ldh, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Measurement hook (no reference counterpart; bench.py's `roofline.kernel` and `shader_clock_GHz`, and the tests that
  * must know which kernel variant they exercised): name of the Gram kernel the calling thread's last Gram launch
  * dispatched, e.g. "gram_cyclic_kernel<true,1>", and -- nullable -- the shader cycles wave 0 of workgroup 0 spent in
@@ -246,6 +259,15 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
                              int64_t ldc, const double* y, const int64_t* part_offsets_host, int K, double tol,
                              int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host,
                              int* status_host, double* loglik_host, void* ws, size_t ws_bytes, void* stream);
+
+/* N3, streaming form: ONE read of X gives, in fp64 whatever the rows' type, g = X'v (p), colsum = X'1 (p, nullable: the
+ * intercept's border of [1 | X]'[1 | X] with the ones column of models.py:121-122 left implicit), stats[0] = v'v and
+ * stats[1] = sum v; accumulate != 0 ADDS to what the outputs hold (the chunks before this one). */
+size_t dlsa_xtv_stats_workspace_bytes(int p, int elem_bytes);
+int dlsa_xtv_stats_f64(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* colsum,
+                       double* stats, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int dlsa_xtv_stats_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, double* g, double* colsum,
+                       double* stats, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
  * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */

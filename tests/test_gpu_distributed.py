@@ -44,10 +44,14 @@ def _worker(rank, world, port, K, n, p, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_full_path(tmp_path):
+@pytest.mark.parametrize("world,K", [(2, 6), (8, 16)])
+def test_ranks_sharing_one_gpu_full_path(tmp_path, world, K):
+    """2 ranks, and the 8 ranks of the driver's node (a dry run: gloo transport, all ranks on the one GPU of the test box,
+    small rows): GPU g owns the partitions {k : k % G == g}, every rank fits its own, ONE all-reduce, every rank
+    solves + shrinks redundantly -- and every rank ends with the single-process oracle's result."""
     import torch.multiprocessing as mp
     from oracle import dlsa_oracle as orc
-    K, n, p, world = 6, 24000, 12, 2
+    n, p = 24000, 12
     mp.spawn(_worker, args=(world, _free_port(), K, n, p, str(tmp_path)), nprocs=world, join=True)
     X, y = orc.synth_logistic(314, 0, n, p)
     parts = orc.partition_rows(n, K)
@@ -61,3 +65,38 @@ def test_two_ranks_one_gpu_full_path(tmp_path):
         assert rel(z["oneshot"], oneshot) < 1e-10
         assert rel(z["S"], S) < 1e-10
         assert rel(z["bic"], by_bic) < 1e-8
+
+
+def _one_rank_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    import dlsa_amd
+    from dlsa_amd import distributed, engine
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = engine.RcclComm(1, engine.RcclComm.unique_id(), 0)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    msg = torch.randn(500 * 500 + 2 * 500 + 1, dtype=torch.float64, device="cuda", generator=gen)
+    a = distributed.allreduce_message(msg.clone())                  # torch.distributed (backend nccl = RCCL)
+    b = distributed.allreduce_message(msg.clone(), comm=comm)        # the C ABI's dlsa_allreduce_f64
+    same_bits = bool(torch.equal(a, b)) and bool(torch.equal(a, msg))
+    # and through dlsa_mapred: the same frame either way
+    from oracle import dlsa_oracle as orc
+    X, y = orc.synth_logistic(9, 0, 9000, 10)
+    mb = dlsa_amd.fit_logistic_partitions(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda(), partition_num=3)
+    o1, o2 = dlsa_amd.dlsa_mapred(mb), dlsa_amd.dlsa_mapred(mb, comm=comm)
+    same_frame = bool(np.array_equal(o1.to_numpy(), o2.to_numpy())) and list(o1.columns) == list(o2.columns)
+    comm.close()
+    dist.destroy_process_group()
+    np.savez(os.path.join(out_dir, "bits.npz"), same_bits=same_bits, same_frame=same_frame)
+
+
+def test_rccl_comm_and_torch_distributed_are_one_reduce_path(tmp_path):
+    """two carriers of the reduce exist (torch.distributed in dlsa_mapred; RcclComm / dlsa_allreduce_f64 in the
+    C ABI).  On a one-rank RCCL communicator of each kind (the test box has one GPU) the same message must come back with
+    identical bits, and dlsa_mapred(..., comm=RcclComm) must return the frame dlsa_mapred(...) returns."""
+    import torch.multiprocessing as mp
+    mp.spawn(_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), "bits.npz"))
+    assert bool(z["same_bits"]) and bool(z["same_frame"])

@@ -1,0 +1,158 @@
+"""GPU: the linear-regression map step (SURVEY N3 / BASELINE config 5) without copies of the shard and as a STREAMING step for
+shards that do not fit HBM: dlsa_xtv_stats_* (X'y, column sums, y'y, sum y in one read, fp64 sums, accumulating),
+dlsa_gram_f32_acc64 (fp32 MFMA passes, fp64 slab sums), dlsa_synth_response_* (y = X beta* + sigma N(0,1) per row),
+fit_linear_partitions (strided partitions, implicit intercept) and fit_linear_streaming.  The reference ships no linear map
+(README.md:6 claims the method): the oracle is numpy's fp64 lstsq on the same rows -- the WLS combine of OLS blocks is
+the global OLS estimate exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available()
+    from dlsa_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("dtype,n,p", [("f64", 5000, 37), ("f64", 1, 8), ("f64", 33333, 500), ("f64", 4097, 1025),
+                                      ("f32", 5000, 37), ("f32", 77777, 2000), ("f32", 3, 256), ("f32", 20001, 999)])
+def test_xtv_stats_matches_numpy_and_accumulates(eng, dtype, n, p):
+    rng = np.random.default_rng(n + p)
+    npdt, tdt = (np.float64, torch.float64) if dtype == "f64" else (np.float32, torch.float32)
+    X = rng.standard_normal((n, p)).astype(npdt)
+    v = rng.standard_normal(n).astype(npdt)
+    X64, v64 = X.astype(np.float64), v.astype(np.float64)
+    g, cs, st = eng.xtv_stats(dev(X), dev(v), want_colsum=True)
+    tol = 1e-12
+    assert rel_inf(g.cpu().numpy(), X64.T @ v64) < tol * max(1.0, np.sqrt(n))
+    assert rel_inf(cs.cpu().numpy(), X64.sum(0)) < tol * max(1.0, np.sqrt(n))
+    assert rel_inf(st.cpu().numpy(), [v64 @ v64, v64.sum()]) < 1e-11
+    # a second chunk added on top (ragged cut, a view with a row pitch), without the column sums
+    cut = n // 3
+    g2, _, st2 = eng.xtv_stats(dev(X)[:cut], dev(v)[:cut].contiguous())
+    eng.xtv_stats(dev(X)[cut:], dev(v)[cut:].contiguous(), g=g2, stats=st2, accumulate=True)
+    assert rel_inf(g2.cpu().numpy(), X64.T @ v64) < tol * max(1.0, np.sqrt(n))
+    assert rel_inf(st2.cpu().numpy(), [v64 @ v64, v64.sum()]) < 1e-11
+    # same call twice: same bits (fixed summation order)
+    g3, cs3, st3 = eng.xtv_stats(dev(X), dev(v), want_colsum=True)
+    assert torch.equal(g, g3) and torch.equal(cs, cs3) and torch.equal(st, st3)
+
+
+@pytest.mark.parametrize("n,p", [(40000, 1024), (30011, 2000), (9000, 300), (5000, 64)])
+def test_gram_f32_acc64_sums_fp32_passes_in_fp64(eng, n, p):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(p)
+    X = torch.randn((n, p), dtype=torch.float32, device="cuda", generator=gen)
+    ref = X.double().T @ X.double()
+    H = eng.gram_acc64(X)
+    assert H.dtype == torch.float64 and torch.equal(H, H.T)
+    d = ref.diagonal().sqrt()
+    assert float(((H - ref).abs() / (d[:, None] * d[None, :])).max()) < 2e-6           # fp32 products / sums inside a slab
+    # chunks accumulate in fp64: two halves added = one pass to fp32-slab accuracy, and into a sub-block view of a bigger matrix
+    big = torch.zeros((p + 1, p + 1), dtype=torch.float64, device="cuda")
+    eng.gram_acc64(X[: n // 2], out=big[1:, 1:])
+    eng.gram_acc64(X[n // 2:], out=big[1:, 1:], accumulate=True)
+    assert float(((big[1:, 1:] - ref).abs() / (d[:, None] * d[None, :])).max()) < 2e-6
+    assert float(big[0].abs().max()) == 0.0 and float(big[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_synth_response_matches_oracle(eng, orc, dtype):
+    n, p, seed = 3000, 21, 77
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    X, _ = eng.synth(seed, 100, n, p, kind=eng.SYNTH_UNIFORM, labels=False, dtype=tdt)
+    y = eng.synth_response(seed, 100, X, sigma=0.5)
+    Xo, yo = orc.synth_linear(seed, 100, n, p, orc.SYNTH_UNIFORM, sigma=0.5)
+    assert rel_inf(y.cpu().numpy(), yo) < (1e-12 if dtype == "f64" else 1e-6)
+    z = orc.synth_response_normals(seed, 0, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01                      # the noise is standard normal
+
+
+@pytest.mark.parametrize("icpt", [False, True])
+def test_linear_partitions_no_copy_strided_and_implicit_intercept(eng, orc, icpt):
+    import dlsa_amd
+    n, p, K = 30000, 33, 4
+    X, y = orc.synth_linear(5, 0, n, p, orc.SYNTH_UNIFORM)
+    y = y + (0.7 if icpt else 0.0)
+    Xd, yd = dev(X), dev(y)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    mb = dlsa_amd.fit_linear_partitions(Xd, yd, partition_num=K, fit_intercept=icpt)
+    assert torch.cuda.max_memory_allocated() - base < 0.5 * X.nbytes + 64e6     # no gathered copy, no [1 | X] copy
+    assert mb.status == [0] * K
+    A = np.hstack([np.ones((n, 1)), X]) if icpt else X
+    parts = orc.partition_rows(n, K)
+    for k in range(K):
+        Ak, yk = A[parts[k]], y[parts[k]]
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), Ak.T @ Ak) < 1e-12
+        assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), Ak.T @ yk) < 1e-11
+        ck = np.linalg.lstsq(Ak, yk, rcond=None)[0]
+        assert rel_inf(mb.coef[k].cpu().numpy(), ck) < 1e-9
+        assert abs(mb.loglik[k] - float(np.sum((yk - Ak @ ck) ** 2))) < 1e-8 * float(yk @ yk)
+    out = dlsa_amd.dlsa_mapred(mb)
+    assert rel_inf(out["beta_byOLS"].to_numpy(), np.linalg.lstsq(A, y, rcond=None)[0]) < 1e-9
+
+
+@pytest.mark.parametrize("dtype,icpt", [("f64", True), ("f64", False), ("f32", True)])
+def test_linear_streaming_equals_resident_fit_and_global_ols(eng, orc, dtype, icpt):
+    """The streaming map step (rows generated on the device chunk by chunk, never resident together) gives the blocks of
+    the resident fit on the same rows, and their WLS combine is the global OLS estimate."""
+    import dlsa_amd
+    n, p, K, seed = 50000, 40, 3, 20260105
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    chunks = []
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=7000, seed=seed, kind="uniform", fit_intercept=icpt,
+                                       dtype=tdt, on_chunk=lambda k, r, m: chunks.append((k, r, m)))
+    assert mb.status == [0] * K and sum(m for _, _, m in chunks) == n and max(m for _, _, m in chunks) <= 7000
+    assert len(chunks) == sum(-(-(int(n * (k + 1) / K) - int(n * k / K)) // 7000) for k in range(K))
+    X, y = orc.synth_linear(seed, 0, n, p, orc.SYNTH_UNIFORM)
+    if dtype == "f32":
+        X, y = X.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
+    A = np.hstack([np.ones((n, 1)), X]) if icpt else X
+    tol = 1e-11 if dtype == "f64" else 2e-6
+    for k in range(K):
+        lo, hi = int(n * k / K), int(n * (k + 1) / K)
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), A[lo:hi].T @ A[lo:hi]) < tol
+        assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), A[lo:hi].T @ y[lo:hi]) < tol * 10
+    out = dlsa_amd.dlsa_mapred(mb)
+    ols = np.linalg.lstsq(A, y, rcond=None)[0]
+    assert rel_inf(out["beta_byOLS"].to_numpy(), ols) < (1e-9 if dtype == "f64" else 2e-5)
+    truth = np.concatenate([[0.0] if icpt else [], orc.true_beta(p)])
+    assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.1
+
+
+def test_linear_streaming_config5_width_bounded_memory(eng):
+    """Config 5's width (p = 2000 fp32) streamed in 2^18-row chunks: 1.5e6 rows (12 GB of rows) pass through a 2 GB chunk
+    buffer; the peak stays under 4 GB and the estimate recovers the generating coefficients."""
+    import dlsa_amd
+    from conftest import _free_device_cache
+    _free_device_cache()
+    n, p = 1_500_000, 2000
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=2, chunk_rows=1 << 18, fit_intercept=True)
+    peak = torch.cuda.max_memory_allocated() - base
+    assert mb.status == [0, 0]
+    assert peak < 4e9, "peak %.2f GB" % (peak / 1e9)
+    assert eng.gram_last_kernel()[0].startswith("gram_wide_f32_kernel")
+    out = dlsa_amd.dlsa_mapred(mb)
+    truth = np.concatenate([[0.0], np.ones(800), np.zeros(1200)])
+    assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.03
