@@ -117,6 +117,39 @@ def linear_config(name, n, p, K):
             "map_fit_s": t_all, "map_reduce_lars_s": t_whole, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max())}
 
 
+def linear_streaming_config(name, n, p, K, chunk_rows):
+    """Config 5 at its STATED per-GPU size: 6.25e7 x 2000 fp32 = 500 GB of rows streamed through one chunk buffer
+    (generated on the device chunk by chunk); per-phase times from a dry pass over the same chunks."""
+    dt = torch.float32
+    rows_max = min(chunk_rows, n // K)
+    Xc = engine.empty_rows(rows_max, p, dt, "cuda"); yc = torch.empty(rows_max, dtype=dt, device="cuda")
+    H = torch.zeros((p, p), dtype=torch.float64, device="cuda")
+    t_syn, _ = timed(lambda: (engine.synth(20260101, 0, rows_max, p, kind=engine.SYNTH_GAUSSIAN, labels=False, dtype=dt, out=Xc),
+                              engine.synth_response(20260101, 0, Xc, out=yc)))
+    t_gram, _ = timed(lambda: engine.gram_acc64(Xc, None, out=H, accumulate=True))
+    kern = engine.gram_last_kernel()[0]
+    t_stats, _ = timed(lambda: engine.xtv_stats(Xc, yc, want_colsum=True))
+    del Xc, yc, H
+    torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+    t0 = time.perf_counter()
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=chunk_rows, fit_intercept=True, dtype=dt)
+    torch.cuda.synchronize(); t_map = time.perf_counter() - t0
+    peak = torch.cuda.max_memory_allocated() - base
+    t1 = time.perf_counter()
+    out = dlsa_amd.dlsa_mapred(mb)
+    sel = dlsa_amd.dlsa(out.iloc[:, 2:], out["beta_byOLS"], n, fit_intercept=True)
+    torch.cuda.synchronize(); t_rest = time.perf_counter() - t1
+    truth = np.concatenate([[0.0], np.ones(int(0.4 * p)), np.zeros(p - int(0.4 * p))])
+    fl = p * (p + 1)
+    return {"config": name, "n": n, "p": p, "K": K, "dtype": "f32", "chunk_rows": rows_max, "gram_kernel": kern,
+            "chunk_synth_ms": t_syn * 1e3, "chunk_gram_ms": t_gram * 1e3, "chunk_stats_ms": t_stats * 1e3,
+            "gram_rows_per_s": rows_max / t_gram, "gram_TF_alg": rows_max * fl / t_gram / 1e12,
+            "stats_GBps": rows_max * 4 * (p + 1) / t_stats / 1e9, "map_fit_s": t_map, "map_rows_per_s": n / t_map,
+            "map_TF_alg_incl_generation": n * fl / t_map / 1e12, "reduce_lars_s": t_rest, "peak_device_bytes": peak,
+            "status_ok": all(v == 0 for v in mb.status),
+            "theta_err_linf": float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth)))}
+
+
 def main():
     class _P(list):
         def append(self, r):
@@ -151,6 +184,9 @@ def main():
         n4 = 14_000_000
         rows.append(logistic_config("C4 shard airline-shaped synthetic n=1.4e7 (113.9M/8) p=260 (7 numeric + 5 factors one-hot on device) K=14", n4, 0, 14, Xy=airline_shaped(n4)))
     torch.cuda.empty_cache()
+    if "C5s" in sel:
+        rows.append(linear_streaming_config("C5 shard at its stated size, STREAMED: linear n=6.25e7 p=2000 fp32 K=8, 2^22-row chunks generated on the device",
+                                            int(os.environ.get("DLSA_C5_ROWS", "62500000")), 2000, 8, 1 << 22))
     if "C5" in sel:
         rows.append(linear_config("C5 shard (capped) linear n=2.4e7 p=2000 fp32 K=8", 24_000_000, 2000, 8))
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "dlsa_loglik_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_xtv_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_xtv_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_irls_pass_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dlsa_irls_pass_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_irls_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dlsa_irls_fit_f64": (c_int, [c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_int, c_int, c_dbl, c_int,
                                   c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -1,0 +1,560 @@
+// One FUSED Newton pass for narrow fp64 designs (49 <= p <= 112): in ONE read of the rows
+//     eta = X beta,  mu = sigmoid(eta),  w = mu (1 - mu),  g = X'(y - mu),  loglik,  H = X' diag(w) X.
+// Reference call sites: dlsa/models.py:110-114 (the solver's inner products and predict_proba), :130 (the Hessian).  The
+// reference reads a partition's rows three times per evaluation (fit iteration, predict_proba, the .dot of :130); the
+// unfused engine twice (logit.hip's pass writes w, gram_narrow.hip's pass reads X and w).  At p = 100 the Gram pass sits at
+// the chip's power limit with 3.8 TB/s streaming, and the logit pass costs two thirds of a Gram pass: every fresh Hessian
+// pays 1.66 passes.  Here the rows a workgroup has staged in LDS for the MFMAs also feed the logistic terms:
+//
+//   * gram_narrow.hip's layout: the whole upper triangle of H (NT full tiles + G tail groups) lives in ONE wave's AGPRs, the
+//     four waves of a workgroup split the ROWS (wave m takes k-steps m and m + 4 of every 32-row chunk), rows stream through a
+//     4-stage LDS-DMA ring three chunks ahead;
+//   * while a wave's MFMAs of chunk c run, the same wave evaluates the logistic terms of ITS OWN eight rows of chunk c + 1 (already
+//     landed) from LDS: lane (j = l >> 3, s = l & 7) holds columns 16 q + 2 s + {0, 1} of row j -- NTC 16-byte LDS reads,
+//     2 NTC FMAs against beta (registers), a 3-step DPP butterfly over the 8 lanes of a row, the lean transcendentals of
+//     logistic.h, the rank-one update g += (y - mu) x on the registers it still holds.  The pieces are issued one behind
+//     each SEGMENT of the generated MFMA blocks (gram_narrow_asm.inc), so their latencies hide under the matrix pipe;
+//   * w goes to the stage's w slot in LDS, where the MFMA part of the next iteration reads it exactly as gram_narrow.hip
+//     reads the DMA'd weights -- by the same wave that wrote it (no cross-wave dependency, no extra barrier);
+//   * y arrives through the same LDS-DMA ring (one piece per wave and chunk in place of gram_narrow's w piece).
+// One workgroup per CU, one wave per SIMD (the wave needs both register sets: 182 accumulators + fragments + beta + g).
+// Outputs per slab: the H partial (summed by gram.hip's reduce kernel), g and loglik partials (summed in a fixed order by
+// irls_pass_finish_kernel): bit-reproducible run to run.
+#include "common.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace dlsa {
+
+template <typename T>
+void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_t ldh, int accumulate, hipStream_t stream);   // gram.hip
+int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* w_out, double* g,
+                    double* loglik, void* ws, size_t ws_bytes, hipStream_t s, int intercept);                                   // logit.hip
+size_t logit_workspace_bytes_impl(int64_t n, int p);
+int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh, int accumulate, void* ws,
+                  size_t ws_bytes, hipStream_t stream);                                                                         // gram.hip
+size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
+
+#include "logistic.h"
+#include "gram_narrow_asm.inc"
+
+constexpr int FP_KC = 32;                 // rows per chunk: two k-steps per wave
+constexpr int FP_NST = 4;                 // LDS stages: the DMA runs three chunks ahead
+constexpr int FP_MIN_P = 49, FP_MAX_P = 112;
+constexpr int64_t FP_MIN_ROWS = 8192;
+
+struct FusedArgs {
+    const double* X;
+    const double* y;
+    const double* beta;
+    double* w_out;        // nullable
+    double* partial;      // [nslab][PP][PP]
+    double* gpart;        // [nslab][GP]: g (16 NTC) | loglik
+    int64_t ldx, n, rows_per_slab;
+    int p, PP;
+    unsigned long long* clk;
+};
+
+constexpr int fp_pitch(int ntc) { return (ntc % 2) ? ntc * 16 : ntc * 16 + 16; }       // = 16 mod 32 (gram_narrow.hip)
+constexpr int fp_buf(int ntc) { return FP_KC * fp_pitch(ntc) + 2 * FP_KC; }            // a chunk + its w (computed) + its y (DMA)
+constexpr int fp_nreg(int nt, int g) { return 8 * (nt * (nt + 1) / 2) + 2 * (nt + 1) * g; }
+constexpr int fp_gp(int ntc) { return 16 * ntc + 8; }
+
+template <int T, int TEND, typename F>
+__device__ __forceinline__ void fp_for_tiles(F&& fn) {
+    if constexpr (T < TEND) {
+        double v[4];
+        narrow_tile_read<T>(v);
+        fn(T, v);
+        fp_for_tiles<T + 1, TEND>(fn);
+    }
+}
+template <int NTRI, int NTAIL, int K, typename F>
+__device__ __forceinline__ void fp_for_tails(F&& fn) {
+    if constexpr (K < NTAIL) {
+        fn(K, narrow_pair_read<8 * NTRI + 2 * K>());
+        fp_for_tails<NTRI, NTAIL, K + 1>(fn);
+    }
+}
+
+// the four waves' partial tiles [T0, T1) meet in LDS (gram_narrow.hip's narrow_meet): waves 1..3 park, wave 0 adds in a fixed order
+template <int T0, int T1, int MEETN>
+__device__ __forceinline__ void fp_meet(double* lds, int wave, int lane, double* __restrict__ P, int PP) {
+    if constexpr (T0 < T1) {
+        if (wave != 0)
+            fp_for_tiles<T0, T1>([&](int t, double (&v)[4]) {
+                double* d = lds + ((wave - 1) * MEETN + (t - T0)) * 256 + lane * 4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            });
+        __syncthreads();
+        if (wave == 0)
+            fp_for_tiles<T0, T1>([&](int t, double (&v)[4]) {
+                int tj = 0;
+                while ((tj + 1) * (tj + 2) / 2 <= t) ++tj;
+                const int ti = t - tj * (tj + 1) / 2;
+                const double* s1 = lds + (t - T0) * 256 + lane * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double sum = ((v[r] + s1[r]) + s1[MEETN * 256 + r]) + s1[2 * MEETN * 256 + r];
+                    P[(int64_t)(ti * 16 + 4 * r + (lane >> 4)) * PP + tj * 16 + (lane & 15)] = sum;
+                }
+            });
+        __syncthreads();
+    }
+}
+template <int NT, int G>
+__device__ __forceinline__ void fp_meet_tails(double* lds, int wave, int lane, double* __restrict__ P, int PP) {
+    constexpr int NTRI = NT * (NT + 1) / 2, NTAIL = (NT + 1) * G;
+    if constexpr (NTAIL > 0) {
+        if (wave != 0)
+            fp_for_tails<NTRI, NTAIL, 0>([&](int k, double v) { lds[((wave - 1) * NTAIL + k) * 64 + lane] = v; });
+        __syncthreads();
+        if (wave == 0)
+            fp_for_tails<NTRI, NTAIL, 0>([&](int k, double v) {
+                const double* s1 = lds + k * 64 + lane;
+                const double sum = ((v + s1[0]) + s1[NTAIL * 64]) + s1[2 * NTAIL * 64];
+                const int gi = k / (NT + 1), t = k - gi * (NT + 1);
+                const int row = 16 * t + 4 * ((lane & 15) >> 2) + (lane >> 4), col = 16 * NT + 4 * gi + (lane & 3);
+                P[(int64_t)row * PP + col] = sum;
+            });
+        __syncthreads();
+    }
+}
+
+// segments SEG .. NARROW_NSEG - 1 of a k-step's MFMA block, with between(q) issued behind segment q
+template <int NT, int G, int SEG, typename F>
+__device__ __forceinline__ void fp_kstep_spread(const double (&f)[NT + (G > 0 ? 1 : 0)], const double (&g)[NT],
+                                                const double (&bt)[G > 0 ? G : 1], F&& between) {
+    if constexpr (SEG < NARROW_NSEG) {
+        narrow_kstep_seg<NT, G, SEG>(f, g, bt);
+        __builtin_amdgcn_sched_barrier(0);
+        between(std::integral_constant<int, SEG>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fp_kstep_spread<NT, G, SEG + 1>(f, g, bt, between);
+    }
+}
+
+// The logistic terms of eight rows (lane (j, s): row j, columns 16 q + 2 s + {0, 1}), cut into the pieces that ride behind
+// the ten MFMA segments of a chunk.  Everything a later piece needs lives in this struct's registers.
+template <int NTC>
+struct LogitState {
+    double x[NTC][2];         // the lane's columns of its row
+    double yv, eta, e, inv, mu, wgt, sv, num, den, q, kf, rr, resid;
+    bool big, valid;
+};
+
+template <bool WOUT, int NT, int G>
+__global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int KC = FP_KC, NWAVES = 4, THREADS = 256;
+    constexpr int NTC = NT + (G > 0 ? 1 : 0);
+    constexpr int LDP = fp_pitch(NTC), BUF = fp_buf(NTC), NTRI = NT * (NT + 1) / 2;
+    constexpr int GA = G > 0 ? G : 1;
+    constexpr int WOFF = KC * LDP, YOFF = KC * LDP + KC;               // the stage's w and y slots
+    constexpr int DMA_PER_CHUNK = KC / NWAVES + 1;                    // 8 row pieces + the y piece, per wave
+    constexpr int MEETN_FIT = (int)((size_t)FP_NST * BUF * 8 / (3 * 2048));
+    constexpr int MEETN = MEETN_FIT < NTRI ? MEETN_FIT : NTRI;
+    static_assert(3 * MEETN >= NTRI, "the tiles meet in at most three passes");
+    static_assert((size_t)3 * (NT + 1) * G * 64 <= (size_t)FP_NST * BUF, "tail meeting fits the ring");
+    static_assert(NARROW_NSEG == 5 && KC == 32, "piece schedule below: two k-steps of five segments per chunk");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool probe = blockIdx.x == 0 && wave == 0;
+    const unsigned long long t_begin = probe ? __builtin_readcyclecounter() : 0ull;
+    const int slab = blockIdx.x;
+    const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
+    const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
+    const int nrows = (int)(rend > rbeg ? rend - rbeg : 0);
+    const int nchunks = (nrows + KC - 1) / KC;
+
+    const unsigned xbytes = nrows > 0 ? (unsigned)(((int64_t)(nrows - 1) * a.ldx + a.p) * 8) : 0u;
+    __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + rbeg), 0, nrows * 8, 0x00020000);
+    // columns p .. 16 NTC - 1 are never written by the DMA (lanes masked): the ring is zeroed once
+    for (int e = tid; e < FP_NST * BUF; e += THREADS) lds[e] = 0.0;
+    __syncthreads();
+
+    const bool col_in = 2 * lane < a.p;
+    constexpr int RQ = KC / NWAVES / 4;                               // rows per wave and DMA part (two)
+    auto stage_rows = [&](int chunk, int buf, int q) {
+        double* base = lds + buf * BUF;
+#pragma unroll
+        for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
+            const int row = wave + NWAVES * ps;
+            const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, 0);
+        }
+    };
+    auto stage_y = [&](int chunk, int buf) {      // every wave fetches the chunk's y: the same in-order count in all waves
+        if (lane < KC / 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_ptr_t)(lds + buf * BUF + YOFF), 16, lane * 16, chunk * KC * 8, 0, 0);
+    };
+
+    // ---- the lane's share of beta and of g (columns 16 q + 2 s + {0, 1}); loglik
+    const int lj = lane >> 3, ls = lane & 7;
+    double bq[NTC][2], gacc[NTC][2];
+#pragma unroll
+    for (int q = 0; q < NTC; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int col = 16 * q + 2 * ls + e;
+            bq[q][e] = col < a.p ? a.beta[col] : 0.0;
+            gacc[q][e] = 0.0;
+        }
+    double llacc = 0.0;
+    // own rows of a chunk: k-step `wave` holds rows 4 wave .. + 3 (j < 4), k-step wave + 4 rows 16 + 4 wave .. + 3 (j >= 4)
+    const int own_row = (lj < 4 ? 4 * wave + lj : 16 + 4 * wave + (lj - 4));
+    const int xoff = own_row * LDP + 2 * ls;              // + 16 q: the lane's b128 of tile column q
+
+    LogitState<NTC> L;
+    // piece 0: the row's columns and its label out of LDS (chunk `chunk` in stage `buf`)
+    auto lp_read = [&](int chunk, int buf) {
+        const double* base = lds + buf * BUF;
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            const d2 v = *(const d2*)(base + xoff + 16 * q);
+            L.x[q][0] = v.x; L.x[q][1] = v.y;
+        }
+        L.yv = base[YOFF + own_row];
+        L.valid = chunk * KC + own_row < nrows;
+    };
+    auto lp_dot = [&]() {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
+        L.eta = s0 + s1;
+    };
+    auto lp_reduce = [&]() {                      // over the 8 lanes of the row: every lane ends with the row's eta
+        double s = L.eta;
+        s += dpp_xor_f64<1>(s);
+        s += dpp_xor_f64<2>(s);
+        s += dpp_xor_f64<4>(s);
+        L.eta = s;
+        const double aabs = fmin(fabs(s), 745.2);
+        L.kf = rint(aabs * 1.4426950408889634);
+        double r = fma(L.kf, 6.93147180369123816490e-01, -aabs);
+        L.rr = fma(L.kf, 1.90821492927058770002e-10, r);
+    };
+    auto lp_exp_a = [&]() {                       // exp(-|eta|): degree-13 polynomial, first half (logistic.h: exp_neg)
+        const double r = L.rr;
+        double q = 1.6059043836821613e-10;
+        q = fma(q, r, 2.08767569878681e-09);
+        q = fma(q, r, 2.505210838544172e-08);
+        q = fma(q, r, 2.755731922398589e-07);
+        q = fma(q, r, 2.7557319223985893e-06);
+        q = fma(q, r, 2.48015873015873e-05);
+        q = fma(q, r, 1.984126984126984e-04);
+        L.q = q;
+    };
+    auto lp_exp_b = [&]() {
+        const double r = L.rr;
+        double q = L.q;
+        q = fma(q, r, 1.388888888888889e-03);
+        q = fma(q, r, 8.333333333333333e-03);
+        q = fma(q, r, 4.1666666666666664e-02);
+        q = fma(q, r, 1.6666666666666666e-01);
+        q = fma(q, r, 0.5);
+        q = fma(q, r, 1.0);
+        q = fma(q, r, 1.0);
+        L.e = ldexp(q, -(int)L.kf);
+    };
+    auto lp_mu = [&](int buf) {                   // mu, w -> the stage's w slot (read back by this wave's MFMA part next chunk)
+        const double inv = rcp_newton(1.0 + L.e);
+        L.mu = L.eta >= 0.0 ? inv : L.e * inv;
+        L.wgt = L.e * inv * inv;
+        L.resid = L.yv - L.mu;
+        if (ls == 0) lds[buf * BUF + WOFF + own_row] = L.wgt;
+    };
+    auto lp_log_a = [&]() {                       // log1p(e), logistic.h: logistic_terms
+        L.big = L.e > 0.41421356237309503;
+        L.num = L.big ? fma(0.5, L.e, -0.5) : L.e;
+        L.den = L.big ? fma(0.5, L.e, 1.5) : 2.0 + L.e;
+        L.sv = L.num * rcp_newton(L.den);
+    };
+    auto lp_log_b = [&]() {
+        const double z = L.sv * L.sv;
+        double q = 1.0 / 21.0;
+        q = fma(q, z, 1.0 / 19.0);
+        q = fma(q, z, 1.0 / 17.0);
+        q = fma(q, z, 1.0 / 15.0);
+        q = fma(q, z, 1.0 / 13.0);
+        q = fma(q, z, 1.0 / 11.0);
+        L.q = q; L.num = z;
+    };
+    auto lp_log_c = [&](int chunk) {
+        const double z = L.num;
+        double q = L.q;
+        q = fma(q, z, 1.0 / 9.0);
+        q = fma(q, z, 1.0 / 7.0);
+        q = fma(q, z, 1.0 / 5.0);
+        q = fma(q, z, 1.0 / 3.0);
+        q = fma(q, z, 1.0);
+        const double l1p = fma(2.0 * L.sv, q, L.big ? 6.931471805599453094e-01 : 0.0);
+        const double softplus = fmax(L.eta, 0.0) + l1p;
+        // one lane per row counts; rows past the slab's end (zero-filled by the DMA's bounds check) do not
+        if (ls == 0 && L.valid) llacc += fma(L.yv, L.eta, -softplus);
+        if (!L.valid) L.resid = 0.0;
+        if (WOUT) {
+            if (ls == 0 && L.valid) a.w_out[rbeg + (int64_t)chunk * KC + own_row] = L.wgt;
+        }
+    };
+    auto lp_grad = [&]() {
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            gacc[q][0] = fma(L.resid, L.x[q][0], gacc[q][0]);
+            gacc[q][1] = fma(L.resid, L.x[q][1], gacc[q][1]);
+        }
+    };
+    auto logit_all = [&](int chunk, int buf) {    // the whole of it in one go (prologue: chunk 0)
+        lp_read(chunk, buf); lp_dot(); lp_reduce(); lp_exp_a(); lp_exp_b(); lp_mu(buf); lp_log_a(); lp_log_b(); lp_log_c(chunk); lp_grad();
+    };
+
+    narrow_acc_zero<fp_nreg(NT, G)>();
+
+    // ---- prologue: chunks 0 .. 2 in flight; chunks 0 and 1 landed; the logistic terms of chunk 0
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_rows(ch, ch, q);
+        stage_y(ch, ch);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    logit_all(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int frag_off = (lane >> 4) * LDP + (lane & 15);
+    const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
+        const double* base = lds + cur * BUF;
+        // this wave's fragments of chunk c, and the weights it computed for them one iteration ago
+        double f[2][NTC], wv[2], bt[2][GA];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ks = wave + 4 * kk;
+            const double* kb = base + ks * 4 * LDP;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) f[kk][t] = kb[frag_off + t * 16];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) bt[kk][gi] = kb[tail_off + 4 * gi];
+            wv[kk] = base[WOFF + ks * 4 + (lane >> 4)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            double g[NT], btw[GA];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) g[t] = f[kk][t] * wv[kk];
+#pragma unroll
+            for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? bt[kk][gi] * wv[kk] : 0.0;
+            if (kk == 0) {
+                // behind the five segments of the first k-step: the DMA of chunk c + 3 in five parts (every wave has left chunk c - 1,
+                // whose stage it overwrites) and the first half of the logistic terms of chunk c + 1
+                fp_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q < 4) stage_rows(c + 3, nxt3, q); else stage_y(c + 3, nxt3);
+                    if constexpr (q == 0) lp_read(c + 1, nxt);
+                    else if constexpr (q == 1) lp_dot();
+                    else if constexpr (q == 2) lp_reduce();
+                    else if constexpr (q == 3) lp_exp_a();
+                    else lp_exp_b();
+                });
+            } else {
+                fp_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q == 0) lp_mu(nxt);
+                    else if constexpr (q == 1) lp_log_a();
+                    else if constexpr (q == 2) lp_log_b();
+                    else if constexpr (q == 3) lp_log_c(c + 1);
+                    else lp_grad();
+                });
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 2 has landed (c + 3 is in flight)
+        asm volatile("s_barrier" ::: "memory");
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();
+
+    // ---- H: the four waves' triangles meet in LDS; wave 0 stores the slab's partial
+    double* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
+    fp_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
+    fp_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
+    fp_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
+    fp_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+
+    // ---- g and loglik: over the 8 rows of a wave (lanes with the same s: xor 8, 16, 32), then over the four waves in LDS
+#pragma unroll
+    for (int q = 0; q < NTC; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double s = gacc[q][e], u, v;
+            s += dpp_xor_f64<8>(s);
+            swap_f64<16>(s, s, u, v); s = u + v;
+            swap_f64<32>(s, s, u, v); s = u + v;
+            gacc[q][e] = s;
+        }
+    llacc = wave_allreduce_sum(llacc);
+    constexpr int GP = fp_gp(NTC);
+    if (lane < 8) {
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            lds[wave * GP + 16 * q + 2 * lane] = gacc[q][0];
+            lds[wave * GP + 16 * q + 2 * lane + 1] = gacc[q][1];
+        }
+        if (lane == 0) lds[wave * GP + 16 * NTC] = llacc;
+    }
+    __syncthreads();
+    if (tid <= 16 * NTC)
+        a.gpart[(int64_t)slab * GP + tid] = ((lds[tid] + lds[GP + tid]) + lds[2 * GP + tid]) + lds[3 * GP + tid];
+    if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
+}
+
+// g [p] and loglik: the slab partials in a fixed order
+__global__ __launch_bounds__(256) void irls_pass_finish_kernel(const double* __restrict__ gpart, int nslab, int GP, int p, int ll_at,
+                                                               double* __restrict__ g, double* __restrict__ loglik) {
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    const bool is_ll = col == p;                  // one extra "column": the log-likelihood
+    const int src = is_ll ? ll_at : col;
+    double s = 0.0;
+    if (col <= p)
+        for (int k = kg; k < nslab; k += 16) s += gpart[(int64_t)k * GP + src];
+    red[kg][cl] = s;
+    __syncthreads();
+    if (kg == 0 && col <= p) {
+        double t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        if (is_ll) { if (loglik) *loglik = t; }
+        else if (g) g[col] = t;
+    }
+}
+
+static void fp_shape(int p, int& nt, int& g) {
+    nt = p / 16;
+    g = (p - 16 * nt + 3) / 4;
+    if (g == 4) { ++nt; g = 0; }
+}
+
+static int fp_slabs(int64_t n, int64_t& rows_per_slab) {
+    int64_t ns = std::min<int64_t>(kNumCU, std::max<int64_t>(1, n / 2048));
+    rows_per_slab = ((n + ns - 1) / ns + FP_KC - 1) / FP_KC * FP_KC;
+    return (int)((n + rows_per_slab - 1) / rows_per_slab);
+}
+
+static size_t fp_pp(int p) { return ((size_t)(p + 15) / 16 * 16 + 63) / 64 * 64; }
+
+bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p) {
+    if (p < FP_MIN_P || p > FP_MAX_P || (p & 1) || n < FP_MIN_ROWS) return false;
+    const char* e = getenv("DLSA_IRLS_FUSED");
+    if (e && atoi(e) == 0) return false;          // A/B runs: the two-launch form
+    int64_t rps;
+    fp_slabs(n, rps);
+    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+           (double)(rps + 4 * FP_KC) * (double)ldx * 8.0 < 2.0e9;                    // 32-bit DMA offsets
+}
+
+static size_t fp_fused_ws_bytes(int64_t n, int p) {
+    int64_t rps;
+    const int ns = fp_slabs(n, rps);
+    int nt, g;
+    fp_shape(p, nt, g);
+    const int ntc = nt + (g > 0 ? 1 : 0);
+    return align_up((size_t)ns * fp_pp(p) * fp_pp(p) * 8, 256) + align_up((size_t)ns * fp_gp(ntc) * 8, 256) + kGramProbeBytes;
+}
+
+size_t irls_pass_workspace_bytes_impl(int64_t n, int p) {
+    size_t b = std::max(gram_workspace_bytes_impl(n, p, 8), logit_workspace_bytes_impl(n, p));
+    if (p >= FP_MIN_P && p <= FP_MAX_P && n >= FP_MIN_ROWS) b = std::max(b, fp_fused_ws_bytes(n, p));
+    return b;
+}
+
+// One Newton pass: the fused kernel where the shape allows it, else the logit pass + the Gram pass (two launches, w through
+// `w_out` or scratch).  `w_out` nullable (w_scratch [n] then carries w between the two launches of the unfused form).
+int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
+                   double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
+                   int* fused_out) {
+    DLSA_REQUIRE((X || n == 0) && (y || n == 0) && beta && H, "irls_pass: null argument");
+    DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p && ldh >= p, "irls_pass: bad shape n=%lld p=%d ldx=%lld ldh=%lld",
+                 (long long)n, p, (long long)ldx, (long long)ldh);
+    const bool fused = irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0);
+    if (fused_out) *fused_out = fused ? 1 : 0;
+    if (!fused) {
+        double* w = w_out ? w_out : w_scratch;
+        DLSA_REQUIRE(w || n == 0, "irls_pass: this shape takes the two-launch form, which needs w_out (or scratch) for the weights");
+        int rc = logit_pass_impl(X, ldx, y, beta, n, p, w, g, loglik, ws, ws_bytes, stream, 0);
+        if (rc) return rc;
+        return gram_impl_f64(X, ldx, w, n, p, H, ldh, 0, ws, ws_bytes, stream);
+    }
+    FusedArgs a;
+    a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p; a.PP = (int)fp_pp(p);
+    const int nslab = fp_slabs(n, a.rows_per_slab);
+    int nt, gt;
+    fp_shape(p, nt, gt);
+    const int ntc = nt + (gt > 0 ? 1 : 0), GP = fp_gp(ntc);
+    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), gpb = align_up((size_t)nslab * GP * 8, 256);
+    const size_t need = part + gpb + kGramProbeBytes;
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("irls_pass: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    a.partial = (double*)ws;
+    a.gpart = (double*)((char*)ws + part);
+    a.clk = (unsigned long long*)((char*)ws + part + gpb);
+#define DLSA_LAUNCH_FP(WO, NTV, GV) do { \
+        const size_t shm = (size_t)FP_NST * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, NTV, GV>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_FP_G(WO, NTV) do { switch (gt) { \
+        case 0: DLSA_LAUNCH_FP(WO, NTV, 0); break; case 1: DLSA_LAUNCH_FP(WO, NTV, 1); break; \
+        case 2: DLSA_LAUNCH_FP(WO, NTV, 2); break; default: DLSA_LAUNCH_FP(WO, NTV, 3); break; } } while (0)
+#define DLSA_LAUNCH_FP_NT(WO) do { switch (nt) { \
+        case 3: DLSA_LAUNCH_FP_G(WO, 3); break; case 4: DLSA_LAUNCH_FP_G(WO, 4); break; \
+        case 5: DLSA_LAUNCH_FP_G(WO, 5); break; case 6: DLSA_LAUNCH_FP_G(WO, 6); break; \
+        default: DLSA_LAUNCH_FP(WO, 7, 0); break; } } while (0)
+    if (w_out) DLSA_LAUNCH_FP_NT(true);
+    else DLSA_LAUNCH_FP_NT(false);
+#undef DLSA_LAUNCH_FP_NT
+#undef DLSA_LAUNCH_FP_G
+#undef DLSA_LAUNCH_FP
+    DLSA_HIP_CHECK(hipGetLastError());
+    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<%s,%d,%d>", w_out ? "true" : "false", nt > 6 ? 7 : nt, nt > 6 ? 0 : gt);
+    gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
+    hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((p + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, p,
+                       16 * ntc, g, loglik);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+}  // namespace dlsa
+
+extern "C" {
+
+size_t dlsa_irls_pass_workspace_bytes(int64_t n, int p) {
+    if (p <= 0 || p > 2048 || n < 0) return 0;
+    // the two-launch form keeps w in the workspace when the caller does not ask for it
+    return dlsa::irls_pass_workspace_bytes_impl(n, p) + dlsa::align_up((size_t)n * sizeof(double), 256);
+}
+
+int dlsa_irls_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H,
+                       int64_t ldh, double* g, double* loglik, double* w_out, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    const size_t pass = irls_pass_workspace_bytes_impl(n, p), wbytes = align_up((size_t)n * sizeof(double), 256);
+    if (!ws || ws_bytes < pass + wbytes || ((uintptr_t)ws & 255)) {
+        set_error("irls_pass: workspace %zu bytes needed (256-aligned), got %zu", pass + wbytes, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    const size_t pass_al = align_up(pass, 256);
+    return irls_pass_impl(X, ldx, y, beta, n, p, H, ldh, g, loglik, w_out, (double*)((char*)ws + pass_al), ws, pass_al,
+                          (hipStream_t)stream, nullptr);
+}
+
+}  // extern "C"

@@ -276,6 +276,27 @@ def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True, fit_inter
     return w, g, ll
 
 
+def irls_pass(X, y, beta, want_w=False):
+    """One Newton pass in ONE call (dlsa_irls_pass_f64): w = mu(1-mu) at beta, g = X'(y-mu), loglik and H = X' diag(w) X.
+    Narrow designs (49 <= p <= 112, even, aligned rows, n >= 8192) run the FUSED kernel -- one read of X; every other shape
+    the logit pass + the Gram pass behind the same entry (gram_last_kernel() names what ran).  Returns (H, g, loglik, w or None)."""
+    lib = _lib.load()
+    _require_gpu(X, y, beta)
+    _f64(X, "X"); _f64(y, "y"); _f64(beta, "beta")
+    n, p = X.shape
+    if y.numel() != n or beta.numel() != p:
+        raise ValueError("irls_pass: y must have n = %d and beta p = %d elements" % (n, p))
+    dev = X.device
+    H = torch.empty((p, p), dtype=torch.float64, device=dev)
+    g = torch.empty((p,), dtype=torch.float64, device=dev)
+    ll = torch.empty((1,), dtype=torch.float64, device=dev)
+    w = torch.empty((n,), dtype=torch.float64, device=dev) if want_w else None
+    ws = _workspace(lib.dlsa_irls_pass_workspace_bytes(n, p), dev)
+    check(lib.dlsa_irls_pass_f64(_ptr(X), _rowmajor(X), _ptr(y), _ptr(beta), n, p, _ptr(H), p, _ptr(g), _ptr(ll), _ptr(w),
+                                 _ptr(ws), ws.numel(), _stream()))
+    return H, g, ll, w
+
+
 def gram_icpt(X, w=None, out=None):
     """H = [1 | X]' diag(w) [1 | X], (p + 1) x (p + 1), without materialising the ones column (models.py:121-130)."""
     lib = _lib.load()

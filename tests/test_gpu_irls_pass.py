@@ -1,0 +1,100 @@
+"""GPU: the fused Newton pass (csrc/irls_pass.hip, dlsa_irls_pass_f64): w, g = X'(y - mu), loglik and H = X'WX in ONE read of
+the rows for narrow designs, against the oracle's logit_pass + gram (dlsa/models.py:110-114,130 restated) and against the
+two-launch form, over every shape class of the kernel; and the fit that uses it against the reference's goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available()
+    from dlsa_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# NT = 3..7 full tiles x G = 0..3 tail groups; ragged row counts (not a multiple of the 32-row chunk, of the slab)
+@pytest.mark.parametrize("p,n", [(50, 8192), (52, 9001), (56, 10000), (60, 12345), (64, 8200), (66, 20000), (72, 15000), (76, 9999),
+                                 (80, 30011), (84, 8192), (88, 17000), (92, 8193), (96, 40000), (100, 60000), (104, 25001),
+                                 (108, 33333), (112, 50001)])
+def test_fused_pass_matches_oracle(eng, orc, p, n):
+    X, y = orc.synth_logistic(300 + p, 0, n, p, orc.SYNTH_GAUSSIAN)
+    rng = np.random.default_rng(p)
+    beta = orc.true_beta(p) * 0.8 + 0.05 * rng.standard_normal(p)
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    Ho = orc.gram(X, wo)
+    H, g, ll, w = eng.irls_pass(dev(X), dev(y), dev(beta), want_w=True)
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<true"), eng.gram_last_kernel()
+    assert torch.equal(H, H.T)
+    assert rel_inf(w.cpu().numpy(), wo) < 1e-12
+    assert rel_inf(H.cpu().numpy(), Ho) < 1e-12
+    assert np.max(np.abs(g.cpu().numpy() - go)) < 1e-12 * np.max(np.abs(X).sum(0))       # a gradient near the MLE cancels: absolute scale
+    assert abs(float(ll) - llo) < 1e-12 * abs(llo)
+    # without w_out: the other instantiation, same bits for H / g / loglik; twice the same call: same bits (fixed orders)
+    H2, g2, ll2, _ = eng.irls_pass(dev(X), dev(y), dev(beta))
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<false")
+    assert torch.equal(H, H2) and torch.equal(g, g2) and torch.equal(ll, ll2)
+
+
+def test_fused_pass_equals_two_launch_form_and_extreme_eta(eng, monkeypatch):
+    """|eta| up to ~40 (w underflows towards 0, softplus is linear) and the two-launch form of the same entry point."""
+    n, p = 40000, 100
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    X = torch.randn((n, p), dtype=torch.float64, device="cuda", generator=gen)
+    beta = torch.randn(p, dtype=torch.float64, device="cuda", generator=gen) * 1.2
+    y = (torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) < 0.5).double()
+    H, g, ll, w = eng.irls_pass(X, y, beta, want_w=True)
+    monkeypatch.setenv("DLSA_IRLS_FUSED", "0")
+    H0, g0, ll0, w0 = eng.irls_pass(X, y, beta, want_w=True)
+    assert not eng.gram_last_kernel()[0].startswith("irls_pass")
+    assert float((w - w0).abs().max()) < 1e-14
+    assert float((H - H0).abs().max()) < 1e-12 * float(H0.abs().max())
+    assert float((g - g0).abs().max()) < 1e-11 * float(g0.abs().max())
+    assert abs(float(ll) - float(ll0)) < 1e-12 * abs(float(ll0))
+
+
+def test_other_shapes_take_the_two_launches(eng, orc):
+    for p, n in ((30, 9000), (101, 20000), (200, 9000), (100, 5000)):          # too narrow, odd, too wide, too few rows
+        X, y = orc.synth_logistic(p, 0, n, p)
+        beta = orc.true_beta(p) * 0.5
+        H, g, ll, w = eng.irls_pass(dev(X), dev(y), dev(beta), want_w=True)
+        assert not eng.gram_last_kernel()[0].startswith("irls_pass"), (p, n)
+        wo, go, llo = orc.logit_pass(X, y, beta)
+        assert rel_inf(H.cpu().numpy(), orc.gram(X, wo)) < 1e-12 and rel_inf(g.cpu().numpy(), go) < 1e-11
+
+
+def test_fused_pass_full_size_config2_properties(eng):
+    """BASELINE config 2 (n = 1e7, p = 100): the fused pass over the whole shard equals the sum of its parts over ragged
+    row blocks, and w / g / loglik / H those of the separate passes."""
+    n, p = 10_000_000, 100
+    X, y = eng.synth(20260101, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[:40] = 0.9
+    H, g, ll, _ = eng.irls_pass(X, y, beta)
+    assert eng.gram_last_kernel()[0] == "irls_pass_narrow_kernel<false,6,1>"
+    w0, g0, ll0 = eng.logit_pass(X, y, beta)
+    H0 = eng.gram(X, w0)
+    scale = float(H0.abs().max())
+    assert float((H - H0).abs().max()) < 1e-12 * scale
+    assert float((g - g0).abs().max()) < 1e-12 * scale and abs(float(ll) - float(ll0)) < 1e-12 * abs(float(ll0))
+    cut = (n // 3 // 7) * 7 + 5
+    Ha, ga, lla, _ = eng.irls_pass(X[:cut], y[:cut], beta)
+    Hb, gb, llb, _ = eng.irls_pass(X[cut:], y[cut:], beta)
+    assert float((Ha + Hb - H).abs().max()) < 1e-12 * scale
+    assert float((ga + gb - g).abs().max()) < 1e-12 * scale and abs(float(lla) + float(llb) - float(ll)) < 1e-12 * abs(float(ll))
