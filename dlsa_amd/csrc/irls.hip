@@ -29,6 +29,13 @@ namespace dlsa {
 int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
+// irls_pass.hip: one Newton pass in one launch where the shape allows it (narrow designs: the rows staged for the MFMAs also
+// feed the logistic terms -- one read of X per fresh Hessian instead of two)
+bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p);
+size_t irls_pass_workspace_bytes_impl(int64_t n, int p);
+int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
+                   double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
+                   int* fused_out);
 size_t logit_workspace_bytes_impl(int64_t n, int p);
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
                     double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept);
@@ -349,6 +356,10 @@ struct IrlsBuffers {
 struct IrlsData {
     std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s)> logit;
     std::function<int(const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s)> gram;
+    // optional: both passes of a fresh-Hessian iteration in ONE launch (w, g, ll as `logit`, H as `gram`); `fusable(nrows)`
+    // says whether that launch really is the fused kernel for this many leading rows (else logit + gram are called)
+    std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s)> pass;
+    std::function<bool(int64_t nrows)> fusable;
 };
 
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
@@ -397,14 +408,30 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     const size_t qn_shm = ((size_t)p + 16) * sizeof(double);
     *status = DLSA_PART_NOT_CONVERGED;
     *fresh = false;
+    const char* env_fl = getenv("DLSA_IRLS_FUSE_LAST");
+    const bool can_fuse = d.pass && d.fusable && d.fusable(n);
+    const bool fuse_last = can_fuse && (env_fl ? atoi(env_fl) != 0 : true);
+    bool peek_next = false;
     for (int it = 1; it <= max_iter; ++it) {
         ++*iters;
-        int rc = d.logit(b.beta, n, b.w, b.g, b.stats + 3, b, s);
-        if (rc) return rc;
         const bool fresh_now = need_H || !have_factor;
-        if (fresh_now) {
-            rc = d.gram(b.w, n, H, b, s);
+        // peek: the iteration expected to end the run takes the fused pass for the RESULT's Hessian only -- the step still comes
+        // from the factor in hand (no refactorisation, the secant pairs stay)
+        const bool peek = !fresh_now && peek_next && can_fuse;
+        peek_next = false;
+        int rc;
+        if ((fresh_now || peek) && can_fuse) {
+            rc = d.pass(b.beta, n, b.w, b.g, b.stats + 3, H, b, s);      // w, g, loglik and H in one read of the rows
             if (rc) return rc;
+        } else {
+            rc = d.logit(b.beta, n, b.w, b.g, b.stats + 3, b, s);
+            if (rc) return rc;
+            if (fresh_now) {
+                rc = d.gram(b.w, n, H, b, s);
+                if (rc) return rc;
+            }
+        }
+        if (fresh_now) {
             ++*gram_passes;
             gscale = 1.0;
             ord.m = 0;                               // a new H0: the old pairs go
@@ -505,7 +532,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         const double scale = std::max(1.0, h[1]);
         if (h[0] <= tol * scale) {
             *status = DLSA_PART_OK;
-            *fresh = fresh_now;
+            *fresh = fresh_now || peek;
             return DLSA_OK;
         }
         // Predicted convergence: the steps have contracted by r <= 0.2 twice in a row, this one is within 10 tol, and the
@@ -521,13 +548,27 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 rc = launch_axpby(b.beta, b.delta, 1.0, p, b.beta, s);
                 if (rc) return rc;
                 *status = DLSA_PART_OK;
-                *fresh = false;
+                // the closing Gram of irls_fit_core would use b.w of THIS iterate: when this iteration evaluated H (from the
+                // same w) the matrix is already there
+                *fresh = fresh_now || peek;
                 return DLSA_OK;
             }
         }
         // frozen-Hessian policy: keep the factor while steps are small and still shrinking fast
         if (!fresh_now && h[0] > 0.25 * dprev) need_H = true;            // stalled: refresh
         else need_H = h[0] > freeze_at * scale;
+        // The iteration that is expected to CONVERGE runs fused: when the steps contract at rate r and the next one (<= r |delta|)
+        // would pass the test, that iteration's logit pass would be followed by the closing Gram of irls_fit_core at the same
+        // beta -- two reads of the rows; the fused pass gives the converged check and Sig_inv in one.  A wrong guess costs the
+        // difference between a fused pass and a logit pass and buys a fresh Hessian.
+        if (fuse_last && !need_H && isfinite(dprev) && h[0] < dprev) {
+            // secant-corrected steps contract faster and faster (observed at p = 100: 6.8e-3, 1.1e-3, 9.5e-5): extrapolate the
+            // rate by its own trend.  "Ends the run" = passes the step test, or takes the predicted-convergence exit above.
+            double r = h[0] / dprev;
+            if (isfinite(dprev2) && dprev < dprev2) r *= std::min(1.0, r / (dprev / dprev2));
+            const double next = r * h[0];
+            if (next <= tol * scale || (predict_on && next <= 10.0 * tol * scale && r * next <= tol * scale)) peek_next = true;
+        }
         dprev2 = dprev;
         dprev = h[0];
         DLSA_HIP_CHECK(hipMemcpyAsync(b.prev, b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -737,7 +778,7 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
 }
 
 static size_t dense_pass_bytes(int64_t rows, int p) {
-    return std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p));
+    return std::max(irls_pass_workspace_bytes_impl(rows, p), std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p)));
 }
 
 // ---- implicit intercept (the ones column of models.py:121-122 is never materialised) --------------------------------
@@ -802,6 +843,10 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
             return gram_impl_f64(Xk, ldx, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
         };
+        d.pass = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s) {
+            return irls_pass_impl(Xk, ldx, yk, beta, nrows, p, H, p, g, ll, w, nullptr, b.ws_pass, b.ws_pass_bytes, s, nullptr);
+        };
+        d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, ldx, yk, nrows, p); };
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, part_offsets_host, K, p, tol,
@@ -862,6 +907,12 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
             if (intercept) return gram_icpt_impl(Xk, pitch, w, nrows, p, H, pe, b.ws_pass, b.ws_pass_bytes, s);
             return gram_impl_f64(Xk, pitch, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
         };
+        if (!intercept) {        // (the implicit intercept's border needs its own streaming pass: those fits keep the two launches)
+            d.pass = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s) {
+                return irls_pass_impl(Xk, pitch, yk, beta, nrows, p, H, p, g, ll, w, nullptr, b.ws_pass, b.ws_pass_bytes, s, nullptr);
+            };
+            d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, pitch, yk, nrows, p); };
+        }
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },
