@@ -143,7 +143,9 @@ struct LogitState {
     bool big, valid;
 };
 
-template <bool WOUT, int NT, int G>
+// HESS = false: the same streaming skeleton without the Hessian -- the logit pass of narrow designs (w, g, loglik) fed by the
+// LDS-DMA ring instead of logit.hip's register loads
+template <bool WOUT, bool HESS, int NT, int G>
 __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
         L.mu = L.eta >= 0.0 ? inv : L.e * inv;
         L.wgt = L.e * inv * inv;
         L.resid = L.yv - L.mu;
-        if (ls == 0) lds[buf * BUF + WOFF + own_row] = L.wgt;
+        if (HESS && ls == 0) lds[buf * BUF + WOFF + own_row] = L.wgt;
     };
     auto lp_log_a = [&]() {                       // log1p(e), logistic.h: logistic_terms
         L.big = L.e > 0.41421356237309503;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
         lp_read(chunk, buf); lp_dot(); lp_reduce(); lp_exp_a(); lp_exp_b(); lp_mu(buf); lp_log_a(); lp_log_b(); lp_log_c(chunk); lp_grad();
     };
 
-    narrow_acc_zero<fp_nreg(NT, G)>();
+    if constexpr (HESS) narrow_acc_zero<fp_nreg(NT, G)>();
 
     // ---- prologue: chunks 0 .. 2 in flight; chunks 0 and 1 landed; the logistic terms of chunk 0
 #pragma unroll
@@ -328,7 +330,21 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);
     int cur = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    if constexpr (!HESS) {
+        for (int c = 0; c < nchunks; ++c) {
+            const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stage_rows(c + 3, nxt3, q);
+            stage_y(c + 3, nxt3);
+            __builtin_amdgcn_sched_barrier(0);
+            logit_all(c + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            cur = nxt;
+        }
+    }
+    for (int c = 0; HESS && c < nchunks; ++c) {
         const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
         const double* base = lds + cur * BUF;
         // this wave's fragments of chunk c, and the weights it computed for them one iteration ago
@@ -382,11 +398,13 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
     __syncthreads();
 
     // ---- H: the four waves' triangles meet in LDS; wave 0 stores the slab's partial
-    double* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
-    fp_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
-    fp_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
-    fp_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
-    fp_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+    if constexpr (HESS) {
+        double* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
+        fp_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
+        fp_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
+        fp_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
+        fp_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+    }
 
     // ---- g and loglik: over the 8 rows of a wave (lanes with the same s: xor 8, 16, 32), then over the four waves in LDS
 #pragma unroll
@@ -457,7 +475,7 @@ bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int
     if (e && atoi(e) == 0) return false;          // A/B runs: the two-launch form
     int64_t rps;
     fp_slabs(n, rps);
-    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0 &&          // (the y pieces are dword-aligned buffer loads)
            (double)(rps + 4 * FP_KC) * (double)ldx * 8.0 < 2.0e9;                    // 32-bit DMA offsets
 }
 
@@ -481,7 +499,7 @@ size_t irls_pass_workspace_bytes_impl(int64_t n, int p) {
 int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
                    double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
                    int* fused_out) {
-    DLSA_REQUIRE((X || n == 0) && (y || n == 0) && beta && H, "irls_pass: null argument");
+    DLSA_REQUIRE((X || n == 0) && (y || n == 0) && beta, "irls_pass: null argument");      // H == nullptr: the logit pass alone
     DLSA_REQUIRE(p > 0 && p <= 2048 && n >= 0 && ldx >= p && ldh >= p, "irls_pass: bad shape n=%lld p=%d ldx=%lld ldh=%lld",
                  (long long)n, p, (long long)ldx, (long long)ldh);
     const bool fused = irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0);
@@ -490,7 +508,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
         double* w = w_out ? w_out : w_scratch;
         DLSA_REQUIRE(w || n == 0, "irls_pass: this shape takes the two-launch form, which needs w_out (or scratch) for the weights");
         int rc = logit_pass_impl(X, ldx, y, beta, n, p, w, g, loglik, ws, ws_bytes, stream, 0);
-        if (rc) return rc;
+        if (rc || !H) return rc;
         return gram_impl_f64(X, ldx, w, n, p, H, ldh, 0, ws, ws_bytes, stream);
     }
     FusedArgs a;
@@ -499,7 +517,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     int nt, gt;
     fp_shape(p, nt, gt);
     const int ntc = nt + (gt > 0 ? 1 : 0), GP = fp_gp(ntc);
-    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), gpb = align_up((size_t)nslab * GP * 8, 256);
+    const size_t part = H ? align_up((size_t)nslab * a.PP * a.PP * 8, 256) : 0, gpb = align_up((size_t)nslab * GP * 8, 256);
     const size_t need = part + gpb + kGramProbeBytes;
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
         set_error("irls_pass: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
@@ -508,11 +526,12 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     a.partial = (double*)ws;
     a.gpart = (double*)((char*)ws + part);
     a.clk = (unsigned long long*)((char*)ws + part + gpb);
-#define DLSA_LAUNCH_FP(WO, NTV, GV) do { \
+#define DLSA_LAUNCH_FP2(WO, HS, NTV, GV) do { \
         const size_t shm = (size_t)FP_NST * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
-        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, NTV, GV>), \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, HS, NTV, GV>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, HS, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_FP(WO, NTV, GV) do { if (H) DLSA_LAUNCH_FP2(WO, true, NTV, GV); else DLSA_LAUNCH_FP2(WO, false, NTV, GV); } while (0)
 #define DLSA_LAUNCH_FP_G(WO, NTV) do { switch (gt) { \
         case 0: DLSA_LAUNCH_FP(WO, NTV, 0); break; case 1: DLSA_LAUNCH_FP(WO, NTV, 1); break; \
         case 2: DLSA_LAUNCH_FP(WO, NTV, 2); break; default: DLSA_LAUNCH_FP(WO, NTV, 3); break; } } while (0)
@@ -525,9 +544,11 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
 #undef DLSA_LAUNCH_FP_NT
 #undef DLSA_LAUNCH_FP_G
 #undef DLSA_LAUNCH_FP
+#undef DLSA_LAUNCH_FP2
     DLSA_HIP_CHECK(hipGetLastError());
-    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<%s,%d,%d>", w_out ? "true" : "false", nt > 6 ? 7 : nt, nt > 6 ? 0 : gt);
-    gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
+    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<%s,%s,%d,%d>", w_out ? "true" : "false", H ? "true" : "false", nt > 6 ? 7 : nt,
+                     nt > 6 ? 0 : gt);
+    if (H) gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
     hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((p + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, p,
                        16 * ntc, g, loglik);
     DLSA_HIP_CHECK(hipGetLastError());

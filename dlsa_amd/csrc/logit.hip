@@ -353,6 +353,12 @@ size_t logit_workspace_bytes_impl(int64_t n, int p) {
            2 * align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
 }
 
+// irls_pass.hip: the streaming skeleton of the fused Newton pass (rows through an LDS-DMA ring) without the Hessian
+bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p);
+int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
+                   double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
+                   int* fused_out);
+
 // intercept != 0: beta and g have p + 1 entries, [intercept | the p columns of X]; X itself has p columns.
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
                     double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept) {
@@ -363,6 +369,13 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     if (!ws || ws_bytes < logit_workspace_bytes_impl(n, p) || ((uintptr_t)ws & 255)) {
         set_error("logit_pass: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
         return DLSA_ERR_WORKSPACE;
+    }
+    // Narrow designs (49 <= p <= 112, aligned rows): the rows come through the LDS-DMA ring of the fused Newton pass, which streams
+    // at the HBM rate where this kernel's register loads reach 5.2-5.5 TB/s (DLSA_LOGIT_RING=0: keep the register-load kernel).
+    if (!intercept && irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0)) {
+        const char* e = getenv("DLSA_LOGIT_RING");
+        if (!e || atoi(e) != 0)
+            return irls_pass_impl(X, ldx, y, beta, n, p, nullptr, p, g, loglik, w_out, nullptr, ws, ws_bytes, stream, nullptr);
     }
     Arena ar(ws, ws_bytes);
     LogitArgs a;

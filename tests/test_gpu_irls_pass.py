@@ -41,7 +41,7 @@ def test_fused_pass_matches_oracle(eng, orc, p, n):
     wo, go, llo = orc.logit_pass(X, y, beta)
     Ho = orc.gram(X, wo)
     H, g, ll, w = eng.irls_pass(dev(X), dev(y), dev(beta), want_w=True)
-    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<true"), eng.gram_last_kernel()
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<true,true"), eng.gram_last_kernel()
     assert torch.equal(H, H.T)
     assert rel_inf(w.cpu().numpy(), wo) < 1e-12
     assert rel_inf(H.cpu().numpy(), Ho) < 1e-12
@@ -49,7 +49,7 @@ def test_fused_pass_matches_oracle(eng, orc, p, n):
     assert abs(float(ll) - llo) < 1e-12 * abs(llo)
     # without w_out: the other instantiation, same bits for H / g / loglik; twice the same call: same bits (fixed orders)
     H2, g2, ll2, _ = eng.irls_pass(dev(X), dev(y), dev(beta))
-    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<false")
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<false,true")
     assert torch.equal(H, H2) and torch.equal(g, g2) and torch.equal(ll, ll2)
 
 
@@ -87,7 +87,7 @@ def test_fused_pass_full_size_config2_properties(eng):
     X, y = eng.synth(20260101, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
     beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[:40] = 0.9
     H, g, ll, _ = eng.irls_pass(X, y, beta)
-    assert eng.gram_last_kernel()[0] == "irls_pass_narrow_kernel<false,6,1>"
+    assert eng.gram_last_kernel()[0] == "irls_pass_narrow_kernel<false,true,6,1>"
     w0, g0, ll0 = eng.logit_pass(X, y, beta)
     H0 = eng.gram(X, w0)
     scale = float(H0.abs().max())
@@ -98,3 +98,26 @@ def test_fused_pass_full_size_config2_properties(eng):
     Hb, gb, llb, _ = eng.irls_pass(X[cut:], y[cut:], beta)
     assert float((Ha + Hb - H).abs().max()) < 1e-12 * scale
     assert float((ga + gb - g).abs().max()) < 1e-12 * scale and abs(float(lla) + float(llb) - float(ll)) < 1e-12 * abs(float(ll))
+
+
+def test_ring_logit_pass_is_block_invariant_and_handles_odd_label_offsets(eng, orc):
+    """The narrow logit pass now streams through the same LDS-DMA ring (irls_pass_narrow_kernel<*, false, ...>): w of a row
+    must not depend on how the rows are cut into calls (odd cuts leave y 8 bytes off a 16-byte boundary), g and loglik add up."""
+    n, p = 50001, 100
+    X, y = orc.synth_logistic(77, 0, n, p, orc.SYNTH_GAUSSIAN)
+    beta = orc.true_beta(p) * 0.7
+    Xd, yd, bd = dev(X), dev(y), dev(beta)
+    w, g, ll = eng.logit_pass(Xd, yd, bd)
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<true,false"), eng.gram_last_kernel()
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    assert rel_inf(w.cpu().numpy(), wo) < 1e-12 and np.max(np.abs(g.cpu().numpy() - go)) < 1e-12 * np.max(np.abs(X).sum(0))
+    assert abs(float(ll) - llo) < 1e-12 * abs(llo)
+    for cut in (20001, 8193, 30000):
+        w1, g1, l1 = eng.logit_pass(Xd[:cut], yd[:cut], bd)
+        w2, g2, l2 = eng.logit_pass(Xd[cut:], yd[cut:], bd)
+        assert torch.equal(torch.cat([w1, w2]), w), cut
+        assert float((g1 + g2 - g).abs().max()) < 1e-11 * float(g.abs().max())
+        assert abs(float(l1 + l2 - ll)) < 1e-12 * abs(float(ll))
+    # g only / loglik only / w only
+    _, g3, _ = eng.logit_pass(Xd, yd, bd, want_w=False, want_loglik=False)
+    assert torch.equal(g3, g)
