@@ -19,6 +19,7 @@ struct RcclApi {
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";      // dlerror() of the failed dlopen, captured once (a second dlerror() call returns NULL)
 };
 
 static RcclApi& rccl() {
@@ -31,7 +32,13 @@ static RcclApi& rccl() {
         api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (api.handle) break;
     }
-    for (size_t i = 0; !api.handle && i < sizeof(names) / sizeof(names[0]); ++i) api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    for (size_t i = 0; !api.handle && i < sizeof(names) / sizeof(names[0]); ++i) {
+        api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) {
+            const char* e = dlerror();
+            if (e) snprintf(api.why, sizeof(api.why), "%s", e);
+        }
+    }
     if (!api.handle) return api;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
@@ -53,7 +60,7 @@ static RcclApi& rccl() {
     } while (0)
 
 static int need_rccl() {
-    if (!rccl().ok) { set_error("RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return DLSA_ERR_HIP; }
+    if (!rccl().ok) { set_error("RCCL (librccl.so) could not be loaded: %s", rccl().why); return DLSA_ERR_HIP; }
     return DLSA_OK;
 }
 

@@ -167,6 +167,7 @@ int sym_pinv_solve_impl(const double* S, int64_t lds, const double* v, int p, do
     const int64_t mm = (int64_t)m * m;
     hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, S, lds, p, m, A[0], V[0], acc);
     int cur = 0, sweeps = 0;
+    bool settled = m <= 1;
     const dim3 blk(32, 8), grd((half + 31) / 32, (half + 7) / 8);
     const int red_blocks = (int)std::min<int64_t>(256, (mm + 255) / 256);
     for (int sweep = 0; sweep < 40 && m > 1; ++sweep) {
@@ -181,7 +182,11 @@ int sym_pinv_solve_impl(const double* S, int64_t lds, const double* v, int p, do
         DLSA_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, s));
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
         if (h[2] != 0.0 || !isfinite(h[0]) || !isfinite(h[1])) { set_error("sym_pinv_solve: NaN/Inf in the system"); return DLSA_ERR_NAN; }
-        if (h[0] <= 1e-30 * (h[0] + h[1])) break;            // off-diagonal mass below 1e-15 of the Frobenius norm
+        if (h[0] <= 1e-30 * (h[0] + h[1])) { settled = true; break; }      // off-diagonal mass below 1e-15 of the Frobenius norm
+    }
+    if (!settled) {          // 40 sweeps without reaching the target: say so instead of returning a half-diagonalised spectrum
+        set_error("sym_pinv_solve: the Jacobi iteration did not reach its off-diagonal target in %d sweeps (p = %d)", sweeps, p);
+        return DLSA_ERR_NOT_CONVERGED;
     }
     DLSA_HIP_CHECK(hipMemsetAsync(rank, 0, sizeof(int), s));
     hipLaunchKernelGGL(pinv_project_kernel, dim3((m + 255) / 256), dim3(256), 0, s, (const double*)A[cur], (const double*)V[cur], m, p, v,
@@ -251,8 +256,17 @@ int dlsa_wls_solve_f64(const double* S, int64_t lds, const double* v, int p, dou
     if (h[2] == 2.0) { set_error("wls_solve: NaN/Inf in the system"); return DLSA_ERR_NAN; }
     bool full = (h[2] == 0.0);
     const double thresh = 8.0 * 2.220446049250313e-16 * p;
-    for (int i = 0; i < p && full; ++i)
+    double lmin = INFINITY, smax = 0.0;
+    for (int i = 0; i < p && full; ++i) {
         if (!(dl[i] * dl[i] > thresh * fabs(ds[i])) || !isfinite(dl[i])) full = false;
+        lmin = fmin(lmin, dl[i] * dl[i]);
+        smax = fmax(smax, fabs(ds[i]));
+    }
+    // lstsq(rcond=None) cuts singular values relative to the LARGEST one (eps p sigma_max), not relative to a pivot's own diagonal
+    // entry: a badly scaled SPD sum -- diag(1, 1e-20), unstandardised columns with cond > 1 / (eps p) -- passes the test above
+    // and would return S^-1 v where numpy returns the truncated minimum-norm solution.  min L_ii^2 <= lambda_min-ish and
+    // max S_ii <= lambda_max <= p max S_ii bracket the condition number cheaply; below the cut the spectral path decides.
+    if (full && !(lmin > 2.220446049250313e-16 * p * smax)) full = false;
     if (full) { if (rank_host) *rank_host = p; return DLSA_OK; }
     // 2. rank-deficient (or indefinite): minimum-norm least-squares solution, lstsq(rcond=None) semantics
     return sym_pinv_solve_impl(S, lds, v, p, 2.220446049250313e-16 * p, theta, rank_host, nullptr, nullptr, ws, ws_bytes, s);

@@ -344,32 +344,36 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
             cur = nxt;
         }
     }
-    for (int c = 0; HESS && c < nchunks; ++c) {
-        const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
-        const double* base = lds + cur * BUF;
-        // this wave's fragments of chunk c, and the weights it computed for them one iteration ago
-        double f[2][NTC], wv[2], bt[2][GA];
+    // The fragments of chunk c + 1 (landed since the last barrier) and the weights just computed for it are requested at the END of
+    // iteration c, in front of the barrier: the LDS latency passes while the wave waits there, and the next iteration starts on its
+    // MFMAs at once.  Two register sets, the loop unrolled over them (no copies).
+    struct Frags { double f[2][NTC], wv[2], bt[2][GA]; };
+    auto load_frags = [&](int buf, Frags& fr) {
+        const double* base = lds + buf * BUF;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int ks = wave + 4 * kk;
             const double* kb = base + ks * 4 * LDP;
 #pragma unroll
-            for (int t = 0; t < NTC; ++t) f[kk][t] = kb[frag_off + t * 16];
+            for (int t = 0; t < NTC; ++t) fr.f[kk][t] = kb[frag_off + t * 16];
 #pragma unroll
-            for (int gi = 0; gi < G; ++gi) bt[kk][gi] = kb[tail_off + 4 * gi];
-            wv[kk] = base[WOFF + ks * 4 + (lane >> 4)];
+            for (int gi = 0; gi < G; ++gi) fr.bt[kk][gi] = kb[tail_off + 4 * gi];
+            fr.wv[kk] = base[WOFF + ks * 4 + (lane >> 4)];
         }
+    };
+    auto iteration = [&](int c, const Frags& fr, Frags& fnext) {
+        const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             double g[NT], btw[GA];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) g[t] = f[kk][t] * wv[kk];
+            for (int t = 0; t < NT; ++t) g[t] = fr.f[kk][t] * fr.wv[kk];
 #pragma unroll
-            for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? bt[kk][gi] * wv[kk] : 0.0;
+            for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? fr.bt[kk][gi] * fr.wv[kk] : 0.0;
             if (kk == 0) {
                 // behind the five segments of the first k-step: the DMA of chunk c + 3 in five parts (every wave has left chunk c - 1,
                 // whose stage it overwrites) and the first half of the logistic terms of chunk c + 1
-                fp_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](auto qc) {
+                fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     if constexpr (q < 4) stage_rows(c + 3, nxt3, q); else stage_y(c + 3, nxt3);
                     if constexpr (q == 0) lp_read(c + 1, nxt);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
                     else lp_exp_b();
                 });
             } else {
-                fp_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](auto qc) {
+                fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     if constexpr (q == 0) lp_mu(nxt);
                     else if constexpr (q == 1) lp_log_a();
@@ -389,9 +393,20 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
                 });
             }
         }
+        load_frags(nxt, fnext);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 2 has landed (c + 3 is in flight)
         asm volatile("s_barrier" ::: "memory");
         cur = nxt;
+    };
+    if constexpr (HESS) {
+        Frags fa, fb;
+        load_frags(0, fa);
+        // an odd chunk count runs one chunk past the slab's end: zero rows through the DMA's bounds check, masked in the logistic sums
+        for (int c = 0; c < nchunks; c += 2) {
+            iteration(c, fa, fb);
+            iteration(c + 1, fb, fa);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");

@@ -188,30 +188,46 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
                 if (j < pe) { stepv[j] *= 0.5; beta[j] = prev[j] + stepv[j]; }
                 state = 3;
             } else {
+                // One wave, lane = row, data passed between lanes through LDS: every store that another lane reads next is followed by
+                // a wavefront-scope release / acquire + wave barrier -- lock-step execution alone is not part of the memory model, and
+                // nothing else stops the compiler from hoisting the next column's loads above these stores.
+                auto wave_sync = [&]() {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
                 for (int c = 0; c < pe; ++c) if (j < pe && c <= j) Ls[j * SM_LD + c] = Hs[j * SM_LD + c];
+                wave_sync();
                 bool ok = true;
                 for (int c = 0; c < pe; ++c) {
                     const double d = Ls[c * SM_LD + c];
                     if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
                     const double s = sqrt(d);
                     if (j >= c && j < pe) Ls[j * SM_LD + c] = (j == c) ? s : Ls[j * SM_LD + c] / s;
+                    wave_sync();                            // column c is scaled: the trailing update reads other lanes' entries of it
                     if (j > c && j < pe) {
                         const double ljc = Ls[j * SM_LD + c];
                         for (int m = c + 1; m <= j; ++m) Ls[j * SM_LD + m] -= ljc * Ls[m * SM_LD + c];
                     }
+                    wave_sync();
                 }
                 if (!ok) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NOT_SPD; }
                 else {
                     if (j < pe) bs[j] = gs[j];
+                    wave_sync();
                     for (int c = 0; c < pe; ++c) {          // L z = g
                         const double z = bs[c] / Ls[c * SM_LD + c];
+                        wave_sync();                        // every lane has read bs[c] before lane c overwrites it
                         if (j == c) bs[c] = z;
                         if (j > c && j < pe) bs[j] -= Ls[j * SM_LD + c] * z;
+                        wave_sync();
                     }
                     for (int c = pe - 1; c >= 0; --c) {     // L' delta = z
                         const double z = bs[c] / Ls[c * SM_LD + c];
+                        wave_sync();
                         if (j == c) bs[c] = z;
                         if (j < c) bs[j] -= Ls[c * SM_LD + j] * z;
+                        wave_sync();
                     }
                     const double dj = j < pe ? bs[j] : 0.0, bj = j < pe ? beta[j] : 0.0;
                     const double dmax = wave_allreduce_max(fabs(dj)), bmax = wave_allreduce_max(fabs(bj));

@@ -55,23 +55,36 @@ def _f64(t, name, dtype=torch.float64):
     return t
 
 
+_WS_MAX_STREAMS = 4
+
+
 def _workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, current stream), 256-byte aligned by the torch allocator.  The C ABI is
-    re-entrant across streams as long as concurrent calls bring their own workspace: work enqueued on two streams must
-    not share scratch, and work on ONE stream is ordered, so a buffer per stream is exactly enough."""
+    """Scratch buffer per (device, current stream), 256-byte aligned by the torch allocator.  The C ABI is re-entrant across
+    streams as long as concurrent calls bring their own workspace: work enqueued on two streams must not share scratch, and
+    work on ONE stream is ordered, so a buffer per stream is exactly enough.  The cache is an LRU of _WS_MAX_STREAMS streams
+    (a Gram scratch is ~0.5 GB at p = 500: a stream-per-request caller must not pin one per short-lived stream forever);
+    an evicted buffer goes back to torch's stream-aware allocator, which keeps it alive until the work queued on it is done.
+    release_workspace() drops everything."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
+    buf = _ws_cache.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = None
-        _ws_cache.pop(key, None)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    _ws_cache[key] = buf                     # (re)inserted last: dict order is the LRU order
+    while len(_ws_cache) > _WS_MAX_STREAMS:
+        old = next(iter(_ws_cache))
+        victim = _ws_cache.pop(old)
+        victim.record_stream(torch.cuda.current_stream(device))      # conservative: not reused before this stream's queued work
+        del victim
     return buf
 
 
 def release_workspace():
     _ws_cache.clear()
+
+
+release_workspaces = release_workspace
 
 
 def _rowmajor(X):

@@ -205,3 +205,21 @@ def test_bench_refuses_world_size_mismatch():
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, text=True, timeout=300)
     assert pr.returncode != 0 and "WORLD_SIZE" in pr.stderr
+
+
+def test_workspace_cache_is_bounded_per_stream(eng):
+    """the per-stream scratch cache was grow-only with no eviction.  Six short-lived streams touching the Gram must
+    leave at most engine._WS_MAX_STREAMS buffers behind, results staying right on every stream."""
+    X = torch.randn((20000, 64), dtype=torch.float64, device="cuda")
+    ref = X.T @ X
+    eng.release_workspace()
+    for _ in range(6):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            H = eng.gram(X)
+        st.synchronize()
+        assert float((H - ref).abs().max()) < 1e-11 * float(ref.abs().max())
+        assert len(eng._ws_cache) <= eng._WS_MAX_STREAMS
+    eng.release_workspaces()
+    assert len(eng._ws_cache) == 0

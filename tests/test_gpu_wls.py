@@ -104,3 +104,23 @@ def test_all_zero_blocks_give_the_zero_estimate(eng):
     with pytest.warns(UserWarning, match="rank 0"):
         out = dlsa_amd.dlsa_mapred(mb)
     assert np.all(out["beta_byOLS"].to_numpy() == 0.0) and np.all(out["beta_byONESHOT"].to_numpy() == 0.0)
+
+
+def test_badly_scaled_spd_sum_follows_lstsq_not_cholesky():
+    """lstsq(rcond=None) cuts singular values relative to sigma_MAX.  diag(1, 1e-20) factors without a failing
+    pivot (each pivot is fine relative to its own diagonal entry) but numpy returns the truncated minimum-norm solution."""
+    from dlsa_amd import engine as eng
+    for S, v in ((np.diag([1.0, 1e-20]), np.array([2.0, 3e-20])),
+                 (np.diag([4.0, 1.0, 1e-18, 2.0]), np.array([1.0, -1.0, 1e-18, 0.5]))):
+        ref = np.linalg.lstsq(S, v, rcond=None)[0]
+        th, rank = eng.wls_solve(torch.from_numpy(S).cuda(), torch.from_numpy(v).cuda())
+        assert rank == np.linalg.matrix_rank(S)
+        assert np.allclose(th.cpu().numpy(), ref, rtol=1e-12, atol=1e-14), (th, ref)
+    # a well-scaled but wide-range SPD matrix (cond 1e8) still takes the Cholesky path and solves exactly
+    rng = np.random.default_rng(4)
+    Q, _ = np.linalg.qr(rng.standard_normal((40, 40)))
+    S = Q @ np.diag(np.logspace(0, 8, 40)) @ Q.T
+    S = (S + S.T) / 2
+    v = rng.standard_normal(40)
+    th, rank = eng.wls_solve(torch.from_numpy(S).cuda(), torch.from_numpy(v).cuda())
+    assert rank == 40 and np.allclose(S @ th.cpu().numpy(), v, rtol=1e-6, atol=1e-6)
