@@ -132,7 +132,8 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
     del Xc, yc, H
     torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
     t0 = time.perf_counter()
-    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=chunk_rows, fit_intercept=True, dtype=dt)
+    overlap = os.environ.get("DLSA_C5_OVERLAP", "0") != "0"
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=chunk_rows, fit_intercept=True, dtype=dt, overlap=overlap)
     torch.cuda.synchronize(); t_map = time.perf_counter() - t0
     peak = torch.cuda.max_memory_allocated() - base
     t1 = time.perf_counter()
@@ -146,7 +147,7 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
             "gram_rows_per_s": rows_max / t_gram, "gram_TF_alg": rows_max * fl / t_gram / 1e12,
             "stats_GBps": rows_max * 4 * (p + 1) / t_stats / 1e9, "map_fit_s": t_map, "map_rows_per_s": n / t_map,
             "map_TF_alg_incl_generation": n * fl / t_map / 1e12, "reduce_lars_s": t_rest, "peak_device_bytes": peak,
-            "status_ok": all(v == 0 for v in mb.status),
+            "status_ok": all(v == 0 for v in mb.status), "generation_overlapped": overlap,
             "theta_err_linf": float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth)))}
 
 

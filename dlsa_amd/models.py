@@ -313,13 +313,16 @@ def fit_linear_partitions(X, y, partition_num=None, part_offsets=None, fit_inter
 
 
 def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=20260101, row0=0, kind="gaussian", sigma=1.0,
-                         fit_intercept=False, dtype=torch.float32, names=None, device="cuda", on_chunk=None):
+                         fit_intercept=False, dtype=torch.float32, names=None, device="cuda", on_chunk=None, overlap=False):
     """The linear map step for a shard that does NOT fit HBM (BASELINE config 5: 6.25e7 x 2000 fp32 = 500 GB per GPU, SURVEY
     8(d)): rows row0 .. row0 + n of the seeded stream are generated ON THE DEVICE chunk by chunk (dlsa_synth_*: a row is a
     pure function of (seed, i); y = X beta* + sigma N(0,1) by dlsa_synth_response_*), each chunk goes once through the Gram
     kernel (accumulating) and once through the X'y pass, and is overwritten by the next.  The K partitions are contiguous
     row ranges of the stream (the layout repartition(K, "partition_id") gives, logistic_dlsa.py:295); chunks never straddle
-    a partition.  Peak memory = one chunk + K blocks.  Returns MappedBlocks (fp64 blocks)."""
+    a partition.  Peak memory = one chunk buffer + K blocks.  overlap=True generates chunk i + 1 into a second buffer on a side
+    stream while chunk i is consumed; measured at config 5's size it buys 2 % (2.75 -> 2.69 s for 6.25e7 rows: the wide Gram
+    kernel holds every CU's registers and LDS, so the generator's workgroups wait for it either way) for twice the chunk
+    memory -- off by default.  Returns MappedBlocks (fp64 blocks)."""
     K = int(partition_num)
     n, p, chunk_rows = int(n), int(p), int(chunk_rows)
     if K < 1 or n < 0 or chunk_rows < 1:
@@ -334,24 +337,47 @@ def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=2026010
     sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=device)
     offs = [int(n * k / K) for k in range(K + 1)]
     rows_max = min(chunk_rows, max(1, max(offs[k + 1] - offs[k] for k in range(K))))
-    Xbuf = engine.empty_rows(rows_max, p, dtype, device)
-    ybuf = torch.empty((rows_max,), dtype=dtype, device=device)
-    blocks = []
-    for k in range(K):
-        lo, hi = offs[k], offs[k + 1]
-        if hi <= lo:
-            blocks.append(None)
-            continue
-        blk = _LinearBlock(p, fit_intercept, sig[k], smc[k], device)
-        for r in range(lo, hi, rows_max):
-            m = min(rows_max, hi - r)
-            Xc, yc = Xbuf[:m], ybuf[:m]
-            engine.synth(seed, row0 + r, m, p, kind=kind_id, labels=False, dtype=dtype, out=Xc)
-            engine.synth_response(seed, row0 + r, Xc, sigma=sigma, out=yc)
-            blk.add(Xc, yc)
-            if on_chunk is not None:
-                on_chunk(k, r, m)
-        blocks.append(blk)
+    chunks = [(k, r, min(rows_max, offs[k + 1] - r)) for k in range(K) for r in range(offs[k], offs[k + 1], rows_max)]
+    # Two chunk buffers: chunk i + 1 is generated on a side stream while chunk i goes through the Gram and X'y kernels on the
+    # caller's stream (generation is ~1/4 of a chunk's time at p = 2000: hidden instead of added).  HIP events order the hand-offs.
+    nbuf = 2 if (overlap and len(chunks) > 1) else 1
+    Xbuf = [engine.empty_rows(rows_max, p, dtype, device) for _ in range(nbuf)]
+    ybuf = [torch.empty((rows_max,), dtype=dtype, device=device) for _ in range(nbuf)]
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if nbuf == 2 else main
+    ready = [torch.cuda.Event() for _ in range(nbuf)]
+    done = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def generate(i):
+        k, r, m = chunks[i]
+        b = i % nbuf
+        with torch.cuda.stream(side):
+            if i >= nbuf:
+                side.wait_event(done[b])             # the kernels that read this buffer two chunks ago have finished
+            engine.synth(seed, row0 + r, m, p, kind=kind_id, labels=False, dtype=dtype, out=Xbuf[b][:m])
+            engine.synth_response(seed, row0 + r, Xbuf[b][:m], sigma=sigma, out=ybuf[b][:m])
+            ready[b].record(side)
+
+    blocks = [None] * K
+    if nbuf == 2:
+        side.wait_stream(main)
+    if chunks:
+        generate(0)
+    for i, (k, r, m) in enumerate(chunks):
+        b = i % nbuf
+        if i + 1 < len(chunks) and nbuf == 2:
+            generate(i + 1)
+        main.wait_event(ready[b])
+        if blocks[k] is None:
+            blocks[k] = _LinearBlock(p, fit_intercept, sig[k], smc[k], device)
+        blocks[k].add(Xbuf[b][:m], ybuf[b][:m])
+        done[b].record(main)
+        if nbuf == 1 and i + 1 < len(chunks):
+            generate(i + 1)
+        if on_chunk is not None:
+            on_chunk(k, r, m)
+    if nbuf == 2:
+        main.wait_stream(side)
     return _linear_finish(blocks, coef, smc, sig, names, n)
 
 

@@ -120,7 +120,7 @@ def test_linear_streaming_equals_resident_fit_and_global_ols(eng, orc, dtype, ic
     tdt = torch.float64 if dtype == "f64" else torch.float32
     chunks = []
     mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=7000, seed=seed, kind="uniform", fit_intercept=icpt,
-                                       dtype=tdt, on_chunk=lambda k, r, m: chunks.append((k, r, m)))
+                                       dtype=tdt, on_chunk=lambda k, r, m: chunks.append((k, r, m)), overlap=(dtype == "f64"))
     assert mb.status == [0] * K and sum(m for _, _, m in chunks) == n and max(m for _, _, m in chunks) <= 7000
     assert len(chunks) == sum(-(-(int(n * (k + 1) / K) - int(n * k / K)) // 7000) for k in range(K))
     X, y = orc.synth_linear(seed, 0, n, p, orc.SYNTH_UNIFORM)
