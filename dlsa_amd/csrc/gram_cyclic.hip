@@ -27,6 +27,12 @@
 #define DLSA_CYC_SPLIT 1
 #endif
 #include <algorithm>
+#ifndef DLSA_CYC_PAIR
+#define DLSA_CYC_PAIR 0                   // 1: one barrier per PAIR of chunks (16 rows), the next pair's DMA issued during this pair's first two k-steps
+#endif
+#ifndef DLSA_CYC_PRIO
+#define DLSA_CYC_PRIO 0                   // experiment: 1 = the second-dispatched waves (4..7) run at s_setprio 1, 2 = the first four
+#endif
 
 namespace dlsa {
 
@@ -136,12 +142,12 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
     // Chunks past the end of the slab are fetched (and computed: the chunk loop runs in rounds of four stages) all the same:
     // zeros through the descriptor's bounds check, no traffic, and the in-order vmcnt bookkeeping stays a constant.
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
+    for (int ch = 0; ch < (DLSA_CYC_PAIR ? 2 : 3); ++ch) {
 #pragma unroll
         for (int pc = 0; pc < PIECES; ++pc) dma_piece(ch, ch, pc);
         dma_w(ch, ch);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DLSA_CYC_PAIR ? 0 : 2 * DMA_PER_CHUNK) : "memory");
     asm volatile("s_barrier" ::: "memory");
 
     // Per-lane BYTE addresses of the fragments inside stage pair sp (stages 2 sp, 2 sp + 1): row (lane >> 4) of a k-step,
@@ -208,6 +214,54 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
 
     Frag fr0, fr1;
     load_frags(0, 0, fr0);
+    if (DLSA_CYC_PRIO == 1 && db) __builtin_amdgcn_s_setprio(1);
+    if (DLSA_CYC_PRIO == 2 && !db) __builtin_amdgcn_s_setprio(1);
+#if DLSA_CYC_PAIR
+    // One barrier per PAIR of chunks: pair (c, c + 1) sits in stages (u, u + 1), the DMA of the next pair goes into the other two
+    // stages behind the tile rows of this pair's first two k-steps and is waited for (vmcnt 0) at the pair's end.  Half the
+    // barriers: the skew between the four SIMDs of a workgroup is paid once per 16 rows instead of once per 8.
+    for (int c4 = 0; c4 < nchunks; c4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            const int c = c4 + u;
+            load_frags(u, 1, fr1);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(fr0, c + 2, (u + 2) & 3, true);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(u + 1, 0, fr0);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(fr1, c + 3, (u + 3) & 3, true);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(u + 1, 1, fr1);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(fr0, 0, 0, false);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double aw[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) aw[r] = HASW ? fr1.fa[r] * fr1.wv : fr1.fa[r];
+                cyc_row<0>(aw[0], fr1.fb[0], fr1.fb[1], fr1.fb[2], fr1.fb[3], fr1.fb[4], fr1.fb[5], fr1.fb[6], fr1.fb[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (db) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                if (G > 0 || two_rows)
+                    cyc_row<1>(aw[1], fr1.fb[1], fr1.fb[2], fr1.fb[3], fr1.fb[4], fr1.fb[5], fr1.fb[6], fr1.fb[7], fr1.fb[8]);
+                if constexpr (G > 0) {
+                    if (tails) cyc_tail_a<RW, G>(aw, fr1.bt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!db) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                }
+            }
+            load_frags((u + 2) & 3, 0, fr0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
     for (int c4 = 0; c4 < nchunks; c4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                        // chunk c4 + u sits in stage u
@@ -250,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-fill DMA of the chunks past the end
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs retire before the accumulators are read
 

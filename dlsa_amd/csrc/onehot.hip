@@ -65,8 +65,13 @@ struct OhDesc {                       // device-visible description of the desig
     int lvl_off[OH_MAXF + 1];         // factor t's levels occupy [lvl_off[t], lvl_off[t+1]) of level_col
     int nlev_total;
     int dbg;                          // DLSA_OH_DBG (timing experiments only, wrong results): 1 = no dense x level atomics, 2 = no pair-table atomics
-    int ordered;                      // 1 (default): the waves of a workgroup add to its LDS tables one after another in wave order --
-                                      // bit-reproducible; 0 (DLSA_OH_ORDERED=0): all waves at once, last bits vary from run to run
+    int ordered;                      // LDS accumulation of the passes.  2 (default, Gram): EXACT -- every addend goes in as a 64-bit
+                                      // fixed-point integer (ds_add_u64), integer addition is associative, so all waves add at once
+                                      // and the result is bit-identical from run to run whatever the order; 1: floating-point adds in
+                                      // a fixed wave order (turn-taking in the logit pass, the systolic schedule in the Gram;
+                                      // DLSA_OH_ORDERED=1, and the Gram's fall-back when an addend leaves the fixed-point range);
+                                      // 0 (DLSA_OH_ORDERED=0): floating-point adds from all waves at once, last bits vary
+    int* overflow;                    // exact mode: set to 1 by a thread whose addend exceeds OH_FIX_VMAX (or is not finite)
 };
 
 }  // namespace dlsa
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
         if (valid) ll += yv * eta - (fmax(eta, 0.0) + log1p(e));
 #pragma unroll
         for (int a = 0; a < OH_MAXD; ++a) gd[a] = fma(r, d[a], gd[a]);
-        if (ds.ordered) {                           // one wave at a time, in wave order: a fixed order of the LDS adds
+        if (ds.ordered) {                           // one wave at a time, in wave order: a fixed order of the LDS adds (modes 1 and 2)
             for (int turn = 0; turn < nwaves; ++turn) {
                 if (turn == mywave && valid) {
 #pragma unroll
@@ -219,6 +224,25 @@ __global__ __launch_bounds__(OH_THREADS) void oh_logit_kernel(OhDesc ds, const i
 // g[j] = sum_b gpart[b][j], loglik = sum_b llpart[b] in a fixed order: the dense pass's finish kernel (logit.hip)
 void logit_finish_launch(const double* gpart, const double* llpart, int nblocks, int pitch, int p, double* g,
                          double* loglik, hipStream_t stream, const double* s0part, double* s0);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Exact LDS accumulation.  An addend v (|v| <= OH_FIX_VMAX = 16: w d with w <= 1/4 and a standardised numeric below 64 sigma,
+// or a weight itself) is rounded ONCE to a multiple of 2^-OH_FIX_S and added as a two's-complement 64-bit integer.  Integer
+// addition is associative and commutative, so the LDS atomics of sixteen waves may land in any order: the table a workgroup
+// flushes is the same bit pattern every run -- determinism without the wave turn-taking that cost 60 % (2.67 vs 1.66 ms on
+// config 4's shard).  Rounding error: 2^-41 per addend (4.5e-13 absolute; a workgroup's ~3e4 addends to a cell: <= 1.4e-8 worst
+// case, ~8e-11 typical, on sums of 1e2..1e4 -- below the fp64 rounding of the ordered sum it replaces).  Range: a workgroup
+// adds at most rows_per_workgroup * 16 * 2^40 < 2^62 (checked on the host: rows_per_workgroup < 2^18).  The conversion is the
+// magic-number rounding (v 2^S + 1.5 2^52, valid below 2^51) -- two VALU ops, no 64-bit float->int instruction needed.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int OH_FIX_S = 40;
+constexpr double OH_FIX_VMAX = 16.0;
+__device__ __forceinline__ long long oh_to_fixed(double v) {
+    const double magic = 6755399441055744.0;                        // 1.5 * 2^52
+    const double t = fma(v, (double)(1ull << OH_FIX_S), magic);
+    return __double_as_longlong(t) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ double oh_from_fixed(long long q) { return (double)q * (1.0 / (double)(1ull << OH_FIX_S)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gram: a workgroup of role r accumulates r's tables in LDS and writes them to its slot of the partial buffer
@@ -274,6 +298,15 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
         // Units own disjoint cells.  (Measured on config 4's shard, ordered Gram: these 20 units 2.65 ms; the dense blocks in
         // halves 2.71; one fat unit per factor 3.62; single-add units with a run-time column select 3.30.)
         const int nd = dense ? ds.f : 0, nunit = nd + role.ntab;
+        const bool exact = ds.ordered == 2;
+        auto add_cell = [&](double* cell, double v) {
+            if (exact) {
+                if (!(fabs(v) <= OH_FIX_VMAX)) { *ds.overflow = 1; return; }          // (NaN fails the test too)
+                atomicAdd(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)oh_to_fixed(v));
+            } else {
+                unsafeAtomicAdd(cell, v);
+            }
+        };
         auto unit = [&](int u) {
             if (u < nd) {
                 int l = -1;
@@ -283,18 +316,18 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
                 double* dst = dense_tab + (ds.lvl_off[u] + l) * OH_MAXD;
 #pragma unroll
                 for (int a = 0; a < OH_MAXD; ++a)
-                    if (a < ds.D && !DLSA_DBG_WRONG(ds.dbg, 1)) unsafeAtomicAdd(dst + a, wi * d[a]);
+                    if (a < ds.D && !DLSA_DBG_WRONG(ds.dbg, 1)) add_cell(dst + a, wi * d[a]);
             } else {
                 const OhTable tb = role.tab[u - nd];
                 int lt = -1, lu = -1;
 #pragma unroll
                 for (int t = 0; t < OH_MAXF; ++t) { lt = (t == tb.t) ? lv[t] : lt; lu = (t == tb.u) ? lv[t] : lu; }
                 if (lt < 0 || lu < 0 || DLSA_DBG_WRONG(ds.dbg, 2)) return;
-                if (tb.t == tb.u) unsafeAtomicAdd(tab + tb.lds_off + lt, wi);
-                else unsafeAtomicAdd(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
+                if (tb.t == tb.u) add_cell(tab + tb.lds_off + lt, wi);
+                else add_cell(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
             }
         };
-        if (ds.ordered) {
+        if (ds.ordered == 1) {
             // Ordered mode: wave k works on unit (step - k) -- a systolic schedule with a barrier between steps.  Every unit has
             // its own cells, and the waves reach a unit one after another in wave order, so the adds to any cell happen in a
             // fixed order (bit-reproducible) while all waves keep the LDS atomic pipeline busy on different units.
@@ -308,16 +341,23 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
         }
     }
     __syncthreads();
-    if (role.with_dense && role.dense_rep > 1) {   // fold the copies (fixed order)
+    const bool exact_out = ds.ordered == 2;
+    if (role.with_dense && role.dense_rep > 1) {   // fold the copies (fixed order; exact mode: integer sums)
         for (int j = threadIdx.x; j < dblock; j += blockDim.x) {
-            double t = tab[role.dense_off + j];
-            for (int r = 1; r < role.dense_rep; ++r) t += tab[role.cells + (r - 1) * dblock + j];
-            tab[role.dense_off + j] = t;
+            if (exact_out) {
+                long long t = __double_as_longlong(tab[role.dense_off + j]);
+                for (int r = 1; r < role.dense_rep; ++r) t += __double_as_longlong(tab[role.cells + (r - 1) * dblock + j]);
+                tab[role.dense_off + j] = __longlong_as_double(t);
+            } else {
+                double t = tab[role.dense_off + j];
+                for (int r = 1; r < role.dense_rep; ++r) t += tab[role.cells + (r - 1) * dblock + j];
+                tab[role.dense_off + j] = t;
+            }
         }
         __syncthreads();
     }
     double* out = partial + (int64_t)role_id * role_stride + (int64_t)bl * (role.cells + OH_MAXD * (OH_MAXD + 1) / 2);
-    for (int j = threadIdx.x; j < role.cells; j += blockDim.x) out[j] = tab[j];
+    for (int j = threadIdx.x; j < role.cells; j += blockDim.x) out[j] = exact_out ? oh_from_fixed(__double_as_longlong(tab[j])) : tab[j];
     if (dense) {
 #pragma unroll
         for (int k = 0; k < OH_MAXD * (OH_MAXD + 1) / 2; ++k) {
@@ -413,7 +453,8 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
     DLSA_REQUIRE(pl && y && beta && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot logit pass: null argument");
     OhDesc ds = pl->desc;
-    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }
+    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }      // the logit pass: wave turn-taking unless 0
+    ds.overflow = nullptr;
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot logit pass: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
         return DLSA_ERR_WORKSPACE;
@@ -443,9 +484,12 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
 #ifdef DLSA_DEBUG_KNOBS
     { const char* e = getenv("DLSA_OH_DBG"); ds.dbg = e ? atoi(e) : 0; }
 #endif
-    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }
-    if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
-        set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
+    // accumulation mode of the LDS tables: exact fixed-point (2, the default), ordered floating point (DLSA_OH_ORDERED=1),
+    // unordered floating point (DLSA_OH_ORDERED=0)
+    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0 ? 1 : 0) : 2; }
+    const size_t ws_need = onehot_workspace_bytes_impl(pl, n);
+    if (!ws || ws_bytes < ws_need || ((uintptr_t)ws & 255)) {
+        set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", ws_need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
     const int nb = oh_blocks(n);
@@ -457,19 +501,35 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
     }
     const int64_t role_stride = (int64_t)(align_up(per_role * nb * sizeof(double), 256) / sizeof(double));
     const int nroles = (int)pl->roles.size();
-    DLSA_HIP_CHECK(hipMemset2DAsync(H, (size_t)ldh * sizeof(double), 0, (size_t)ds.p * sizeof(double), (size_t)ds.p, s));
+    int* flag = (int*)((char*)ws + ws_need - 256);            // the spare tail of the workspace
+    ds.overflow = flag;
+    // exact mode's range: a workgroup's rows x OH_FIX_VMAX x 2^OH_FIX_S must stay below 2^62
+    const int64_t rows_per_wg = (n + nb - 1) / nb + OH_GRAM_THREADS;
+    if (ds.ordered == 2 && (double)rows_per_wg * OH_FIX_VMAX * (double)(1ull << OH_FIX_S) >= 4.0e18) ds.ordered = 1;
     const size_t shm = (max_cells + 16) * sizeof(double);
     if (shm > 64 * 1024)
         DLSA_HIP_CHECK(hipFuncSetAttribute((const void*)oh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(oh_gram_kernel, dim3(nb * nroles), dim3(OH_GRAM_THREADS), shm, s, ds, (const OhRole*)pl->d_roles, nroles, nb,
-                       num, ldn, codes, ldc, w, n, (double*)ws, role_stride);
-    DLSA_HIP_CHECK(hipGetLastError());
-    for (int r = 0; r < nroles; ++r) {
-        const int per = pl->roles[r].cells + NDD;
-        hipLaunchKernelGGL(oh_gram_finish_kernel, dim3((per + 31) / 32), dim3(256), 0, s, ds, (const OhRole*)pl->d_roles, r, nb,
-                           (const int32_t*)pl->d_level_col, (const double*)ws, role_stride, H, ldh);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (ds.ordered == 2) DLSA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+        DLSA_HIP_CHECK(hipMemset2DAsync(H, (size_t)ldh * sizeof(double), 0, (size_t)ds.p * sizeof(double), (size_t)ds.p, s));
+        hipLaunchKernelGGL(oh_gram_kernel, dim3(nb * nroles), dim3(OH_GRAM_THREADS), shm, s, ds, (const OhRole*)pl->d_roles, nroles, nb,
+                           num, ldn, codes, ldc, w, n, (double*)ws, role_stride);
+        DLSA_HIP_CHECK(hipGetLastError());
+        for (int r = 0; r < nroles; ++r) {
+            const int per = pl->roles[r].cells + NDD;
+            hipLaunchKernelGGL(oh_gram_finish_kernel, dim3((per + 31) / 32), dim3(256), 0, s, ds, (const OhRole*)pl->d_roles, r, nb,
+                               (const int32_t*)pl->d_level_col, (const double*)ws, role_stride, H, ldh);
+        }
+        DLSA_HIP_CHECK(hipGetLastError());
+        if (ds.ordered != 2) break;
+        // an addend outside the fixed-point range (|w d| > 16: a numeric beyond 64 sigma, or caller weights above 1/4 times that)
+        // or a NaN: the launch is repeated with ordered floating-point adds, which take anything
+        int over = 0;
+        DLSA_HIP_CHECK(hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        if (!over) break;
+        ds.ordered = 1;
     }
-    DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
 

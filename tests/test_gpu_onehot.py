@@ -89,9 +89,10 @@ def test_onehot_passes_match_dense_oracle(api, orc, n, q, nlevels):
 
 
 def test_onehot_passes_are_bit_reproducible(api):
-    """Ordered accumulation (the default): the waves of a workgroup add to its LDS tables in a fixed order, so the
-    gradient, the Hessian and a whole structured fit come out bit-identical run after run -- with skewed levels (many lanes
-    on one address), several table roles and enough rows for every workgroup to run many rounds."""
+    """Deterministic accumulation (the default): the Gram adds 64-bit fixed-point integers to its LDS tables (order-independent),
+    the logit pass takes turns by wave, so the gradient, the Hessian and a whole structured fit come out bit-identical run
+    after run -- with skewed levels (many lanes on one address), several table roles and enough rows for every workgroup to
+    run many rounds."""
     from dlsa_amd import engine
     rng = np.random.default_rng(2026)
     n, q, nlevels = 600000, 7, (11, 6, 20, 110, 110)
@@ -113,6 +114,41 @@ def test_onehot_passes_are_bit_reproducible(api):
     r0 = engine.onehot_irls_fit(plan, dn, dc, dy, offs)
     r1 = engine.onehot_irls_fit(plan, dn, dc, dy, offs)
     assert torch.equal(r0["coef"], r1["coef"]) and torch.equal(r0["Sig_inv"], r1["Sig_inv"])
+
+
+def test_onehot_gram_exact_mode_agrees_with_float_modes_and_falls_back_on_overflow(api, monkeypatch):
+    """The default Gram accumulates 64-bit fixed-point integers in LDS (order-independent, hence bit-reproducible at the speed
+    of the unordered adds).  It must agree with the ordered and the unordered floating-point modes to rounding, and an addend
+    outside its range (|w d| > 16) must send the launch to the ordered mode instead of corrupting H."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(7)
+    n, q, nlevels = 200000, 5, (9, 4, 30, 60)
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, q, nlevels)
+    plan = _plan(api, p, desc, nl, level_col)
+    w = rng.random(n) * 0.25
+    dn, dc, dw = dev(num), dev(codes), dev(w)
+    H2 = engine.onehot_gram(plan, dn, dc, dw)                     # exact (default)
+    assert torch.equal(H2, engine.onehot_gram(plan, dn, dc, dw))
+    monkeypatch.setenv("DLSA_OH_ORDERED", "1")
+    H1 = engine.onehot_gram(plan, dn, dc, dw)
+    monkeypatch.setenv("DLSA_OH_ORDERED", "0")
+    H0 = engine.onehot_gram(plan, dn, dc, dw)
+    monkeypatch.delenv("DLSA_OH_ORDERED")
+    scale = float(H1.abs().max())
+    assert float((H2 - H1).abs().max()) < 1e-13 * scale and float((H0 - H1).abs().max()) < 1e-13 * scale
+    d = H1.diagonal().clamp_min(1e-300).sqrt()
+    assert float(((H2 - H1).abs() / (d[:, None] * d[None, :])).max()) < 1e-11       # small cells on their own scale
+    # weights far above the fixed-point range: every addend overflows -> ordered fall-back, same matrix as the ordered mode
+    big = dev(w * 1e6)
+    Hb = engine.onehot_gram(plan, dn, dc, big)
+    monkeypatch.setenv("DLSA_OH_ORDERED", "1")
+    Hb1 = engine.onehot_gram(plan, dn, dc, big)
+    monkeypatch.delenv("DLSA_OH_ORDERED")
+    assert torch.equal(Hb, Hb1) and bool(torch.isfinite(Hb).all())
+    assert float((Hb - H1 * 1e6).abs().max()) < 1e-12 * float(Hb.abs().max())
+    # a NaN weight must surface as NaN (through the fall-back), not vanish
+    wn = w.copy(); wn[12345] = np.nan
+    assert not bool(torch.isfinite(engine.onehot_gram(plan, dn, dc, dev(wn))).all())
 
 
 def test_onehot_plan_refuses_tables_beyond_lds(api):
