@@ -31,6 +31,10 @@ static void plan_shape(int p, int& nt, int& g) {
     nt = p / 16;
     g = (p - 16 * nt + 3) / 4;
     if (g == 4) { ++nt; g = 0; }
+    // 17 tiles + 3 tail groups (p = 281 .. 284) do not fit the registers of a single-CU plan at two waves per SIMD (168 accumulators
+    // + 92 VGPRs): the shape runs as 18 full tiles on a two-CU group instead -- columns p .. 287 of the LDS rows hold whatever
+    // follows the row, which only reaches rows / columns >= p of H (2.8 % more MFMAs than the tail groups would have cost)
+    if (nt == 17 && g == 3) { nt = 18; g = 0; }
 }
 
 static int plan_slabs(int64_t n, int C, int64_t& rows_per_slab) {
@@ -43,7 +47,6 @@ static int plan_slabs(int64_t n, int C, int64_t& rows_per_slab) {
 bool gram_plan_shape_ok(int64_t n, int p) {
     int nt, g;
     plan_shape(p + (p & 1), nt, g);
-    if ((nt == 17 || nt == 35) && g == 3) return false;      // > 168 AGPRs + the VGPRs: one wave per SIMD, the 8-wave workgroup would not fit
     return nt >= PLAN_NT_MIN && nt <= PLAN_NT_MAX && n >= PLAN_MIN_ROWS;
 }
 

@@ -106,6 +106,9 @@ def test_gram_cyclic_every_instantiation_matches_oracle(eng, p, G, weighted):
 
 @pytest.mark.parametrize("p,n,kernel", [(260, 40000, "gram_plan_kernel<true,16,1>"), (400, 50000, "gram_plan_kernel<true,25,0>"),
                                         (566, 36000, "gram_plan_kernel<true,35,2>"),
+                                        # round 3: the two shapes the plan kernel used to leave to the panel kernel
+                                        (572, 36000, "gram_plan_kernel<true,35,3>"), (284, 36000, "gram_plan_kernel<true,18,0>"),
+                                        (282, 40001, "gram_plan_kernel<true,18,0>"),
                                         (100, 30000, "gram_narrow_kernel<true,6,1>"), (50, 20000, "gram_narrow_kernel<true,3,1>"),
                                         (112, 20000, "gram_narrow_kernel<true,7,0>")])
 def test_plan_and_narrow_kernels_match_oracle(eng, p, n, kernel):

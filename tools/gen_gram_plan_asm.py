@@ -20,7 +20,7 @@ usage: gen_gram_plan_asm.py common            > gram_plan_common.inc
 import os
 import sys
 
-MAXG, BAND, MAX_AGPR = 3, 4, 184
+MAXG, BAND, MAX_AGPR, TAIL_REG_CAP = 3, 4, 184, 168
 
 
 def groups_for(nt):
@@ -61,13 +61,27 @@ def plan(nt, g, C):
         load = [len(r["tiles"]) * 4 for r in runs]                 # in quarter-tiles (a 4x4x4 tail MFMA = 1)
         cap = (nt + 1 + nw - 1) // nw
         nrows_t = [0] * nw
+        # a wave's accumulators must leave room for its ~86 VGPRs at two waves per SIMD: 8 per tile + 2 per tail entry <= TAIL_REG_CAP
+        # (NT = 17 / 35 with three tail groups put 6 entries on 20-tile waves -- 172 registers -- before this cap existed and
+        # were left to the panel kernel).  A tile row's g entries stay on one wave when one has room for all of them; otherwise
+        # they are placed one by one (NT = 17, G = 3: 54 entries on seven 19-tile waves and one 20-tile wave).
+        room = lambda q, k: 8 * len(runs[q]["tiles"]) + 2 * (len(runs[q]["tails"]) + k) <= TAIL_REG_CAP
+        holds = lambda q, t: any(t in (ti, tj) for ti, tj in runs[q]["tiles"])
         for t in range(nt + 1):
-            holders = [w for w, r in enumerate(runs) if nrows_t[w] < cap and any(t in (ti, tj) for ti, tj in r["tiles"])]
-            cand = holders if holders else [w for w in range(nw) if nrows_t[w] < cap]
-            w = min(cand, key=lambda q: load[q])
-            runs[w]["tails"].extend((t, gi) for gi in range(g))
-            load[w] += g
-            nrows_t[w] += 1
+            whole = [w for w in range(nw) if nrows_t[w] < cap and room(w, g)]
+            if whole:
+                cand = [w for w in whole if holds(w, t)] or whole
+                w = min(cand, key=lambda q: load[q])
+                runs[w]["tails"].extend((t, gi) for gi in range(g))
+                load[w] += g
+                nrows_t[w] += 1
+                continue
+            for gi in range(g):
+                cand = [w for w in range(nw) if room(w, 1)] or list(range(nw))
+                cand = [w for w in cand if holds(w, t)] or cand
+                w = min(cand, key=lambda q: load[q])
+                runs[w]["tails"].append((t, gi))
+                load[w] += 1
     for r in runs:
         r["load"] = 4 * len(r["tiles"]) + len(r["tails"])
         a_set = sorted(set([ti for ti, _ in r["tiles"]] + [t for t, _ in r["tails"]]))
