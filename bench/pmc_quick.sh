@@ -3,7 +3,7 @@
 #   bench/pmc_quick.sh "<gram_quick args>" <tag> [kernel-name pattern]
 ARGS="$1"; TAG=${2:-x}; PAT=${3:-gram}
 OUT=gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench/gram_quick.py $ARGS > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 ${DRIVER:-bench/gram_quick.py} $ARGS > $OUT/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD
 run grbm GRBM_GUI_ACTIVE

@@ -80,6 +80,10 @@ SIGNATURES = {
     "dlsa_onehot_irls_fit_f64": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_int, c_dbl, c_int,
                                          c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                          ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
+    "dlsa_onehot_irls_ex_workspace_bytes": (c_sz, [c_vp, c_i64, c_i64]),
+    "dlsa_onehot_irls_fit_ex_f64": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i64,
+                                            c_int, c_dbl, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                            ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
     "dlsa_gram_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dlsa_gram_wide_plan_check": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
 }

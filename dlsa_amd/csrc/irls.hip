@@ -968,4 +968,61 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
                          p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
+// The same for partitions given as (first row, rows, common row step): partition_id = i % K (models.py:33) is first = 0..K-1,
+// step = K -- strided VIEWS of the raw numerics and the level codes (row pitches ldn * step, ldc * step), nothing gathered
+// but the partition's labels (8 bytes per row).
+size_t dlsa_onehot_irls_ex_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition, int64_t row_step) {
+    if (!plan || max_rows_per_partition < 0 || row_step < 1) return 0;
+    const size_t ybuf = row_step > 1 ? dlsa::align_up((size_t)std::max<int64_t>(max_rows_per_partition, 1) * sizeof(double), 256) : 0;
+    return ybuf + dlsa_onehot_irls_workspace_bytes(plan, max_rows_per_partition);
+}
+
+int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
+                                const double* y, const int64_t* part_first_host, const int64_t* part_rows_host, int64_t row_step,
+                                int K, double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef,
+                                int* n_iter_host, int* status_host, double* loglik_host, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dlsa;
+    DLSA_REQUIRE(plan && y && part_first_host && part_rows_host && coef && Sig_inv && Sig_invMcoef, "onehot irls_fit_ex: null argument");
+    DLSA_REQUIRE(K > 0 && max_iter > 0 && tol > 0 && row_step >= 1, "onehot irls_fit_ex: bad K/tol/max_iter/row_step");
+    const int p = onehot_plan_p(plan);
+    int64_t max_rows = 0;
+    std::vector<int64_t> offs((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        DLSA_REQUIRE(part_rows_host[k] >= 0 && part_first_host[k] >= 0, "onehot irls_fit_ex: negative partition shape");
+        max_rows = std::max(max_rows, part_rows_host[k]);
+        offs[(size_t)k + 1] = offs[(size_t)k] + part_rows_host[k];
+    }
+    const size_t need = dlsa_onehot_irls_ex_workspace_bytes(plan, max_rows, row_step);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("onehot irls_fit_ex: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
+    double* ybuf = (double*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t pn = ldn * row_step, pc = ldc * row_step;
+    auto make_data = [=](int k, int64_t) {
+        const double* numk = num ? num + part_first_host[k] * ldn : nullptr;
+        const int32_t* codesk = codes ? codes + part_first_host[k] * ldc : nullptr;
+        const double* yk = y + part_first_host[k];
+        const int64_t nk = part_rows_host[k];
+        if (row_step > 1 && nk > 0) {
+            hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, y, part_first_host[k],
+                               row_step, nk, ybuf);
+            yk = ybuf;
+        }
+        IrlsData d;
+        d.logit = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, const IrlsBuffers& b, hipStream_t s) {
+            return onehot_logit_pass_impl(plan, numk, pn, codesk, pc, yk, beta, nrows, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
+            return onehot_gram_impl(plan, numk, pn, codesk, pc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        return d;
+    };
+    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, offs.data(), K, p, tol,
+                         max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, (char*)ws + ybytes,
+                         ws_bytes - ybytes, stream);
+}
+
 }  // extern "C"

@@ -636,6 +636,36 @@ def onehot_irls_fit(plan, num, codes, y, part_offsets, tol=1e-13, max_iter=100):
             "loglik": list(ll), "rc": rc}
 
 
+def onehot_irls_fit_ex(plan, num, codes, y, part_first, part_rows, row_step=1, tol=1e-13, max_iter=100):
+    """onehot_irls_fit for partitions given as (first row, rows, common row step): partition_id = i % K is part_first = 0..K-1,
+    row_step = K -- strided views of num / codes, no gather (dlsa_onehot_irls_fit_ex_f64).  Same result dict."""
+    lib = _lib.load()
+    _require_gpu(y)
+    _f64(y, "y")
+    p = plan.p
+    first, rows = [int(v) for v in part_first], [int(v) for v in part_rows]
+    K, step, n = len(first), int(row_step), y.numel()
+    if len(rows) != K or K == 0 or step < 1:
+        raise ValueError("onehot_irls_fit_ex: part_first / part_rows must have K >= 1 entries each, row_step >= 1")
+    for f, r in zip(first, rows):
+        if f < 0 or r < 0 or (r > 0 and f + (r - 1) * step >= n):
+            raise ValueError("onehot_irls_fit_ex: partition outside the %d rows" % n)
+    dev = y.device
+    coef = torch.empty((K, p), dtype=torch.float64, device=dev)
+    smc = torch.empty((K, p), dtype=torch.float64, device=dev)
+    sig = torch.empty((K, p, p), dtype=torch.float64, device=dev)
+    ws = _workspace(lib.dlsa_onehot_irls_ex_workspace_bytes(plan._h, max(rows), step), dev)
+    c_first, c_rows = (ctypes.c_int64 * K)(*first), (ctypes.c_int64 * K)(*rows)
+    n_iter, status, ll = (ctypes.c_int * K)(), (ctypes.c_int * K)(), (ctypes.c_double * K)()
+    pn, ldn, pc, ldc = _oh_args(plan, num, codes)
+    rc = lib.dlsa_onehot_irls_fit_ex_f64(plan._h, pn, ldn, pc, ldc, _ptr(y), c_first, c_rows, step, K, tol, max_iter, _ptr(coef),
+                                         _ptr(sig), _ptr(smc), n_iter, status, ll, _ptr(ws), ws.numel(), _stream())
+    if rc not in (0, 4, 5, 6):
+        check(rc)
+    return {"coef": coef, "Sig_invMcoef": smc, "Sig_inv": sig, "n_iter": list(n_iter), "status": list(status),
+            "loglik": list(ll), "rc": rc}
+
+
 class RcclComm:
     """An RCCL communicator opened through the C ABI (dlsa_comm_unique_id / dlsa_comm_init_rank), for hosts that do not
     use torch.distributed: rank 0 creates `RcclComm.unique_id()`, ships the 128 bytes to the other ranks out of band, every

@@ -179,26 +179,22 @@ def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=No
     if num is not None and num.dtype != torch.float64:
         raise TypeError("fit_logistic_design: num must be float64, got %s" % num.dtype)
     n = y.numel()
+    # partition_id = i % K (models.py:33) as strided views: nothing is gathered (the structured fit takes (first, rows, step); the
+    # dense one builds the matrix once and hands the same views to dlsa_irls_fit_ex_f64)
     if part_offsets is None:
         K = int(partition_num) if partition_num else 1
-        if K > 1:
-            idx = torch.arange(n, device=y.device)
-            order = torch.argsort(idx % K, stable=True)
-            num = num[order] if num is not None else None
-            codes = codes[order] if codes is not None else None
-            y = y[order]
-            counts = torch.bincount(idx % K, minlength=K).cpu().tolist()
-        else:
-            counts = [n]
-        part_offsets = np.concatenate([[0], np.cumsum(counts)])
+        first, rows, step = list(range(K)), [len(range(k, n, K)) for k in range(K)], K
+    else:
+        offs = [int(v) for v in part_offsets]
+        first, rows, step = offs[:-1], [offs[k + 1] - offs[k] for k in range(len(offs) - 1)], 1
     plan = spec.onehot_plan() if structured else None
     if plan is not None:
-        r = engine.onehot_irls_fit(plan, num.contiguous() if num is not None else None,
-                                   codes.contiguous() if codes is not None else None, y.contiguous(), part_offsets,
-                                   tol=tol, max_iter=max_iter)
+        r = engine.onehot_irls_fit_ex(plan, engine.row_major(num) if num is not None else None,
+                                      engine.row_major(codes) if codes is not None else None, y.contiguous(), first, rows,
+                                      row_step=step, tol=tol, max_iter=max_iter)
     else:
         X, _ = spec.build(num, codes)
-        r = engine.irls_fit(X, y.contiguous(), part_offsets, tol=tol, max_iter=max_iter)
+        r = engine.irls_fit_ex(X, y.contiguous(), first, rows, row_step=step, tol=tol, max_iter=max_iter)
     return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], spec.names, r["status"], r["n_iter"], r["loglik"],
                         sample_size=n)
 

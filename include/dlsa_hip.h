@@ -281,6 +281,15 @@ int dlsa_xtv_stats_f64(const double* X, int64_t ldx, const double* v, int64_t n,
 int dlsa_xtv_stats_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p, double* g, double* colsum,
                        double* stats, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* dlsa_onehot_irls_fit_f64 for partitions given as (first row, rows, common row step) -- partition_id = i % K (models.py:33)
+ * as strided views of the raw numerics and level codes: nothing is gathered but each partition's labels (8 B per row). */
+size_t dlsa_onehot_irls_ex_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition, int64_t row_step);
+int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes,
+                                int64_t ldc, const double* y, const int64_t* part_first_host, const int64_t* part_rows_host,
+                                int64_t row_step, int K, double tol, int max_iter, double* coef, double* Sig_inv,
+                                double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
+                                void* ws, size_t ws_bytes, void* stream);
+
 /* test hook: host-only validation of the Gram tile plan for p (0 = every tile on/above the diagonal
  * is stored exactly once; outputs: workgroup items, tile slots computed, tiles stored). */
 int dlsa_gram_plan_check(int p, int* nitems, int* nslots, int* ntiles);

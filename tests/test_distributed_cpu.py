@@ -72,3 +72,28 @@ def test_shard_helpers():
                                    torch.tensor([7.0, 8.0], dtype=torch.float64), 3)
     S, v, c, k = distributed.unpack_message(distributed.allreduce_message(msg), 2)
     assert S.tolist() == [[0.0, 1.0], [2.0, 3.0]] and v.tolist() == [5.0, 6.0] and c.tolist() == [7.0, 8.0] and k == 3
+
+
+def test_allreduce_message_takes_a_communicator_object():
+    """One reduce path, two carriers: distributed.allreduce_message(msg, comm=...) hands the message to the communicator's
+    allreduce (engine.RcclComm on a GPU host) instead of torch.distributed; anything without .allreduce is refused."""
+    import torch
+    from dlsa_amd import distributed
+
+    class FakeComm:
+        def __init__(self):
+            self.calls = 0
+
+        def allreduce(self, msg):
+            self.calls += 1
+            msg.mul_(2.0)              # "two ranks with the same message"
+            return msg
+
+    c = FakeComm()
+    msg = torch.arange(7, dtype=torch.float64)
+    out = distributed.allreduce_message(msg, comm=c)
+    assert out is msg and c.calls == 1 and torch.equal(msg, torch.arange(7, dtype=torch.float64) * 2)
+    with pytest.raises(TypeError):
+        distributed.allreduce_message(msg, comm=object())
+    # no communicator, no process group: the identity
+    assert torch.equal(distributed.allreduce_message(msg.clone()), msg)

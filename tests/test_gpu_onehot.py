@@ -198,3 +198,35 @@ def test_structured_fit_many_partitions_matches_dense(api, orc):
     assert rel_inf(r["Sig_inv"].cpu().numpy(), d["Sig_inv"].cpu().numpy()) < 1e-10
     c, _, s = orc.logistic_model_block(X[:30_000], y[:30_000])
     assert rel_inf(r["coef"][0].cpu().numpy(), c) < TOL_MLE and rel_inf(r["Sig_inv"][0].cpu().numpy(), s) < TOL_MLE
+
+
+@pytest.mark.parametrize("K", [1, 3, 7])
+def test_structured_fit_strided_partitions_no_gather(api, orc, K):
+    """partition_id = i % K (models.py:33) on the RAW representation: strided views of the numerics and the level codes go to
+    dlsa_onehot_irls_fit_ex_f64 -- no gathered copy -- and give the oracle's per-partition MLE and Hessian on the rows i % K == k."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(100 + K)
+    n = 90_001
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, 3, (7, 4, 12))
+    plan = _plan(api, p, desc, nl, level_col)
+    X, _ = orc.design_matrix(num, codes, *desc)
+    beta = rng.normal(size=p) * 0.3
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(np.float64)
+    dn, dc, dy = dev(num), dev(codes), dev(y)
+    first, rows = list(range(K)), [len(range(k, n, K)) for k in range(K)]
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    r = engine.onehot_irls_fit_ex(plan, dn, dc, dy, first, rows, row_step=K)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < 0.5 * (num.nbytes + codes.nbytes) + 48e6      # scratch, not a copy of the rows
+    assert r["status"] == [0] * K
+    for k in range(K):
+        c, smc, sig = orc.logistic_model_block(X[k::K], y[k::K])
+        assert rel_inf(r["coef"][k].cpu().numpy(), c) < TOL_MLE
+        assert rel_inf(r["Sig_inv"][k].cpu().numpy(), sig) < TOL_MLE
+        assert rel_inf(r["Sig_invMcoef"][k].cpu().numpy(), smc) < TOL_MLE
+    # contiguous partitions through the same entry (row_step = 1) equal dlsa_onehot_irls_fit_f64
+    offs = [0, 20000, 20000, n]
+    a = engine.onehot_irls_fit_ex(plan, dn, dc, dy, offs[:-1], [offs[i + 1] - offs[i] for i in range(3)], 1)
+    b = engine.onehot_irls_fit(plan, dn, dc, dy, offs)
+    assert a["status"] == b["status"] == [0, 4, 0] and torch.equal(a["coef"], b["coef"]) and torch.equal(a["Sig_inv"], b["Sig_inv"])
