@@ -747,7 +747,7 @@ size_t gram_wide_f32_ws_bytes(int64_t n, int p);
 int gram_wide_f32(const float* X, int64_t ldx, const float* w, int64_t n, int p, float* H, int64_t ldh,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream, double* H64 = nullptr);
 
-// gram_narrow.hip: the row-split fp64 kernel for 49 <= p <= 112
+// gram_narrow.hip: the row-split fp64 kernel for 49 <= p <= 120
 bool gram_narrow_shape_ok(int64_t n, int p);
 bool gram_narrow_eligible(const double* X, int64_t ldx, const double* w, int64_t n, int p);
 size_t gram_narrow_ws_bytes(int64_t n, int p);

@@ -1,4 +1,4 @@
-// Weighted Gram H = X' diag(w) X for NARROW fp64 designs (49 <= p <= 112 in an even row pitch: config 2's p = 100,
+// Weighted Gram H = X' diag(w) X for NARROW fp64 designs (49 <= p <= 120 in an even row pitch: config 2's p = 100,
 // config 1's p = 50, and the same with an intercept column),
 // reference call site dlsa/models.py:130.
 //
@@ -42,7 +42,7 @@ void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_
 #endif
 constexpr int NARROW_KC = DLSA_NARROW_KC;         // rows per chunk: a multiple of 16 (KC/16 k-steps per wave)
 constexpr int NARROW_STAGES = 3;
-constexpr int NARROW_MIN_P = 49, NARROW_MAX_P = 112;      // 4..7 tiles: 8 tiles (288 accumulator registers) spill
+constexpr int NARROW_MIN_P = 49, NARROW_MAX_P = 120;      // 3..7 tiles (+ tail groups while the triangle fits the 256 AGPRs: 7 tiles + 2 groups)
 constexpr int64_t NARROW_MIN_ROWS = 8192;
 
 struct NarrowArgs {
@@ -362,10 +362,11 @@ int gram_narrow_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
 #define DLSA_LAUNCH_NARROW_NT(HW) do { switch (nt) { \
         case 3: DLSA_LAUNCH_NARROW_G(HW, 3); break; case 4: DLSA_LAUNCH_NARROW_G(HW, 4); break; \
         case 5: DLSA_LAUNCH_NARROW_G(HW, 5); break; case 6: DLSA_LAUNCH_NARROW_G(HW, 6); break; \
-        default: DLSA_LAUNCH_NARROW(HW, 7, 0); break; } } while (0)
+        default: switch (g) { case 0: DLSA_LAUNCH_NARROW(HW, 7, 0); break; case 1: DLSA_LAUNCH_NARROW(HW, 7, 1); break; \
+                              default: DLSA_LAUNCH_NARROW(HW, 7, 2); break; } break; } } while (0)
     if (w) DLSA_LAUNCH_NARROW_NT(true);
     else DLSA_LAUNCH_NARROW_NT(false);
-    note_gram_kernel(a.clk, stream, "gram_narrow_kernel<%s,%d,%d>", w ? "true" : "false", nt > 6 ? 7 : (nt < 3 ? 3 : nt), nt > 6 ? 0 : g);
+    note_gram_kernel(a.clk, stream, "gram_narrow_kernel<%s,%d,%d>", w ? "true" : "false", nt > 6 ? 7 : (nt < 3 ? 3 : nt), nt > 6 ? (g > 2 ? 2 : g) : g);
 #undef DLSA_LAUNCH_NARROW_G
 #undef DLSA_LAUNCH_NARROW_NT
 #undef DLSA_LAUNCH_NARROW

@@ -35,6 +35,8 @@ static void plan_shape(int p, int& nt, int& g) {
     // + 92 VGPRs): the shape runs as 18 full tiles on a two-CU group instead -- columns p .. 287 of the LDS rows hold whatever
     // follows the row, which only reaches rows / columns >= p of H (2.8 % more MFMAs than the tail groups would have cost)
     if (nt == 17 && g == 3) { nt = 18; g = 0; }
+    // p = 121 .. 124 (7 tiles + 3 tail groups: 272 accumulator registers, beyond gram_narrow.hip's AGPR file) run as 8 full tiles
+    if (nt == 7 && g == 3) { nt = 8; g = 0; }
 }
 
 static int plan_slabs(int64_t n, int C, int64_t& rows_per_slab) {

@@ -1,4 +1,4 @@
-// One FUSED Newton pass for narrow fp64 designs (49 <= p <= 112): in ONE read of the rows
+// One FUSED Newton pass for narrow fp64 designs (49 <= p <= 120): in ONE read of the rows
 //     eta = X beta,  mu = sigmoid(eta),  w = mu (1 - mu),  g = X'(y - mu),  loglik,  H = X' diag(w) X.
 // Reference call sites: dlsa/models.py:110-114 (the solver's inner products and predict_proba), :130 (the Hessian).  The
 // reference reads a partition's rows three times per evaluation (fit iteration, predict_proba, the .dot of :130); the
@@ -40,7 +40,7 @@ size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 
 constexpr int FP_KC = 32;                 // rows per chunk: two k-steps per wave
 constexpr int FP_NST = 4;                 // LDS stages: the DMA runs three chunks ahead
-constexpr int FP_MIN_P = 49, FP_MAX_P = 112;
+constexpr int FP_MIN_P = 49, FP_MAX_P = 120;
 constexpr int64_t FP_MIN_ROWS = 8192;
 
 struct FusedArgs {
@@ -553,7 +553,8 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
 #define DLSA_LAUNCH_FP_NT(WO) do { switch (nt) { \
         case 3: DLSA_LAUNCH_FP_G(WO, 3); break; case 4: DLSA_LAUNCH_FP_G(WO, 4); break; \
         case 5: DLSA_LAUNCH_FP_G(WO, 5); break; case 6: DLSA_LAUNCH_FP_G(WO, 6); break; \
-        default: DLSA_LAUNCH_FP(WO, 7, 0); break; } } while (0)
+        default: switch (gt) { case 0: DLSA_LAUNCH_FP(WO, 7, 0); break; case 1: DLSA_LAUNCH_FP(WO, 7, 1); break; \
+                               default: DLSA_LAUNCH_FP(WO, 7, 2); break; } break; } } while (0)
     if (w_out) DLSA_LAUNCH_FP_NT(true);
     else DLSA_LAUNCH_FP_NT(false);
 #undef DLSA_LAUNCH_FP_NT
@@ -562,7 +563,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
 #undef DLSA_LAUNCH_FP2
     DLSA_HIP_CHECK(hipGetLastError());
     note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<%s,%s,%d,%d>", w_out ? "true" : "false", H ? "true" : "false", nt > 6 ? 7 : nt,
-                     nt > 6 ? 0 : gt);
+                     nt > 6 ? (gt > 2 ? 2 : gt) : gt);
     if (H) gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
     hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((p + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, p,
                        16 * ntc, g, loglik);

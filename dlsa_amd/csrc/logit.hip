@@ -370,7 +370,7 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
         set_error("logit_pass: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    // Narrow designs (49 <= p <= 112, aligned rows): the rows come through the LDS-DMA ring of the fused Newton pass, which streams
+    // Narrow designs (49 <= p <= 120, aligned rows): the rows come through the LDS-DMA ring of the fused Newton pass, which streams
     // at the HBM rate where this kernel's register loads reach 5.2-5.5 TB/s (DLSA_LOGIT_RING=0: keep the register-load kernel).
     if (!intercept && irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0)) {
         const char* e = getenv("DLSA_LOGIT_RING");

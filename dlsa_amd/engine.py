@@ -291,7 +291,7 @@ def logit_pass(X, y, beta, want_w=True, want_g=True, want_loglik=True, fit_inter
 
 def irls_pass(X, y, beta, want_w=False):
     """One Newton pass in ONE call (dlsa_irls_pass_f64): w = mu(1-mu) at beta, g = X'(y-mu), loglik and H = X' diag(w) X.
-    Narrow designs (49 <= p <= 112, even, aligned rows, n >= 8192) run the FUSED kernel -- one read of X; every other shape
+    Narrow designs (49 <= p <= 120, even, aligned rows, n >= 8192) run the FUSED kernel -- one read of X; every other shape
     the logit pass + the Gram pass behind the same entry (gram_last_kernel() names what ran).  Returns (H, g, loglik, w or None)."""
     lib = _lib.load()
     _require_gpu(X, y, beta)

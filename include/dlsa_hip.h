@@ -121,7 +121,7 @@ int dlsa_xtv_f32(const float* X, int64_t ldx, const float* v, int64_t n, int p,
  * eta = X beta, mu = sigmoid(eta), w = mu(1-mu);  g = X'(y - mu) (p, nullable), loglik (1, nullable), H = X' diag(w) X
  * (p x p, ldh >= p, both triangles), w_out (n, nullable).  The reference evaluates these in three passes over a
  * partition (fit iteration, predict_proba, the Gram of :130); dlsa_logit_pass_f64 + dlsa_gram_f64 in two.  For narrow
- * designs (49 <= p <= 112, even, 16-byte aligned rows, n >= 8192) the rows staged in LDS for the MFMAs also feed the
+ * designs (49 <= p <= 120, even, 16-byte aligned rows, n >= 8192) the rows staged in LDS for the MFMAs also feed the
  * logistic terms: one launch, one read of X (csrc/irls_pass.hip).  Every other shape runs the two launches behind the same
  * entry point (still on the GPU; dlsa_gram_last_kernel tells which form ran).  Results of the two forms agree to 1e-13. */
 size_t dlsa_irls_pass_workspace_bytes(int64_t n, int p);

@@ -131,10 +131,10 @@ def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
     assert rel_inf(H.cpu().numpy(), Hl.cpu().numpy()) < 1e-12
 
 
-@pytest.mark.parametrize("p", list(range(49, 113)))
+@pytest.mark.parametrize("p", list(range(49, 129)))
 def test_gram_narrow_every_width(eng, p):
-    """Every width of the row-split kernel (all tile counts x tail groups, one and two k-steps per chunk), weighted and not,
-    against an fp64 matmul.  The weighted case is the one that exposes an operand hazard at the head of the kernel's
+    """Every width of the row-split kernel (all tile counts x tail groups, one and two k-steps per chunk; round 3: up to 7 tiles +
+    2 tail groups = p 120, then 121 .. 124 as the plan kernel's 8 full tiles), weighted and not, against an fp64 matmul.  The weighted case is the one that exposes an operand hazard at the head of the kernel's
     inline-assembly MFMA block: the scaled fragments are VALU results the compiler may place one instruction earlier."""
     n = 16384 + 3 * p
     gen = torch.Generator(device="cuda"); gen.manual_seed(p)
@@ -149,6 +149,8 @@ def test_gram_narrow_every_width(eng, p):
         ref = Xc.T @ (Xc if wt is None else Xc * wt[:, None])
         d = ref.diagonal().sqrt()
         assert float(((H - ref).abs() / (d[:, None] * d[None, :])).max()) < 1e-12, (p, wt is None)
+    name = eng.gram_last_kernel()[0]
+    assert name.startswith("gram_narrow_kernel" if p <= 120 else "gram_plan_kernel"), (p, name)
 
 
 @pytest.mark.parametrize("n,p,ld", [(9001, 51, 52), (30000, 101, 102), (8192, 111, 112), (4000, 501, 502), (5000, 37, 38),
