@@ -136,7 +136,7 @@ def test_gram_narrow_every_width(eng, p):
     """Every width of the row-split kernel (all tile counts x tail groups, one and two k-steps per chunk; round 3: up to 7 tiles +
     2 tail groups = p 120, then 121 .. 124 as the plan kernel's 8 full tiles), weighted and not, against an fp64 matmul.  The weighted case is the one that exposes an operand hazard at the head of the kernel's
     inline-assembly MFMA block: the scaled fragments are VALU results the compiler may place one instruction earlier."""
-    n = 16384 + 3 * p
+    n = (16384 if p <= 120 else 32768) + 3 * p               # (the plan kernel serves 32 768 rows and more)
     gen = torch.Generator(device="cuda"); gen.manual_seed(p)
     ld = p + (p & 1)
     buf = torch.full((n, ld), float("nan"), dtype=torch.float64, device="cuda")
