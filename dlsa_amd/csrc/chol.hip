@@ -331,6 +331,178 @@ __global__ __launch_bounds__(1024) void inv_apply_kernel(const double* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small systems (p <= 112: config 2's p = 100, config 1's p = 50): ONE launch, everything in LDS -- factor, explicit
+// inverse of the factor, H^-1 = Linv' Linv, and the solve.  The blocked path above is 13 dependent launches for p = 100
+// (~0.15 ms) + 5 for the inverse + the p-row Gram for H^-1: a fifth of a millisecond per fresh Hessian, five to nine times per
+// config-2 fit (12 ms).  Here:
+//   * left-looking Cholesky, TWO threads per row (the dot product of a column step split by parity, joined with a DPP add),
+//     two barriers per column;
+//   * the inverse of the factor column by column by forward substitution, two threads per column, NO barriers (columns are
+//     independent); it is stored transposed into the strict upper triangle of the same LDS array (L keeps the lower one);
+//   * H^-1[a][b] = sum_{r >= b} Linv[r][a] Linv[r][b]: two contiguous rows of that upper triangle per entry;
+//   * x = Linv' (Linv rhs): two mat-vecs on the LDS copy.
+// Outputs L, Linv, Hinv (global, for the quasi-Newton kernels that reuse them), x and stats as chol_tri_solve_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CS_MAXP = 112;              // measured: p = 66 -10 %, p = 100 -6 % of a 20 000-row fit, p = 128 +5 % (the blocked path wins from there)
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ A, int64_t lda, int p,
+                                                         const double* __restrict__ rhs, const double* __restrict__ ref,
+                                                         double* __restrict__ L, double* __restrict__ Linv,
+                                                         double* __restrict__ Hinv, double* __restrict__ xout,
+                                                         double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int LD = p | 1;                    // odd pitch: a column walk (stride LD) touches every bank pair once
+    double* Ls = sm;                         // [p][LD]: lower triangle + diagonal = L; strict upper = Linv transposed
+    double* dinv = Ls + p * LD;              // 1 / L_ii = Linv_ii
+    double* gv = dinv + p;                   // rhs
+    double* yv = gv + p;                     // Linv rhs
+    double* red = yv + p;                    // 48 + flag
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int e = tid; e < p * p; e += nth) {
+        const int i = e / p, k = e - i * p;
+        if (k <= i) Ls[i * LD + k] = A[(int64_t)i * lda + k];
+    }
+    for (int i = tid; i < p; i += nth) gv[i] = rhs[i];
+    if (tid == 0) red[48] = 0.0;
+    __syncthreads();
+    // ---- Cholesky: thread pair (2i, 2i + 1) owns row i
+    const int row = tid >> 1, half = tid & 1;
+    for (int j = 0; j < p; ++j) {
+        double sacc = 0.0;
+        if (row >= j && row < p) {
+            const double* ri = Ls + row * LD;
+            const double* rj = Ls + j * LD;
+            // four independent chains: the LDS latency of one read pair overlaps the next ones (a single dependent chain
+            // of ~100-cycle round trips made this kernel slower than the 13-launch path it replaces)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = half;
+            for (; k + 6 < j; k += 8) {
+                s0 = fma(ri[k], rj[k], s0); s1 = fma(ri[k + 2], rj[k + 2], s1);
+                s2 = fma(ri[k + 4], rj[k + 4], s2); s3 = fma(ri[k + 6], rj[k + 6], s3);
+            }
+            for (; k < j; k += 2) s0 = fma(ri[k], rj[k], s0);
+            sacc = (s0 + s1) + (s2 + s3);
+        }
+        sacc += dpp_xor_f64<1>(sacc);
+        double v = 0.0;
+        if (row >= j && row < p) v = Ls[row * LD + j] - sacc;
+        if (row == j && half == 0) {
+            double piv;
+            if (!(v > 0.0) || !isfinite(v)) { red[48] = fmax(red[48], isfinite(v) ? 1.0 : 2.0); piv = 1.0; }
+            else piv = sqrt(v);
+            Ls[j * LD + j] = piv;
+            dinv[j] = 1.0 / piv;
+        }
+        __syncthreads();
+        if (row > j && row < p && half == 0) Ls[row * LD + j] = v * dinv[j];
+        __syncthreads();
+    }
+    // ---- inverse of the factor: thread pair owns column c; Linv[r][c] (r > c) lives at Ls[c][r]
+    {
+        const int c = row;
+        if (c < p) {
+            double* up = Ls + c * LD;        // up[r] = Linv[r][c] for r > c
+            const double dc = dinv[c];
+            for (int r = c + 1; r < p; ++r) {
+                const double* lr = Ls + r * LD;
+                double sacc = 0.0;
+                // k = c: Linv[c][c] = dc; k in (c, r): up[k]
+                {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int k = c + 1 + half;
+                    for (; k + 6 < r; k += 8) {
+                        s0 = fma(lr[k], up[k], s0); s1 = fma(lr[k + 2], up[k + 2], s1);
+                        s2 = fma(lr[k + 4], up[k + 4], s2); s3 = fma(lr[k + 6], up[k + 6], s3);
+                    }
+                    for (; k < r; k += 2) s0 = fma(lr[k], up[k], s0);
+                    sacc = (s0 + s1) + (s2 + s3);
+                }
+                sacc += dpp_xor_f64<1>(sacc);
+                const double val = -(sacc + lr[c] * dc) * dinv[r];
+                if (half == 0) up[r] = val;
+                // the pair runs in lock step inside one wave; the partner reads up[r] from the next r on
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+    __syncthreads();
+    // ---- outputs: L, Linv (row-major lower triangles), H^-1 (both triangles)
+    for (int e = tid; e < p * p; e += nth) {
+        const int i = e / p, k = e - i * p;
+        L[e] = (k <= i) ? Ls[i * LD + k] : 0.0;
+        Linv[e] = (k < i) ? Ls[k * LD + i] : (k == i ? dinv[i] : 0.0);
+    }
+    for (int e = tid; e < p * p; e += nth) {
+        const int a = e / p, b = e - a * p;
+        if (a > b) continue;
+        // sum over r >= b of Linv[r][a] Linv[r][b];  r == b: Linv[b][b] = dinv[b], Linv[b][a] = (a == b) ? dinv[a] : Ls[a][b]
+        const double* ua = Ls + a * LD;
+        const double* ub = Ls + b * LD;
+        double sacc = (a == b ? dinv[a] : ua[b]) * dinv[b];
+        {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int r = b + 1;
+            for (; r + 3 < p; r += 4) {
+                s0 = fma(ua[r], ub[r], s0); s1 = fma(ua[r + 1], ub[r + 1], s1);
+                s2 = fma(ua[r + 2], ub[r + 2], s2); s3 = fma(ua[r + 3], ub[r + 3], s3);
+            }
+            for (; r < p; ++r) s0 = fma(ua[r], ub[r], s0);
+            sacc += (s0 + s1) + (s2 + s3);
+        }
+        Hinv[(int64_t)a * p + b] = sacc;
+        Hinv[(int64_t)b * p + a] = sacc;
+    }
+    // ---- x = Linv' (Linv rhs)
+    for (int r = tid; r < p; r += nth) {
+        double sacc = dinv[r] * gv[r];
+        for (int c = 0; c < r; ++c) sacc = fma(Ls[c * LD + r], gv[c], sacc);
+        yv[r] = sacc;
+    }
+    __syncthreads();
+    double mx = 0.0, mr = 0.0;
+    int bad = 0;
+    for (int c = tid; c < p; c += nth) {
+        const double* uc = Ls + c * LD;
+        double sacc = dinv[c] * yv[c];
+        for (int r = c + 1; r < p; ++r) sacc = fma(uc[r], yv[r], sacc);
+        xout[c] = sacc;
+        mx = fmax(mx, fabs(sacc));
+        if (!isfinite(sacc)) bad = 1;
+        if (ref) mr = fmax(mr, fabs(ref[c]));
+    }
+    mx = wave_allreduce_max(mx);
+    mr = wave_allreduce_max(mr);
+    for (int m2 = 32; m2 >= 1; m2 >>= 1) bad |= __shfl_xor(bad, m2, 64);
+    if ((tid & 63) == 0) { red[tid >> 6] = mx; red[16 + (tid >> 6)] = mr; red[32 + (tid >> 6)] = (double)bad; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < nth / 64; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); c = fmax(c, red[32 + k]); }
+        stats[0] = a;
+        stats[1] = b;
+        stats[2] = red[48] != 0.0 ? red[48] : (c != 0.0 ? 2.0 : 0.0);
+    }
+}
+
+bool chol_small_ok(int p) {
+    const char* e = getenv("DLSA_CHOL_SMALL");           // 0: always the blocked path (A/B runs)
+    return p <= CS_MAXP && (!e || atoi(e) != 0);
+}
+
+// factor A (p <= 128), write L, Linv, Hinv = A^-1 and x = A^-1 rhs in one launch; stats as launch_chol_solve
+int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* L, double* Linv,
+                      double* Hinv, double* xout, double* stats, hipStream_t s) {
+    DLSA_REQUIRE(p > 0 && p <= CS_MAXP, "chol_small: p=%d", p);
+    const size_t shm = ((size_t)p * (p | 1) + 3 * (size_t)p + 64) * sizeof(double);
+    if (shm > 48 * 1024)
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), shm, s, A, lda, p, rhs, ref, L, Linv, Hinv, xout, stats);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
 int launch_tri_inverse(const double* L, int p, double* Linv, hipStream_t s) {
     DLSA_HIP_CHECK(hipMemsetAsync(Linv, 0, (size_t)p * p * sizeof(double), s));
     const int nblk = (p + NB - 1) / NB;
