@@ -27,6 +27,9 @@
 #define DLSA_CYC_SPLIT 1
 #endif
 #include <algorithm>
+#ifndef DLSA_CYC_FLAGS
+#define DLSA_CYC_FLAGS 0                  // experiment: per-stage LANDED / DONE flags in LDS instead of s_barrier (a SIMD that is ahead keeps issuing)
+#endif
 #ifndef DLSA_CYC_PAIR
 #define DLSA_CYC_PAIR 0                   // 1: one barrier per PAIR of chunks (16 rows), the next pair's DMA issued during this pair's first two k-steps
 #endif
@@ -147,8 +150,30 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
         for (int pc = 0; pc < PIECES; ++pc) dma_piece(ch, ch, pc);
         dma_w(ch, ch);
     }
+#if DLSA_CYC_FLAGS
+    // Per-stage hand-off flags instead of the workgroup barrier: byte w of LANDED[s] = tag of the chunk whose pieces wave w has
+    // seen land in stage s; byte w of DONE[s] = tag of the chunk wave w has finished reading there.  tag(c) = (c / 4 + 1) & 255.
+    // A wave reads a chunk once all eight LANDED bytes carry its tag, and overwrites a stage once all eight DONE bytes do.
+    unsigned long long* const flagL = reinterpret_cast<unsigned long long*>(lds + CYC_NST * BUF);      // [4]
+    unsigned long long* const flagD = flagL + 4;                                                        // [4]
+    if (tid < 8) flagL[tid] = 0ull;
+    __syncthreads();
+    auto tag_of = [](int c) { return (unsigned)(((c >> 2) + 1) & 255); };
+    auto post = [&](unsigned long long* f, int stage, int c) {
+        if (lane == 0) reinterpret_cast<volatile unsigned char*>(f + stage)[wave] = (unsigned char)tag_of(c);
+    };
+    auto await = [&](unsigned long long* f, int stage, int c) {
+        const unsigned long long want = 0x0101010101010101ull * tag_of(c);
+        while (__builtin_amdgcn_readfirstlane((int)(*reinterpret_cast<volatile unsigned long long*>(f + stage) != want)))
+            __builtin_amdgcn_s_sleep(1);
+    };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
+    post(flagL, 0, 0);
+    await(flagL, 0, 0);
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DLSA_CYC_PAIR ? 0 : 2 * DMA_PER_CHUNK) : "memory");
     asm volatile("s_barrier" ::: "memory");
+#endif
 
     // Per-lane BYTE addresses of the fragments inside stage pair sp (stages 2 sp, 2 sp + 1): row (lane >> 4) of a k-step,
     // column 16 tile + (lane & 15).  Stage parity and k-step are compile-time immediates of the ds_read (the chunk loop is
@@ -216,7 +241,40 @@ __global__ __launch_bounds__(512, 2) void gram_cyclic_kernel(CycArgs a) {
     load_frags(0, 0, fr0);
     if (DLSA_CYC_PRIO == 1 && db) __builtin_amdgcn_s_setprio(1);
     if (DLSA_CYC_PRIO == 2 && !db) __builtin_amdgcn_s_setprio(1);
-#if DLSA_CYC_PAIR
+#if DLSA_CYC_FLAGS
+    for (int c4 = 0; c4 < nchunks; c4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                        // chunk c = c4 + u sits in stage u
+            const int c = c4 + u;
+            load_frags(u, 1, fr1);                               // (c, 1), while (c, 0) computes
+            if (c > 0) post(flagD, (u + 3) & 3, c - 1);          // this wave's reads of chunk c - 1 were consumed by the MFMAs it has issued
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double aw[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) aw[r] = HASW ? fr0.fa[r] * fr0.wv : fr0.fa[r];
+                cyc_row<0>(aw[0], fr0.fb[0], fr0.fb[1], fr0.fb[2], fr0.fb[3], fr0.fb[4], fr0.fb[5], fr0.fb[6], fr0.fb[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // this wave's pieces of chunk c + 1 have landed
+                post(flagL, (u + 1) & 3, c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (G > 0 || two_rows)
+                    cyc_row<1>(aw[1], fr0.fb[1], fr0.fb[2], fr0.fb[3], fr0.fb[4], fr0.fb[5], fr0.fb[6], fr0.fb[7], fr0.fb[8]);
+                if constexpr (G > 0) {
+                    if (tails) cyc_tail_a<RW, G>(aw, fr0.bt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            await(flagL, (u + 1) & 3, c + 1);                    // every wave's pieces of chunk c + 1 are there
+            load_frags((u + 1) & 3, 0, fr0);                     // (c + 1, 0), while (c, 1) computes
+            __builtin_amdgcn_sched_barrier(0);
+            if (c > 0) await(flagD, (u + 3) & 3, c - 1);         // every wave has left chunk c - 1: its stage takes chunk c + 3
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(fr1, c + 3, (u + 3) & 3, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#elif DLSA_CYC_PAIR
     // One barrier per PAIR of chunks: pair (c, c + 1) sits in stages (u, u + 1), the DMA of the next pair goes into the other two
     // stages behind the tile rows of this pair's first two k-steps and is waited for (vmcnt 0) at the pair's end.  Half the
     // barriers: the skew between the four SIMDs of a workgroup is paid once per 16 rows instead of once per 8.
@@ -370,7 +428,7 @@ int gram_cyclic_f64(const double* X, int64_t ldx, const double* w, int64_t n, in
         return DLSA_ERR_WORKSPACE;
     }
     const int g = a.p <= CYC_C0 ? 0 : (a.p - CYC_C0 + 3) / 4;
-    const size_t shm = (size_t)CYC_NST * CYC_BUF * 8;
+    const size_t shm = (size_t)CYC_NST * CYC_BUF * 8 + (DLSA_CYC_FLAGS ? 64 : 0);
     const int blocks = a.nslab * CYC_GROUP;
 #define DLSA_LAUNCH_CYC(HW, GV) do { \
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_cyclic_kernel<HW, GV>), \
