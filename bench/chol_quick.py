@@ -3,6 +3,9 @@ uses irls_fit on a tiny partition count to time the fit's fixed costs.  python b
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from dlsa_amd import _lib
+if len(sys.argv) > 2:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from dlsa_amd import engine
 p = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = 20000

@@ -344,6 +344,9 @@ __global__ __launch_bounds__(1024) void inv_apply_kernel(const double* __restric
 //   * x = Linv' (Linv rhs): two mat-vecs on the LDS copy.
 // Outputs L, Linv, Hinv (global, for the quasi-Newton kernels that reuse them), x and stats as chol_tri_solve_kernel.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef CS_SKIP
+#define CS_SKIP 0                        // timing experiments only (wrong results): 1 no factor loop, 2 no inverse, 4 no L / Linv stores, 8 no H^-1, 16 no solve
+#endif
 constexpr int CS_MAXP = 112;              // measured: p = 66 -10 %, p = 100 -6 % of a 20 000-row fit, p = 128 +5 % (the blocked path wins from there)
 __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ A, int64_t lda, int p,
                                                          const double* __restrict__ rhs, const double* __restrict__ ref,
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
     __syncthreads();
     // ---- Cholesky: thread pair (2i, 2i + 1) owns row i
     const int row = tid >> 1, half = tid & 1;
-    for (int j = 0; j < p; ++j) {
+    for (int j = 0; j < ((CS_SKIP & 1) ? 0 : p); ++j) {
         double sacc = 0.0;
         if (row >= j && row < p) {
             const double* ri = Ls + row * LD;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
     // ---- inverse of the factor: thread pair owns column c; Linv[r][c] (r > c) lives at Ls[c][r]
     {
         const int c = row;
-        if (c < p) {
+        if (c < p && !(CS_SKIP & 2)) {
             double* up = Ls + c * LD;        // up[r] = Linv[r][c] for r > c
             const double dc = dinv[c];
             for (int r = c + 1; r < p; ++r) {
@@ -429,12 +432,12 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
     }
     __syncthreads();
     // ---- outputs: L, Linv (row-major lower triangles), H^-1 (both triangles)
-    for (int e = tid; e < p * p; e += nth) {
+    for (int e = tid; e < ((CS_SKIP & 4) ? 0 : p * p); e += nth) {
         const int i = e / p, k = e - i * p;
         L[e] = (k <= i) ? Ls[i * LD + k] : 0.0;
         Linv[e] = (k < i) ? Ls[k * LD + i] : (k == i ? dinv[i] : 0.0);
     }
-    for (int e = tid; e < p * p; e += nth) {
+    for (int e = tid; e < ((CS_SKIP & 8) ? 0 : p * p); e += nth) {
         const int a = e / p, b = e - a * p;
         if (a > b) continue;
         // sum over r >= b of Linv[r][a] Linv[r][b];  r == b: Linv[b][b] = dinv[b], Linv[b][a] = (a == b) ? dinv[a] : Ls[a][b]
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
         Hinv[(int64_t)b * p + a] = sacc;
     }
     // ---- x = Linv' (Linv rhs)
-    for (int r = tid; r < p; r += nth) {
+    for (int r = tid; r < ((CS_SKIP & 16) ? 0 : p); r += nth) {
         double sacc = dinv[r] * gv[r];
         for (int c = 0; c < r; ++c) sacc = fma(Ls[c * LD + r], gv[c], sacc);
         yv[r] = sacc;
