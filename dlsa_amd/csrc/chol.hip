@@ -332,148 +332,103 @@ __global__ __launch_bounds__(1024) void inv_apply_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Small systems (p <= 112: config 2's p = 100, config 1's p = 50): ONE launch, everything in LDS -- factor, explicit
-// inverse of the factor, H^-1 = Linv' Linv, and the solve.  The blocked path above is 13 dependent launches for p = 100
-// (~0.15 ms) + 5 for the inverse + the p-row Gram for H^-1: a fifth of a millisecond per fresh Hessian, five to nine times per
-// config-2 fit (12 ms).  Here:
-//   * left-looking Cholesky, TWO threads per row (the dot product of a column step split by parity, joined with a DPP add),
-//     two barriers per column;
-//   * the inverse of the factor column by column by forward substitution, two threads per column, NO barriers (columns are
-//     independent); it is stored transposed into the strict upper triangle of the same LDS array (L keeps the lower one);
-//   * H^-1[a][b] = sum_{r >= b} Linv[r][a] Linv[r][b]: two contiguous rows of that upper triangle per entry;
-//   * x = Linv' (Linv rhs): two mat-vecs on the LDS copy.
-// Outputs L, Linv, Hinv (global, for the quasi-Newton kernels that reuse them), x and stats as chol_tri_solve_kernel.
+// Small systems (p <= 112: config 2's p = 100, config 1's p = 50): H^-1 and the Newton step in ONE launch.
+// The blocked path above is 13 dependent launches for p = 100 + 5 for the factor's inverse + the p-row Gram that forms
+// H^-1 for the quasi-Newton kernels: ~0.2 ms per fresh Hessian, four to nine times per config-2 fit.  A first one-launch
+// version (left-looking Cholesky + forward-substituted inverse + Linv' Linv in LDS) was no faster: 220 us, all of it
+// dependent LDS round trips (factor loop 88 us, inverse 59, H^-1 46: timed by leaving the phases out).  This one never
+// factors: the SWEEP operator applied to every pivot in turn turns an SPD matrix A into -A^-1 in place,
+//     sweep k:  A[i][j] -= A[i][k] A[k][j] / d  (i, j != k),  A[i][k] /= d,  A[k][j] /= d,  A[k][k] = -1 / d,   d = A[k][k],
+// and the pivots d are the squares of the Cholesky pivots (d <= 0: not SPD).  The matrix lives in REGISTERS: thread (j, h) holds
+// A[i][j] for the rows i = 2 s + h (56 doubles, static indices), so a sweep is 56 FMAs per thread against a SNAPSHOT of row k
+// in LDS (every thread publishes its element of row k + 1 while it finishes sweep k) -- one barrier per sweep, no
+// read-modify-write of LDS.  With the snapshot's pivot entry stored as d - 1 the one formula
+//     A[i][j] -= s[i] s[j] / d
+// also produces row k and column k (check: s[k] = d - 1 gives A[k][j] - (d - 1) A[k][j] / d = A[k][j] / d); only the pivot
+// itself, kept in a register of its own, is set to -1 / d.  x = H^-1 rhs comes from the registers as well.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef CS_SKIP
-#define CS_SKIP 0                        // timing experiments only (wrong results): 1 no factor loop, 2 no inverse, 4 no L / Linv stores, 8 no H^-1, 16 no solve
+#define CS_SKIP 0                        // timing experiments only (wrong results): 1 no sweeps
 #endif
-constexpr int CS_MAXP = 112;              // measured: p = 66 -10 %, p = 100 -6 % of a 20 000-row fit, p = 128 +5 % (the blocked path wins from there)
-__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ A, int64_t lda, int p,
-                                                         const double* __restrict__ rhs, const double* __restrict__ ref,
-                                                         double* __restrict__ L, double* __restrict__ Linv,
-                                                         double* __restrict__ Hinv, double* __restrict__ xout,
-                                                         double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int LD = p | 1;                    // odd pitch: a column walk (stride LD) touches every bank pair once
-    double* Ls = sm;                         // [p][LD]: lower triangle + diagonal = L; strict upper = Linv transposed
-    double* dinv = Ls + p * LD;              // 1 / L_ii = Linv_ii
-    double* gv = dinv + p;                   // rhs
-    double* yv = gv + p;                     // Linv rhs
-    double* red = yv + p;                    // 48 + flag
-    const int tid = threadIdx.x, nth = blockDim.x;
-    for (int e = tid; e < p * p; e += nth) {
-        const int i = e / p, k = e - i * p;
-        if (k <= i) Ls[i * LD + k] = A[(int64_t)i * lda + k];
+constexpr int CS_MAXP = 112;
+constexpr int CS_NS = CS_MAXP / 2;       // rows per thread
+
+// sweep K and, recursively, K + 1 ..: the recursion is what makes every register index static (a `#pragma unroll` loop with
+// the early exit for k >= p is not unrolled by hipcc, and a[] then lives in scratch)
+template <int K>
+__device__ __forceinline__ void cs_sweeps(double (&a)[CS_NS], double& diag, double (&rk)[2][128], double (&dval)[2], double* red,
+                                          int p, int tid, int j, int h) {
+    if constexpr (K < CS_MAXP) {
+        if (K >= p) return;
+        constexpr int cur = K & 1;
+        __syncthreads();
+        double d = dval[cur];
+        if (!(d > 0.0) || !isfinite(d)) { if (tid == 0) red[48] = fmax(red[48], isfinite(d) ? 1.0 : 2.0); d = 1.0; }
+        const double dinv = 1.0 / d;
+        const double sj = rk[cur][j];
+        const double tj = sj * dinv;
+#pragma unroll
+        for (int sl = 0; sl < CS_NS; ++sl) a[sl] = fma(-rk[cur][2 * sl + h], tj, a[sl]);
+        diag = (j == K) ? -dinv : fma(-sj, tj, diag);
+        if constexpr (K + 1 < CS_MAXP) {         // publish this thread's element of row K + 1: slot (K + 1) >> 1 of the h == (K + 1) & 1 threads
+            if (h == ((K + 1) & 1)) {
+                rk[cur ^ 1][j] = (j == K + 1) ? diag - 1.0 : a[(K + 1) >> 1];
+                if (j == K + 1) dval[cur ^ 1] = diag;
+            }
+        }
+        cs_sweeps<K + 1>(a, diag, rk, dval, red, p, tid, j, h);
     }
-    for (int i = tid; i < p; i += nth) gv[i] = rhs[i];
+}
+
+__global__ __launch_bounds__(256) void spd_inverse_small_kernel(const double* __restrict__ A, int64_t lda, int p,
+                                                                const double* __restrict__ rhs, const double* __restrict__ ref,
+                                                                double* __restrict__ Hinv, double* __restrict__ xout,
+                                                                double* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) double rk[2][128];      // snapshot of the pivot row (= column, by symmetry), indexed by column
+    __shared__ double dval[2];                                      // the pivot itself
+    __shared__ double gv[128], xpart[2][128], red[52];
+    const int tid = threadIdx.x, j = tid & 127, h = tid >> 7;       // h is wave-uniform (waves 0, 1: even rows; 2, 3: odd rows)
+    const bool col = j < p;
+    double a[CS_NS];
+#pragma unroll
+    for (int sl = 0; sl < CS_NS; ++sl) {
+        const int i = 2 * sl + h;
+        a[sl] = (col && i < p) ? A[(int64_t)i * lda + j] : 0.0;
+    }
+    double diag = col ? A[(int64_t)j * lda + j] : 1.0;
+    if (tid < 128) { gv[tid] = tid < p ? rhs[tid] : 0.0; rk[0][tid] = 0.0; rk[1][tid] = 0.0; }
     if (tid == 0) red[48] = 0.0;
     __syncthreads();
-    // ---- Cholesky: thread pair (2i, 2i + 1) owns row i
-    const int row = tid >> 1, half = tid & 1;
-    for (int j = 0; j < ((CS_SKIP & 1) ? 0 : p); ++j) {
-        double sacc = 0.0;
-        if (row >= j && row < p) {
-            const double* ri = Ls + row * LD;
-            const double* rj = Ls + j * LD;
-            // four independent chains: the LDS latency of one read pair overlaps the next ones (a single dependent chain
-            // of ~100-cycle round trips made this kernel slower than the 13-launch path it replaces)
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = half;
-            for (; k + 6 < j; k += 8) {
-                s0 = fma(ri[k], rj[k], s0); s1 = fma(ri[k + 2], rj[k + 2], s1);
-                s2 = fma(ri[k + 4], rj[k + 4], s2); s3 = fma(ri[k + 6], rj[k + 6], s3);
-            }
-            for (; k < j; k += 2) s0 = fma(ri[k], rj[k], s0);
-            sacc = (s0 + s1) + (s2 + s3);
-        }
-        sacc += dpp_xor_f64<1>(sacc);
-        double v = 0.0;
-        if (row >= j && row < p) v = Ls[row * LD + j] - sacc;
-        if (row == j && half == 0) {
-            double piv;
-            if (!(v > 0.0) || !isfinite(v)) { red[48] = fmax(red[48], isfinite(v) ? 1.0 : 2.0); piv = 1.0; }
-            else piv = sqrt(v);
-            Ls[j * LD + j] = piv;
-            dinv[j] = 1.0 / piv;
-        }
-        __syncthreads();
-        if (row > j && row < p && half == 0) Ls[row * LD + j] = v * dinv[j];
-        __syncthreads();
+    // Row k + 1 (the next pivot row) is published element by element: A[k + 1][j] sits in slot (k + 1) >> 1 of the threads with
+    // h == (k + 1) & 1 -- a STATIC register index because the sweeps are unrolled by template recursion (112 sweeps x 56 FMAs:
+    // ~80 KB of code, streamed once).  One 8-byte LDS store per thread and sweep; the owner of the pivot stores d - 1 in its
+    // place and d beside it.  The readers fetch rk[2 sl + h]: the same address in every lane, a broadcast.
+    if (h == 0) {
+        rk[0][j] = (j == 0) ? diag - 1.0 : a[0];
+        if (j == 0) dval[0] = diag;
     }
-    // ---- inverse of the factor: thread pair owns column c; Linv[r][c] (r > c) lives at Ls[c][r]
-    {
-        const int c = row;
-        if (c < p && !(CS_SKIP & 2)) {
-            double* up = Ls + c * LD;        // up[r] = Linv[r][c] for r > c
-            const double dc = dinv[c];
-            for (int r = c + 1; r < p; ++r) {
-                const double* lr = Ls + r * LD;
-                double sacc = 0.0;
-                // k = c: Linv[c][c] = dc; k in (c, r): up[k]
-                {
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                    int k = c + 1 + half;
-                    for (; k + 6 < r; k += 8) {
-                        s0 = fma(lr[k], up[k], s0); s1 = fma(lr[k + 2], up[k + 2], s1);
-                        s2 = fma(lr[k + 4], up[k + 4], s2); s3 = fma(lr[k + 6], up[k + 6], s3);
-                    }
-                    for (; k < r; k += 2) s0 = fma(lr[k], up[k], s0);
-                    sacc = (s0 + s1) + (s2 + s3);
-                }
-                sacc += dpp_xor_f64<1>(sacc);
-                const double val = -(sacc + lr[c] * dc) * dinv[r];
-                if (half == 0) up[r] = val;
-                // the pair runs in lock step inside one wave; the partner reads up[r] from the next r on
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+    if (!(CS_SKIP & 1)) cs_sweeps<0>(a, diag, rk, dval, red, p, tid, j, h);
+    // ---- H^-1 = -A (the slot of the diagonal element is stale: the pivot register holds it)
+    double xs = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < CS_NS; ++sl) {
+        const int i = 2 * sl + h;
+        if (col && i < p) {
+            const double v = (i == j) ? -diag : -a[sl];
+            Hinv[(int64_t)i * p + j] = v;
+            xs = fma(v, gv[i], xs);              // x_j = sum_i H^-1[i][j] rhs[i]  (column j = row j)
         }
     }
-    __syncthreads();
-    // ---- outputs: L, Linv (row-major lower triangles), H^-1 (both triangles)
-    for (int e = tid; e < ((CS_SKIP & 4) ? 0 : p * p); e += nth) {
-        const int i = e / p, k = e - i * p;
-        L[e] = (k <= i) ? Ls[i * LD + k] : 0.0;
-        Linv[e] = (k < i) ? Ls[k * LD + i] : (k == i ? dinv[i] : 0.0);
-    }
-    for (int e = tid; e < ((CS_SKIP & 8) ? 0 : p * p); e += nth) {
-        const int a = e / p, b = e - a * p;
-        if (a > b) continue;
-        // sum over r >= b of Linv[r][a] Linv[r][b];  r == b: Linv[b][b] = dinv[b], Linv[b][a] = (a == b) ? dinv[a] : Ls[a][b]
-        const double* ua = Ls + a * LD;
-        const double* ub = Ls + b * LD;
-        double sacc = (a == b ? dinv[a] : ua[b]) * dinv[b];
-        {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int r = b + 1;
-            for (; r + 3 < p; r += 4) {
-                s0 = fma(ua[r], ub[r], s0); s1 = fma(ua[r + 1], ub[r + 1], s1);
-                s2 = fma(ua[r + 2], ub[r + 2], s2); s3 = fma(ua[r + 3], ub[r + 3], s3);
-            }
-            for (; r < p; ++r) s0 = fma(ua[r], ub[r], s0);
-            sacc += (s0 + s1) + (s2 + s3);
-        }
-        Hinv[(int64_t)a * p + b] = sacc;
-        Hinv[(int64_t)b * p + a] = sacc;
-    }
-    // ---- x = Linv' (Linv rhs)
-    for (int r = tid; r < ((CS_SKIP & 16) ? 0 : p); r += nth) {
-        double sacc = dinv[r] * gv[r];
-        for (int c = 0; c < r; ++c) sacc = fma(Ls[c * LD + r], gv[c], sacc);
-        yv[r] = sacc;
-    }
+    if (tid < 256) xpart[h][j] = xs;
     __syncthreads();
     double mx = 0.0, mr = 0.0;
     int bad = 0;
-    for (int c = tid; c < p; c += nth) {
-        const double* uc = Ls + c * LD;
-        double sacc = dinv[c] * yv[c];
-        for (int r = c + 1; r < p; ++r) sacc = fma(uc[r], yv[r], sacc);
-        xout[c] = sacc;
-        mx = fmax(mx, fabs(sacc));
-        if (!isfinite(sacc)) bad = 1;
-        if (ref) mr = fmax(mr, fabs(ref[c]));
+    if (tid < p) {
+        const double v = xpart[0][tid] + xpart[1][tid];
+        xout[tid] = v;
+        mx = fabs(v);
+        if (!isfinite(v)) bad = 1;
+        if (ref) mr = fabs(ref[tid]);
     }
     mx = wave_allreduce_max(mx);
     mr = wave_allreduce_max(mr);
@@ -481,10 +436,10 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
     if ((tid & 63) == 0) { red[tid >> 6] = mx; red[16 + (tid >> 6)] = mr; red[32 + (tid >> 6)] = (double)bad; }
     __syncthreads();
     if (tid == 0) {
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int k = 0; k < nth / 64; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); c = fmax(c, red[32 + k]); }
-        stats[0] = a;
-        stats[1] = b;
+        double m0 = 0.0, m1 = 0.0, c = 0.0;
+        for (int q = 0; q < 4; ++q) { m0 = fmax(m0, red[q]); m1 = fmax(m1, red[16 + q]); c = fmax(c, red[32 + q]); }
+        stats[0] = m0;
+        stats[1] = m1;
         stats[2] = red[48] != 0.0 ? red[48] : (c != 0.0 ? 2.0 : 0.0);
     }
 }
@@ -494,14 +449,12 @@ bool chol_small_ok(int p) {
     return p <= CS_MAXP && (!e || atoi(e) != 0);
 }
 
-// factor A (p <= 128), write L, Linv, Hinv = A^-1 and x = A^-1 rhs in one launch; stats as launch_chol_solve
-int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* L, double* Linv,
-                      double* Hinv, double* xout, double* stats, hipStream_t s) {
-    DLSA_REQUIRE(p > 0 && p <= CS_MAXP, "chol_small: p=%d", p);
-    const size_t shm = ((size_t)p * (p | 1) + 3 * (size_t)p + 64) * sizeof(double);
-    if (shm > 48 * 1024)
-        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), shm, s, A, lda, p, rhs, ref, L, Linv, Hinv, xout, stats);
+// H^-1 (p <= 112) into Hinv and x = H^-1 rhs in one launch; stats as launch_chol_solve.  No factor is produced: the callers
+// (irls.hip) only take this path when their later steps use H^-1 (the fused quasi-Newton kernel).
+int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* Hinv, double* xout,
+                      double* stats, hipStream_t s) {
+    DLSA_REQUIRE(p > 0 && p <= CS_MAXP, "spd_inverse_small: p=%d", p);
+    hipLaunchKernelGGL(spd_inverse_small_kernel, dim3(1), dim3(256), 0, s, A, lda, p, rhs, ref, Hinv, xout, stats);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

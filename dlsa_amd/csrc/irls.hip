@@ -54,8 +54,8 @@ int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const doubl
 int launch_matvec(const double* A, int64_t lda, const double* x, int p, double* y, hipStream_t s);
 int launch_tri_inverse(const double* L, int p, double* Linv, hipStream_t s);
 bool chol_small_ok(int p);
-int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* L, double* Linv,
-                      double* Hinv, double* xout, double* stats, hipStream_t s);
+int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* Hinv, double* xout,
+                      double* stats, hipStream_t s);
 int launch_inv_apply(const double* Linv, int p, const double* rhs, const double* ref, double* xout, double* stats, hipStream_t s);
 }  // namespace dlsa
 struct dlsa_onehot_plan;
@@ -490,9 +490,10 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 rc = launch_axpby(b.g, b.g, gscale - 1.0, p, b.g, s);       // g <- g * gscale (inherited factor of H / scale)
                 if (rc) return rc;
             }
-            if (fresh_now && chol_small_ok(p)) {
-                // p <= 128: factor, inverse of the factor, H^-1 and the step in ONE launch (chol.hip: chol_small_kernel)
-                rc = launch_chol_small(H, p, p, rhs, b.beta, b.L, b.Linv, b.Hinv, b.delta, b.stats, s);
+            if (fresh_now && qn_on && chol_small_ok(p)) {
+                // p <= 112: H^-1 and the step in ONE launch (chol.hip: spd_inverse_small_kernel).  No factor, no Linv: with the secant
+                // correction on, every later step of this factor goes through the fused quasi-Newton kernel, which reads H^-1 only
+                rc = launch_chol_small(H, p, p, rhs, b.beta, b.Hinv, b.delta, b.stats, s);
                 *b.inv_valid = 3;
             } else if (fresh_now) {
                 *b.inv_valid = 0;
@@ -674,8 +675,8 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
             // a warm start that fails (status != OK) is repeated cold.
             bool warm = have_warm;
             if (warm && pool_ok && pooled > 0 && (pooled & (pooled - 1)) == 0) {
-                if (chol_small_ok(p)) {
-                    rc = launch_chol_small(b.Hpool, p, p, b.g, b.beta, b.L, b.Linv, b.Hinv, b.delta, b.stats, s);
+                if (qn_enabled() && chol_small_ok(p)) {
+                    rc = launch_chol_small(b.Hpool, p, p, b.g, b.beta, b.Hinv, b.delta, b.stats, s);
                     *b.inv_valid = 3;
                 } else {
                     rc = launch_chol_solve(b.Hpool, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
