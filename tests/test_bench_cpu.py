@@ -97,3 +97,23 @@ def test_cpu_baseline_harness_small():
     assert pool["theta_err_vs_truth_linf"] < 0.6          # the combined estimate is near beta* (first 4 ones, rest 0)
     assert r["single_process"]["partitions"] == 2 and r["gram"]["rows_per_s"] > 0
     assert abs(r["value"] - pool["map_rows_per_s"]) < 1e-9
+
+
+def test_bench_arguments_round3():
+    """--scaling / --e2e-partitions parse; the defaults are the contract's (N = 1, K = 10, W = 2: minutes, not hours)."""
+    bench = _load_bench()
+    a = bench.parse([])
+    assert (a.gpus, a.steps, a.warmup, a.scaling, a.e2e_partitions) == (1, 10, 2, "both", 25)
+    assert bench.parse(["--gpus", "8", "--scaling", "strong"]).scaling == "strong"
+    with pytest.raises(SystemExit):
+        bench.parse(["--scaling", "sideways"])
+
+
+def test_committed_traffic_profile_matches_the_tree():
+    """profiles/pmc_latest.json must have been taken from the Gram sources in the tree, or `roofline.traffic` is null in the
+    driver's bench line: a reminder to re-run bench/profile_round.sh after touching gram.hip / gram_cyclic.hip / common.h."""
+    bench = _load_bench()
+    prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert prof.get("gram_hip_sha16") == bench.gram_sources_sha16(), "stale profiles/pmc_latest.json"
+    t, _ = bench.traffic_from_profile(500, 25_000_000)
+    assert 0.99 * 25e6 * 4008 < t < 1.05 * 25e6 * 4008          # fabric traffic ~ the algorithmic bytes of the launch

@@ -156,3 +156,20 @@ def test_linear_streaming_config5_width_bounded_memory(eng):
     out = dlsa_amd.dlsa_mapred(mb)
     truth = np.concatenate([[0.0], np.ones(800), np.zeros(1200)])
     assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.03
+
+
+def test_linear_edge_cases_empty_rows_and_partitions(eng):
+    import dlsa_amd
+    X = torch.randn((0, 12), dtype=torch.float64, device="cuda")
+    v = torch.randn(0, dtype=torch.float64, device="cuda")
+    g, cs, st = eng.xtv_stats(X, v, want_colsum=True)
+    assert float(g.abs().max()) == 0.0 and float(cs.abs().max()) == 0.0 and float(st.abs().max()) == 0.0
+    g[:] = 3.0; st[:] = 5.0
+    eng.xtv_stats(X, v, g=g, stats=st, accumulate=True)                 # adding nothing changes nothing
+    assert float((g - 3.0).abs().max()) == 0.0 and float((st - 5.0).abs().max()) == 0.0
+    # fewer rows than partitions: the empty partitions report status 4 (the reference's zero block), the others fit
+    mb = dlsa_amd.fit_linear_streaming(40, 3, partition_num=64, chunk_rows=16, kind="uniform", dtype=torch.float64)
+    assert mb.status.count(4) == 24 and all(s in (0, 2, 4) for s in mb.status)
+    mb2 = dlsa_amd.fit_linear_partitions(torch.randn((30, 3), dtype=torch.float64, device="cuda"),
+                                         torch.randn(30, dtype=torch.float64, device="cuda"), part_offsets=[0, 0, 30])
+    assert mb2.status == [4, 0] and float(mb2.Sig_inv[0].abs().max()) == 0.0
