@@ -94,8 +94,8 @@ def dlsa(Sig_inv_, beta_, sample_size, fit_intercept=False, type="lar"):
     S = np.asarray(Sig_inv_, dtype=np.float64) if not isinstance(Sig_inv_, torch.Tensor) else Sig_inv_
     b = np.asarray(beta_, dtype=np.float64) if not isinstance(beta_, torch.Tensor) else beta_
     fit = lars_path_device(S, b, fit_intercept, sample_size, type=type)
-    ia = int(torch.argmin(fit["AIC"]).item())
-    ib = int(torch.argmin(fit["BIC"]).item())
+    ia = int(np.argmin(fit["AIC"].cpu().numpy()))          # dlsa.py:87-91: argmin on the host (steps + 1 values)
+    ib = int(np.argmin(fit["BIC"].cpu().numpy()))
     by_aic, by_bic = fit["beta"][ia], fit["beta"][ib]
     if fit_intercept:
         b0 = float(b[0])

@@ -86,11 +86,11 @@ def level_counts_from_codes(codes, levels):
     """Counts of a device-resident shard: codes [n, f] int32 (negative = unknown level), levels = {factor: [level, ...]}
     in code order.  Returns {factor: {level: count}} ordered most frequent first (ties: lower code first), ready for
     select_dummy_factors; across ranks, all-reduce the bincounts (or merge with cumsum_dicts)."""
-    import torch
     out = {}
+    host = codes.cpu().numpy() if hasattr(codes, "cpu") else np.asarray(codes)      # counting is host work (tensors are storage)
     for t, (col, lv) in enumerate(levels.items()):
-        c = codes[:, t]
-        cnt = torch.bincount(c[c >= 0].long(), minlength=len(lv)).cpu().numpy()
+        c = host[:, t]
+        cnt = np.bincount(c[c >= 0].astype(np.int64), minlength=len(lv))
         order = np.lexsort((np.arange(len(lv)), -cnt))
         out[col] = {lv[j]: int(cnt[j]) for j in order if cnt[j] > 0}
     return out
