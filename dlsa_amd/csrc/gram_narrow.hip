@@ -41,7 +41,11 @@ void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_
 #define DLSA_NARROW_KC 32
 #endif
 constexpr int NARROW_KC = DLSA_NARROW_KC;         // rows per chunk: a multiple of 16 (KC/16 k-steps per wave)
-constexpr int NARROW_STAGES = 3;
+#ifndef DLSA_NARROW_STAGES
+#define DLSA_NARROW_STAGES 3          // experiment: 2 = two 32-row stages (half the barriers per row, the DMA one chunk ahead) where two workgroups share a CU
+#endif
+constexpr int NARROW_STAGES = DLSA_NARROW_STAGES;
+constexpr int NARROW_AHEAD = NARROW_STAGES - 1;      // chunks the DMA runs ahead
 constexpr int NARROW_MIN_P = 49, NARROW_MAX_P = 120;      // 3..7 tiles (+ tail groups while the triangle fits the 256 AGPRs: 7 tiles + 2 groups)
 constexpr int64_t NARROW_MIN_ROWS = 8192;
 
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     constexpr int NTAIL = (NT + 1) * G, GA = G > 0 ? G : 1;
     constexpr int MEETN = narrow_meetn(NT, NTC, KC);
     constexpr int DMA_PER_CHUNK = KC / NWAVES + (HASW ? 1 : 0);        // instructions per wave and chunk
-    static_assert(KC % 16 == 0 && 3 * MEETN >= NTRI, "chunk / meeting shape");
+    static_assert(KC % 16 == 0 && 4 * MEETN >= NTRI, "chunk / meeting shape");
     static_assert((size_t)3 * NTAIL * 64 <= (size_t)NARROW_STAGES * BUF, "tail meeting fits the ring");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -235,17 +239,17 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
 
     narrow_acc_zero<narrow_nreg(NT, G)>();
 
-    stage(0, 0);
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+#pragma unroll
+    for (int ch = 0; ch < NARROW_AHEAD; ++ch) stage(ch, ch);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NARROW_AHEAD - 1) * DMA_PER_CHUNK) : "memory");
     asm volatile("s_barrier" ::: "memory");
 
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);      // the 4 tail columns, broadcast to the 4 blocks
-    int cur = 0, nxt2 = 2;                               // ring positions of chunk c and chunk c + 2
+    int cur = 0, nxt2 = NARROW_AHEAD % NARROW_STAGES;    // ring positions of chunk c and of the chunk the DMA fetches (c + NARROW_AHEAD)
     for (int c = 0; c < nchunks; ++c) {
 #if !DLSA_NARROW_SPREAD
-        if (!DLSA_DBG_WRONG(a.dbg, 1)) stage(c + 2, nxt2);            // past the slab end: bounds-checked zeros, no traffic
+        if (!DLSA_DBG_WRONG(a.dbg, 1)) stage(c + NARROW_AHEAD, nxt2);            // past the slab end: bounds-checked zeros, no traffic
 #endif
         const double* base = lds + cur * BUF;
         // all of this wave's fragments of the chunk are requested up front: only the first k-step waits for LDS
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             if (kk == 0 && !DLSA_DBG_WRONG(a.dbg, 128)) {
                 narrow_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](int q) {
                     if (DLSA_DBG_WRONG(a.dbg, 1)) return;
-                    if (q < 4) stage_rows(c + 2, nxt2, q); else stage_w(c + 2, nxt2);
+                    if (q < 4) stage_rows(c + NARROW_AHEAD, nxt2, q); else stage_w(c + NARROW_AHEAD, nxt2);
                 });
                 continue;
             }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT, G>(f[kk], g, btw);
             else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]), "v"(btw[0]));
         }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NARROW_AHEAD - 1) * DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
         asm volatile("s_barrier" ::: "memory");
         cur = (cur == NARROW_STAGES - 1) ? 0 : cur + 1;
         nxt2 = (nxt2 == NARROW_STAGES - 1) ? 0 : nxt2 + 1;
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     double* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
     narrow_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
-    narrow_meet<2 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
+    narrow_meet<2 * MEETN, (3 * MEETN < NTRI ? 3 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
+    narrow_meet<3 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
     if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
 }
