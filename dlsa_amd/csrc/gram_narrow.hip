@@ -41,6 +41,9 @@ void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_
 #define DLSA_NARROW_KC 32
 #endif
 constexpr int NARROW_KC = DLSA_NARROW_KC;         // rows per chunk: a multiple of 16 (KC/16 k-steps per wave)
+#ifndef DLSA_STREAM_AUX
+#define DLSA_STREAM_AUX 0           // experiment: 2 = nt on the row stream (each row is read by one workgroup, once)
+#endif
 #ifndef DLSA_NARROW_STAGES
 #define DLSA_NARROW_STAGES 3          // experiment: 2 = two 32-row stages (half the barriers per row, the DMA one chunk ahead) where two workgroups share a CU
 #endif
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
         for (int ps = 0; ps < KC / NWAVES; ++ps) {
             const int row = wave + NWAVES * ps;
             const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
-            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, 0);
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
         // every wave fetches the chunk's w (same bytes to the same place): the in-order count is then the same in all waves
         if (HASW && lane < KC / 2)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
         for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
             const int row = wave + NWAVES * ps;
             const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
-            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, 0);
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
     };
     auto stage_w = [&](int chunk, int buf) {

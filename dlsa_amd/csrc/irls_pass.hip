@@ -24,6 +24,10 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef DLSA_STREAM_AUX
+#define DLSA_STREAM_AUX 0           // experiment: 2 = nt on the row stream (each row is read by one workgroup, once)
+#endif
+
 namespace dlsa {
 
 template <typename T>
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
         for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
             const int row = wave + NWAVES * ps;
             const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
-            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, 0);
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
     };
     auto stage_y = [&](int chunk, int buf) {      // every wave fetches the chunk's y: the same in-order count in all waves

@@ -13,6 +13,16 @@
 #include "common.h"
 #include <algorithm>
 
+#ifndef DLSA_LOGIT_NT
+#define DLSA_LOGIT_NT 0             // experiment: 1 = non-temporal loads of the rows (read once per pass)
+#endif
+#if DLSA_LOGIT_NT
+typedef double dlsa_d2v __attribute__((ext_vector_type(2)));
+#define DLSA_LOGIT_LD2(ptr) ([&] { dlsa_d2v t_ = __builtin_nontemporal_load(reinterpret_cast<const dlsa_d2v*>(ptr)); return double2{t_.x, t_.y}; }())
+#else
+#define DLSA_LOGIT_LD2(ptr) (*reinterpret_cast<const double2*>(ptr))
+#endif
+
 namespace dlsa {
 
 constexpr int LOGIT_THREADS = 256;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
                 const int col = c * 128 + 2 * lane;
                 const int c0 = col < a.p ? col : 0;                   // clamped first column
                 if (VEC) {                                            // VEC implies p even: a pair never straddles p
-                    x[i][c] = *reinterpret_cast<const double2*>(rowp + c0);
+                    x[i][c] = DLSA_LOGIT_LD2(rowp + c0);
                 } else {
                     x[i][c].x = rowp[c0];
                     x[i][c].y = rowp[col + 1 < a.p ? col + 1 : 0];
