@@ -42,7 +42,7 @@ void gram_reduce_launch(const T* partial, int nslab, int PP, int p, T* H, int64_
 #endif
 constexpr int NARROW_KC = DLSA_NARROW_KC;         // rows per chunk: a multiple of 16 (KC/16 k-steps per wave)
 #ifndef DLSA_STREAM_AUX
-#define DLSA_STREAM_AUX 0           // experiment: 2 = nt on the row stream (each row is read by one workgroup, once)
+#define DLSA_STREAM_AUX 2           // nt on the LDS-DMA row stream (each row is read by one workgroup, once): ring logit pass -7..-8 % at p = 100-112, narrow Gram +3 % at p = 64, neutral at p = 100; 0 = default policy
 #endif
 #ifndef DLSA_NARROW_STAGES
 #define DLSA_NARROW_STAGES 3          // experiment: 2 = two 32-row stages (half the barriers per row, the DMA one chunk ahead) where two workgroups share a CU

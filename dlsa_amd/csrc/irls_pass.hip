@@ -25,7 +25,7 @@
 #include <type_traits>
 
 #ifndef DLSA_STREAM_AUX
-#define DLSA_STREAM_AUX 0           // experiment: 2 = nt on the row stream (each row is read by one workgroup, once)
+#define DLSA_STREAM_AUX 2           // nt on the LDS-DMA row stream (each row is read by one workgroup, once): ring logit pass -7..-8 % at p = 100-112, narrow Gram +3 % at p = 64, neutral at p = 100; 0 = default policy
 #endif
 
 namespace dlsa {
