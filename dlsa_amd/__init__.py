@@ -7,7 +7,7 @@ interface (dlsa/models.py, dlsa/dlsa.py, dlsa/lsa.py).  There is no CPU fallback
 """
 __version__ = "0.1.0"
 
-from .models import (MappedBlocks, fit_linear_partitions, fit_linear_streaming, fit_logistic_design, fit_logistic_partitions, linear_model,   # noqa: E402,F401
+from .models import (MappedBlocks, fit_linear_chunks, fit_linear_partitions, fit_linear_streaming, fit_logistic_design, fit_logistic_partitions, linear_model,   # noqa: E402,F401
                      logistic_model, logistic_model_eval, simulate_logistic)
 from .design import DesignSpec, design_matrix                                                    # noqa: E402,F401
 from .dlsa import dlsa, dlsa_fit, dlsa_mapred, dlsa_mapreduce                                   # noqa: E402,F401

@@ -377,6 +377,81 @@ def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=2026010
     return _linear_finish(blocks, coef, smc, sig, names, n)
 
 
+def fit_linear_chunks(chunks, p, partition_num=1, fit_intercept=False, dtype=None, names=None, device="cuda", sample_size=None):
+    """The linear map step for rows that live OUTSIDE HBM (host memory, files read chunk by chunk: `dlsa_amd.ingest`):
+    `chunks` yields `(k, X, y)` -- rows of partition k, X [m, p] and y [m] as numpy arrays or torch tensors, on the host
+    (pinned memory makes the copy asynchronous) or already on the device, any m >= 1, any order of k.  Two device chunk
+    buffers: the host -> HBM copy of chunk i + 1 runs on a copy stream (SDMA engines, no CU) while chunk i goes through the
+    Gram kernel (accumulating) and the X'y pass on the caller's stream, so a PCIe-bound source costs max(copy, compute) per
+    chunk instead of their sum.  A host chunk may be reused by the producer as soon as the NEXT item is requested (the copy
+    out of it has completed by then).  Every chunk of one call has the same dtype (fp32 -> fp32 MFMA Gram summed in fp64,
+    fp64 -> fp64 Gram); blocks are fp64.  Peak device memory = two buffers of the largest chunk + K blocks.
+    Returns MappedBlocks (`loglik` slot = residual sum of squares per partition), as fit_linear_partitions does."""
+    K = int(partition_num)
+    p = int(p)
+    if K < 1 or p < 1:
+        raise ValueError("fit_linear_chunks: need partition_num >= 1 and p >= 1")
+    if not torch.cuda.is_available():
+        raise RuntimeError("fit_linear_chunks runs on the GPU only (no CPU fallback)")
+    pp = p + (1 if fit_intercept else 0)
+    if names is None:
+        names = ["x" + str(i) for i in range(p)]
+    names = (["intercept"] if fit_intercept else []) + list(names)
+    coef = torch.zeros((K, pp), dtype=torch.float64, device=device)
+    smc = torch.zeros((K, pp), dtype=torch.float64, device=device)
+    sig = torch.zeros((K, pp, pp), dtype=torch.float64, device=device)
+    blocks = [None] * K
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    Xbuf, ybuf = [None, None], [None, None]
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    done = [None, None]
+    rows_seen = 0
+    side.wait_stream(main)
+    for i, item in enumerate(chunks):
+        k, Xc, yc = item
+        k = int(k)
+        if not 0 <= k < K:
+            raise ValueError("fit_linear_chunks: partition index %d outside 0..%d" % (k, K - 1))
+        Xc = torch.from_numpy(Xc) if isinstance(Xc, np.ndarray) else Xc
+        yc = torch.from_numpy(yc) if isinstance(yc, np.ndarray) else yc
+        if Xc.dim() != 2 or Xc.shape[1] != p or yc.dim() != 1 or yc.shape[0] != Xc.shape[0]:
+            raise ValueError("fit_linear_chunks: chunk %d has X %s, y %s (need [m, %d] and [m])" % (i, tuple(Xc.shape), tuple(yc.shape), p))
+        m = int(Xc.shape[0])
+        if m == 0:
+            continue
+        if dtype is None:
+            dtype = Xc.dtype if Xc.dtype in (torch.float32, torch.float64) else torch.float64
+        b = i & 1
+        if Xc.is_cuda and Xc.dtype == dtype and Xc.stride(1) == 1 and yc.is_cuda:
+            # rows already in HBM: no staging copy (the caller keeps them alive until the call returns)
+            Xd, yd = Xc, yc if yc.dtype == dtype else yc.to(dtype)
+        else:
+            with torch.cuda.stream(side):
+                if done[b] is not None:
+                    side.wait_event(done[b])             # the kernels that read this buffer two chunks ago have finished
+                if Xbuf[b] is None or Xbuf[b].shape[0] < m:
+                    if done[b] is not None:
+                        done[b].synchronize()            # (growing a buffer: its old storage must be idle before it is freed)
+                    Xbuf[b] = engine.empty_rows(m, p, dtype, device)
+                    ybuf[b] = torch.empty((m,), dtype=dtype, device=device)
+                Xbuf[b][:m].copy_(Xc, non_blocking=True)
+                ybuf[b][:m].copy_(yc, non_blocking=True)
+                ready[b].record(side)
+            main.wait_event(ready[b])
+            Xd, yd = Xbuf[b][:m], ybuf[b][:m]
+        if blocks[k] is None:
+            blocks[k] = _LinearBlock(p, fit_intercept, sig[k], smc[k], device)
+        blocks[k].add(Xd, yd)
+        done[b] = torch.cuda.Event()
+        done[b].record(main)
+        rows_seen += m
+        if not Xc.is_cuda:
+            ready[b].synchronize()                       # the producer may overwrite its host chunk from here on
+    main.wait_stream(side)
+    return _linear_finish(blocks, coef, smc, sig, names, rows_seen if sample_size is None else int(sample_size))
+
+
 def linear_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_factors_baseline=[], data_info=[]):
     """Frame-level sibling of logistic_model for a linear response: same arguments, same
     p x (3+p) output frame `par_id, coef, Sig_invMcoef, [intercept,] <features>`."""

@@ -102,3 +102,8 @@ def test_engine_refuses_cpu_tensors():
     from dlsa_amd import engine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         engine.gram(torch.zeros(4, 2, dtype=torch.float64))
+    if not torch.cuda.is_available():
+        import numpy as np
+        import dlsa_amd
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            dlsa_amd.fit_linear_chunks([(0, np.zeros((4, 2)), np.zeros(4))], 2)

@@ -173,3 +173,55 @@ def test_linear_edge_cases_empty_rows_and_partitions(eng):
     mb2 = dlsa_amd.fit_linear_partitions(torch.randn((30, 3), dtype=torch.float64, device="cuda"),
                                          torch.randn(30, dtype=torch.float64, device="cuda"), part_offsets=[0, 0, 30])
     assert mb2.status == [4, 0] and float(mb2.Sig_inv[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype,icpt,pinned", [("f64", True, True), ("f64", False, False), ("f32", True, True)])
+def test_linear_chunks_from_host_equal_resident_fit_and_global_ols(eng, orc, dtype, icpt, pinned):
+    """Rows that live in HOST memory, handed over as ragged chunks in a shuffled partition order (numpy arrays or pinned
+    tensors; the copy of chunk i + 1 overlaps the kernels of chunk i): the blocks of the resident fit, the global OLS."""
+    import dlsa_amd
+    n, p, K, seed = 41000, 36, 3, 20260107
+    X, y = orc.synth_linear(seed, 0, n, p, orc.SYNTH_UNIFORM)
+    y = y + (0.3 if icpt else 0.0)
+    ndt = np.float64 if dtype == "f64" else np.float32
+    Xh, yh = X.astype(ndt), y.astype(ndt)
+    rng = np.random.default_rng(3)
+    cuts = np.sort(rng.choice(np.arange(1, n), size=11, replace=False))
+    pieces = [(int(a), int(b)) for a, b in zip(np.r_[0, cuts], np.r_[cuts, n])]
+    pieces = [pieces[i] for i in rng.permutation(len(pieces))]
+    part_of = lambda a: (a * K) // n                                 # partition of a chunk = of its first row (any rule works)
+
+    def produce():
+        for a, b in pieces:
+            if pinned:
+                yield part_of(a), torch.from_numpy(Xh[a:b].copy()).pin_memory(), torch.from_numpy(yh[a:b].copy()).pin_memory()
+            else:
+                yield part_of(a), Xh[a:b], yh[a:b]
+        yield 0, np.zeros((0, p), ndt), np.zeros((0,), ndt)          # an empty chunk is skipped
+
+    mb = dlsa_amd.fit_linear_chunks(produce(), p, partition_num=K, fit_intercept=icpt)
+    assert mb.status == [0] * K and mb.sample_size == n
+    X64, y64 = Xh.astype(np.float64), yh.astype(np.float64)
+    A = np.hstack([np.ones((n, 1)), X64]) if icpt else X64
+    tol = 1e-11 if dtype == "f64" else 2e-6
+    for k in range(K):
+        rows = np.concatenate([np.arange(a, b) for a, b in pieces if part_of(a) == k])
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), A[rows].T @ A[rows]) < tol
+        assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), A[rows].T @ y64[rows]) < tol * 10
+    out = dlsa_amd.dlsa_mapred(mb)
+    assert rel_inf(out["beta_byOLS"].to_numpy(), np.linalg.lstsq(A, y64, rcond=None)[0]) < (1e-9 if dtype == "f64" else 2e-5)
+
+
+def test_linear_chunks_device_chunks_and_errors(eng, orc):
+    import dlsa_amd
+    n, p = 9000, 12
+    X, y = orc.synth_linear(11, 0, n, p, orc.SYNTH_UNIFORM)
+    Xd, yd = dev(X), dev(y)
+    mb = dlsa_amd.fit_linear_chunks([(0, Xd[:5000], yd[:5000]), (1, Xd[5000:], yd[5000:]), (0, X[:0], y[:0])], p, partition_num=3)
+    assert mb.status == [0, 0, 4]                                    # partition 2 saw no rows: the reference's zero block
+    ref = dlsa_amd.fit_linear_partitions(Xd, yd, part_offsets=[0, 5000, n, n])
+    assert torch.equal(mb.Sig_inv, ref.Sig_inv) and torch.equal(mb.Sig_invMcoef, ref.Sig_invMcoef)
+    with pytest.raises(ValueError, match="partition index"):
+        dlsa_amd.fit_linear_chunks([(3, X, y)], p, partition_num=3)
+    with pytest.raises(ValueError, match="need \\[m, 12\\]"):
+        dlsa_amd.fit_linear_chunks([(0, X[:, :5], y)], p, partition_num=1)
