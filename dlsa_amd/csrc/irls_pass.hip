@@ -43,7 +43,15 @@ size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 #include "gram_narrow_asm.inc"
 
 constexpr int FP_KC = 32;                 // rows per chunk: two k-steps per wave
-constexpr int FP_NST = 4;                 // LDS stages: the DMA runs three chunks ahead
+constexpr int FP_NST = 4;                 // LDS stages of the fused pass: the DMA runs three chunks ahead of the MFMAs, two ahead of the logistic terms
+// ... of the logit-only pass: nothing reads chunk c once its logistic terms are done, so D stages keep D - 1 chunks between
+// "requested" and "in use".  Three everywhere: five stages for the one-workgroup shapes (102 instead of 51 KB in flight per CU at
+// p = 100) measured no gain (p = 100 1.35-1.40 ms, p = 112 1.54 ms either way), and the two-workgroup shapes (below) fit three twice.
+constexpr int fp_logit_stages(int ntc) { (void)ntc; return 3; }
+// The logit-only pass evaluates ~100 dependent fp64 operations per 8 rows in ONE wave per SIMD: for short rows (p <= 80) that
+// chain, not HBM, sets the pace (p = 50: 57 cycles per row and CU where the stream needs 38).  Its three-stage ring is <= 63 KB
+// there, so two workgroups share a CU: two chains per SIMD, twice the bytes in flight.
+constexpr int fp_logit_wgs(int ntc) { return ntc <= 5 ? 2 : 1; }
 constexpr int FP_MIN_P = 49, FP_MAX_P = 120;
 constexpr int64_t FP_MIN_ROWS = 8192;
 
@@ -150,7 +158,7 @@ struct LogitState {
 // HESS = false: the same streaming skeleton without the Hessian -- the logit pass of narrow designs (w, g, loglik) fed by the
 // LDS-DMA ring instead of logit.hip's register loads
 template <bool WOUT, bool HESS, int NT, int G>
-__global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 1)) void irls_pass_narrow_kernel(FusedArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef double d2 __attribute__((ext_vector_type(2)));
     constexpr int KC = FP_KC, NWAVES = 4, THREADS = 256;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
     __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + rbeg), 0, nrows * 8, 0x00020000);
     // columns p .. 16 NTC - 1 are never written by the DMA (lanes masked): the ring is zeroed once
-    for (int e = tid; e < FP_NST * BUF; e += THREADS) lds[e] = 0.0;
+    for (int e = tid; e < (HESS ? FP_NST : fp_logit_stages(NTC)) * BUF; e += THREADS) lds[e] = 0.0;
     __syncthreads();
 
     const bool col_in = 2 * lane < a.p;
@@ -319,31 +327,33 @@ __global__ __launch_bounds__(256, 1) void irls_pass_narrow_kernel(FusedArgs a) {
 
     if constexpr (HESS) narrow_acc_zero<fp_nreg(NT, G)>();
 
-    // ---- prologue: chunks 0 .. 2 in flight; chunks 0 and 1 landed; the logistic terms of chunk 0
+    // ---- prologue: chunks 0 .. 2 in flight (logit only: 0 .. D - 1); chunks 0 and 1 landed; the logistic terms of chunk 0
+    constexpr int D = HESS ? 3 : fp_logit_stages(NTC);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
+    for (int ch = 0; ch < D; ++ch) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) stage_rows(ch, ch, q);
         stage_y(ch, ch);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * DMA_PER_CHUNK) : "memory");
     asm volatile("s_barrier" ::: "memory");
     logit_all(0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!HESS) asm volatile("s_barrier" ::: "memory");       // the loop's first DMA overwrites chunk 0, which every wave must have left
 
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);
     int cur = 0;
     if constexpr (!HESS) {
         for (int c = 0; c < nchunks; ++c) {
-            const int nxt = (cur + 1) & 3, nxt3 = (cur + 3) & 3;
+            const int nxt = cur == D - 1 ? 0 : cur + 1;                 // D stages: chunk c + D replaces chunk c, done with
 #pragma unroll
-            for (int q = 0; q < 4; ++q) stage_rows(c + 3, nxt3, q);
-            stage_y(c + 3, nxt3);
+            for (int q = 0; q < 4; ++q) stage_rows(c + D, cur, q);
+            stage_y(c + D, cur);
             __builtin_amdgcn_sched_barrier(0);
             logit_all(c + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * DMA_PER_CHUNK) : "memory");     // chunk c + 2 has landed
             asm volatile("s_barrier" ::: "memory");
             cur = nxt;
         }
@@ -480,8 +490,8 @@ static void fp_shape(int p, int& nt, int& g) {
     if (g == 4) { ++nt; g = 0; }
 }
 
-static int fp_slabs(int64_t n, int64_t& rows_per_slab) {
-    int64_t ns = std::min<int64_t>(kNumCU, std::max<int64_t>(1, n / 2048));
+static int fp_slabs(int64_t n, int64_t& rows_per_slab, int wgs_per_cu = 1) {
+    int64_t ns = std::min<int64_t>((int64_t)kNumCU * wgs_per_cu, std::max<int64_t>(1, n / 2048));
     rows_per_slab = ((n + ns - 1) / ns + FP_KC - 1) / FP_KC * FP_KC;
     return (int)((n + rows_per_slab - 1) / rows_per_slab);
 }
@@ -495,7 +505,7 @@ bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int
     int64_t rps;
     fp_slabs(n, rps);
     return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0 &&          // (the y pieces are dword-aligned buffer loads)
-           (double)(rps + 4 * FP_KC) * (double)ldx * 8.0 < 2.0e9;                    // 32-bit DMA offsets
+           (double)(rps + 8 * FP_KC) * (double)ldx * 8.0 < 2.0e9;                    // 32-bit DMA offsets
 }
 
 static size_t fp_fused_ws_bytes(int64_t n, int p) {
@@ -504,7 +514,9 @@ static size_t fp_fused_ws_bytes(int64_t n, int p) {
     int nt, g;
     fp_shape(p, nt, g);
     const int ntc = nt + (g > 0 ? 1 : 0);
-    return align_up((size_t)ns * fp_pp(p) * fp_pp(p) * 8, 256) + align_up((size_t)ns * fp_gp(ntc) * 8, 256) + kGramProbeBytes;
+    int64_t rps2;
+    const int ns_logit = fp_slabs(n, rps2, fp_logit_wgs(ntc));          // the logit-only launch of short rows: two workgroups per CU
+    return align_up((size_t)ns * fp_pp(p) * fp_pp(p) * 8, 256) + align_up((size_t)std::max(ns, ns_logit) * fp_gp(ntc) * 8, 256) + kGramProbeBytes;
 }
 
 size_t irls_pass_workspace_bytes_impl(int64_t n, int p) {
@@ -532,10 +544,10 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     }
     FusedArgs a;
     a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p; a.PP = (int)fp_pp(p);
-    const int nslab = fp_slabs(n, a.rows_per_slab);
     int nt, gt;
     fp_shape(p, nt, gt);
     const int ntc = nt + (gt > 0 ? 1 : 0), GP = fp_gp(ntc);
+    const int nslab = fp_slabs(n, a.rows_per_slab, H ? 1 : fp_logit_wgs(ntc));
     const size_t part = H ? align_up((size_t)nslab * a.PP * a.PP * 8, 256) : 0, gpb = align_up((size_t)nslab * GP * 8, 256);
     const size_t need = part + gpb + kGramProbeBytes;
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
@@ -546,7 +558,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     a.gpart = (double*)((char*)ws + part);
     a.clk = (unsigned long long*)((char*)ws + part + gpb);
 #define DLSA_LAUNCH_FP2(WO, HS, NTV, GV) do { \
-        const size_t shm = (size_t)FP_NST * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
+        const size_t shm = (size_t)((HS) ? FP_NST : fp_logit_stages(NTV + (GV > 0 ? 1 : 0))) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, HS, NTV, GV>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, HS, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)

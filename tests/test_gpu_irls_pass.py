@@ -121,3 +121,20 @@ def test_ring_logit_pass_is_block_invariant_and_handles_odd_label_offsets(eng, o
     # g only / loglik only / w only
     _, g3, _ = eng.logit_pass(Xd, yd, bd, want_w=False, want_loglik=False)
     assert torch.equal(g3, g)
+
+
+@pytest.mark.parametrize("p,n", [(50, 8192), (50, 70001), (64, 33333), (80, 41234), (96, 20000), (120, 9000)])
+def test_ring_logit_pass_short_rows_two_workgroups_per_cu(eng, orc, p, n):
+    """Short rows (<= 5 tile columns) run the logit-only ring with three stages and two workgroups per CU; longer ones one.
+    Both against the oracle; repeated calls give identical bits (fixed slab order)."""
+    X, y = orc.synth_logistic(91 + p, 0, n, p, orc.SYNTH_GAUSSIAN)
+    beta = orc.true_beta(p) * 0.6
+    Xd, yd, bd = dev(X), dev(y), dev(beta)
+    w, g, ll = eng.logit_pass(Xd, yd, bd)
+    assert eng.gram_last_kernel()[0].startswith("irls_pass_narrow_kernel<true,false"), eng.gram_last_kernel()
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    assert rel_inf(w.cpu().numpy(), wo) < 1e-12
+    assert np.max(np.abs(g.cpu().numpy() - go)) < 1e-12 * np.max(np.abs(X).sum(0))
+    assert abs(float(ll) - llo) < 1e-12 * abs(llo)
+    w2, g2, ll2 = eng.logit_pass(Xd, yd, bd)
+    assert torch.equal(w, w2) and torch.equal(g, g2) and torch.equal(ll, ll2)
