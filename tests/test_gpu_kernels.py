@@ -508,3 +508,24 @@ def test_full_size_properties_p500(eng):
         xs = X[r:r + step]
         col += (xs * (xs[:, 3] * w[r:r + step])[:, None]).sum(0)
     assert float((col - H[3]).abs().max()) < 1e-11 * scale
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_lars_randomised_problems_match_oracle(eng, orc, seed):
+    """Seeded random LSA problems (p 2..90, three correlation structures, lar / lasso, with and without the intercept
+    branch): the whole path, beta0, AIC, BIC and the step count against the oracle's restatement of lsa.py:90-212."""
+    rng = np.random.default_rng(9000 + seed)
+    p = int(rng.integers(2, 91))
+    intercept = bool(rng.random() < 0.4) and p > 2
+    typ = "lasso" if rng.random() < 0.5 else "lar"
+    rho = float(rng.choice([0.0, 0.5, 0.9, 0.97]))
+    S, b, n = _correlated_lsa_problem(p, rho, 9100 + seed)
+    if rng.random() < 0.3:                                        # sparse truth: some coefficients near zero enter late
+        b[rng.random(p) < 0.5] *= 1e-3
+    ro = orc.lars_lsa(S, b, intercept, n, type=typ)
+    r = eng.lars_path(dev(S), dev(b), intercept, float(n), type=typ)
+    assert r["beta"].shape == ro["beta"].shape, (p, typ, intercept, rho)
+    assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
+    assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7 and rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
+    if intercept:
+        assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7
