@@ -88,6 +88,32 @@ def test_onehot_passes_match_dense_oracle(api, orc, n, q, nlevels):
         assert plan.roles >= 2                                  # the 110 x 110 table gets a role of its own
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_onehot_passes_randomised_designs(api, orc, seed):
+    """Seeded random designs: 0-7 numerics, 1-5 factors of 2-120 levels (a few rows with an unknown level), with and without
+    intercept / baselines, 1-40000 rows -- structured logit pass and Gram against the oracle on the dense matrix."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 6000), rng.integers(6000, 40000)]))
+    q = int(rng.integers(0, 8))                                  # the structured plan holds at most 8 dense columns (1 + 7)
+    nlevels = tuple(int(rng.choice([rng.integers(2, 8), rng.integers(8, 40), rng.integers(40, 121)])) for _ in range(int(rng.integers(1, 6))))    # (a pair table must fit LDS: <= ~140 x 140)
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, q, nlevels, intercept=bool(rng.random() < 0.7), baseline=bool(rng.random() < 0.7))
+    if n > 10:
+        codes[rng.integers(0, n, max(1, n // 40)), int(rng.integers(0, len(nlevels)))] = -1
+    plan = _plan(api, p, desc, nl, level_col)
+    X, _ = orc.design_matrix(num, codes, *desc)
+    beta = rng.normal(size=p) * float(rng.choice([0.05, 0.4, 1.5]))
+    y = (rng.random(n) < 0.5).astype(np.float64)
+    wo, go, llo = orc.logit_pass(X, y, beta)
+    w, g, ll = engine.onehot_logit_pass(plan, dev(num) if q else None, dev(codes), dev(y), dev(beta))
+    assert rel_inf(w.cpu().numpy(), wo) < 1e-12, (n, q, nlevels)
+    assert np.max(np.abs(g.cpu().numpy() - go)) < 1e-11 * max(1.0, np.max(np.abs(X).sum(0))) and abs(ll.item() - llo) < 1e-11 * abs(llo)
+    H = engine.onehot_gram(plan, dev(num) if q else None, dev(codes), dev(wo)).cpu().numpy()
+    Ho = orc.gram(X, wo)
+    assert np.max(np.abs(H - Ho)) < 1e-12 * max(np.max(np.abs(Ho)), 1e-300), (n, q, nlevels)
+    assert np.array_equal(H, H.T)
+
+
 def test_onehot_passes_are_bit_reproducible(api):
     """Deterministic accumulation (the default): the Gram adds 64-bit fixed-point integers to its LDS tables (order-independent),
     the logit pass takes turns by wave, so the gradient, the Hessian and a whole structured fit come out bit-identical run
