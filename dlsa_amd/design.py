@@ -10,6 +10,8 @@ the n x p matrix itself is written by `dlsa_design_f64` on the device, so what c
 n x (q numeric + f codes) instead of n x p, and a shard whose codes are already in HBM never touches
 the host at all.
 """
+import warnings
+
 import numpy as np
 import pandas as pd
 import torch
@@ -17,6 +19,15 @@ import torch
 from . import engine
 
 OTHERS = "000_OTHERS"      # models.py:60
+
+
+def _row_major(t):
+    """[n, q] with strides (q, 1) exactly (`.contiguous()` keeps whatever stride a size-1 dimension has)."""
+    if t.stride(1) == 1 and t.stride(0) == t.shape[1]:
+        return t
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
 
 
 class DesignSpec:
@@ -80,13 +91,19 @@ class DesignSpec:
                    np.asarray(kind, np.int32), np.asarray(src, np.int32), np.asarray(level, np.int32),
                    np.asarray(shift, np.float64), np.asarray(scale, np.float64), dummy_cols)
 
-    def encode(self, sample_df, dummy_info=[]):
+    def _numeric_host(self, sample_df):
+        """The numeric columns as one fp64 host array [n, q], in whatever order pandas hands it over (to_numpy() of a
+        single-dtype frame is a column-major view of its block: engine.rows_to_device() uploads that and transposes in HBM)."""
+        if not self.numeric_cols:
+            return np.zeros((len(sample_df), 0))
+        return sample_df[self.numeric_cols].to_numpy(dtype=np.float64)
+
+    def encode(self, sample_df, dummy_info=[], numeric=True):
         """Host step: numeric columns as one fp64 array, categorical columns as int32 level codes
         (dropped levels fold into the OTHERS code, models.py:60; a level that is neither selected nor
         dropped gets -1 and `unknown` is set -- get_dummies would have produced an unexpected column)."""
         n = len(sample_df)
-        num = np.ascontiguousarray(sample_df[self.numeric_cols].to_numpy(dtype=np.float64)) if self.numeric_cols \
-            else np.zeros((n, 0))
+        num = np.ascontiguousarray(self._numeric_host(sample_df)) if numeric else None      # row-major for host users (ingest)
         codes = np.zeros((n, len(self.factors)), dtype=np.int32)
         unknown = False
         for fi, fct in enumerate(self.factors):
@@ -123,6 +140,43 @@ class DesignSpec:
         except Exception:
             self._oh_plan = None
         return self._oh_plan
+
+    def numeric_to_device(self, sample_df, device="cuda"):
+        """The numeric columns as a row-major fp64 device tensor [n, q] (None when q == 0) without a host-side gather: a
+        frame that arrives column by column (Arrow / read_csv: every column a contiguous array) is uploaded column by column
+        into a [q, n] buffer and transposed in HBM; other layouts take encode()'s array through engine.rows_to_device()."""
+        q, n = len(self.numeric_cols), len(sample_df)
+        if q == 0:
+            return None
+        if n * q >= (1 << 16):
+            cols = [sample_df[c].to_numpy() for c in self.numeric_cols]            # per-column views, no copy
+            if all(c.dtype == np.float64 and c.ndim == 1 and c.flags.c_contiguous for c in cols):
+                buf = torch.empty((q, n), dtype=torch.float64, device=device)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")                                   # (read-only views under copy-on-write)
+                    for j, c in enumerate(cols):
+                        buf[j].copy_(torch.from_numpy(c))
+                return _row_major(buf.t())
+            # A frame built FROM a row-major array (pd.DataFrame(ndarray), the reference's simulate_logistic): every column is a
+            # strided view of the same [n, width] parent.  The window of parent columns that holds them goes up as one strided
+            # tensor (torch gathers it with all host threads; pandas' column subset is a single-threaded copy, 73 ms per 1e6 x 100)
+            # and the wanted columns are picked in HBM.
+            strides = {c.strides[0] for c in cols}
+            if len(strides) == 1 and all(c.dtype == np.float64 and c.ndim == 1 for c in cols):
+                S = strides.pop()
+                addr = [c.ctypes.data for c in cols]
+                a0 = min(addr)
+                w = (max(addr) - a0) // 8 + 1
+                if S > 8 and S % 8 == 0 and w <= S // 8 and all((a - a0) % 8 == 0 for a in addr):
+                    window = np.lib.stride_tricks.as_strided(cols[addr.index(a0)], shape=(n, w), strides=(S, 8), writeable=False)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        Wd = torch.from_numpy(window).to(device)
+                    idx = [(a - a0) // 8 for a in addr]
+                    if idx == list(range(q)) and w == q:
+                        return _row_major(Wd)
+                    return _row_major(Wd.index_select(1, torch.tensor(idx, dtype=torch.int64, device=device)))
+        return engine.rows_to_device(self._numeric_host(sample_df), device)
 
     def missing_levels(self, codes):
         """Names of the dummy columns whose level does not occur in `codes` (host array or device tensor [n, f])."""

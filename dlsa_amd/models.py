@@ -74,9 +74,9 @@ def _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_b
     names = [intercept,] usecols_x)."""
     spec = DesignSpec.from_reference(list(sample_df.columns), Y_name, fit_intercept, dummy_info,
                                      ([] if (for_eval and len(dummy_info) == 0) else dummy_factors_baseline), data_info)
-    num, codes, unknown = spec.encode(sample_df, dummy_info)
+    _, codes, unknown = spec.encode(sample_df, dummy_info, numeric=False)
     dev = torch.device("cuda")
-    X, missing = spec.build(torch.from_numpy(num).to(dev), torch.from_numpy(codes).to(dev))
+    X, missing = spec.build(spec.numeric_to_device(sample_df, dev), torch.from_numpy(codes).to(dev))
     if missing or unknown:          # models.py:80-91 / :187-194
         shape = (len(sample_df), len(spec.names) - (1 if fit_intercept else 0) - len(missing))
         if not for_eval:
@@ -103,14 +103,14 @@ def logistic_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_
         plan = spec.onehot_plan()
         if plan is not None:
             names = spec.names
-            num, codes, unknown = spec.encode(sample_df, dummy_info)
+            _, codes, unknown = spec.encode(sample_df, dummy_info, numeric=False)
             missing = spec.missing_levels(codes)
             if missing or unknown:
                 shape = (len(sample_df), len(names) - (1 if fit_intercept else 0) - len(missing))
                 warnings.warn("Dummies:" + str(set(missing)) + "missing in this data chunk " + str(shape)
                               + "Skip modeling this part of data.")
                 return pd.DataFrame(0, index=np.arange(len(names)), columns=["par_id", "coef", "Sig_invMcoef"] + names)
-            r = engine.onehot_irls_fit(plan, torch.from_numpy(num).cuda(), torch.from_numpy(codes).cuda(), yd, [0, len(sample_df)])
+            r = engine.onehot_irls_fit(plan, spec.numeric_to_device(sample_df), torch.from_numpy(codes).cuda(), yd, [0, len(sample_df)])
     if r is None:
         Xd, names = _device_design(sample_df, Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
         if Xd is None:

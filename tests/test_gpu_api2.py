@@ -132,3 +132,24 @@ def test_cabi_rccl_allreduce_single_rank_communicator():
     with pytest.raises(TypeError):
         comm.allreduce(msg.float())
     comm.close()
+
+
+def test_logistic_model_same_block_for_columnar_and_row_major_frames(api):
+    """The frame-level operator takes the numeric columns as pandas holds them: a frame built column by column (the Arrow /
+    read_csv layout: uploaded per column, transposed in HBM), one built from a row-major array, and one with the feature
+    columns scattered between other columns must give the same block, bit for bit."""
+    import numpy as np
+    import pandas as pd
+    rng = np.random.default_rng(12)
+    n, p = 3000, 24                                  # n * p >= 2^16: the per-column upload path
+    X = rng.random((n, p)) - 0.5
+    y = (rng.random(n) < 1 / (1 + np.exp(-X[:, :8].sum(1)))).astype(np.int64)
+    names = ["x%d" % i for i in range(p)]
+    row_major = pd.DataFrame(X, columns=names); row_major.insert(0, "label", y); row_major.insert(0, "partition_id", 0)
+    columnar = pd.DataFrame({"partition_id": 0, "label": y, **{c: np.ascontiguousarray(X[:, i]) for i, c in enumerate(names)}})
+    scattered = columnar[["partition_id"] + names[:5] + ["label"] + names[5:]]
+    outs = [api.logistic_model(df, "label", fit_intercept=True) for df in (row_major, columnar, scattered)]
+    assert list(outs[0].columns) == ["par_id", "coef", "Sig_invMcoef", "intercept"] + names
+    for o in outs[1:]:
+        assert list(o.columns) == list(outs[0].columns)
+        assert np.array_equal(o.to_numpy(), outs[0].to_numpy())
