@@ -104,16 +104,36 @@ class DesignSpec:
         dropped gets -1 and `unknown` is set -- get_dummies would have produced an unexpected column)."""
         n = len(sample_df)
         num = np.ascontiguousarray(self._numeric_host(sample_df)) if numeric else None      # row-major for host users (ingest)
-        codes = np.zeros((n, len(self.factors)), dtype=np.int32)
-        unknown = False
-        for fi, fct in enumerate(self.factors):
-            col = sample_df[fct].astype(str)
+        # One hash pass per factor (pd.factorize), then the FEW distinct values are turned into strings and looked up: the level
+        # of a value is what the reference's astype(str) / replace / get_dummies chain gives it, without a string operation per row
+        # (1e6 rows x 5 factors: 242 -> ~60 ms).
+        cols, unknown = [], False
+        for fct in self.factors:
+            if isinstance(sample_df[fct].dtype, pd.CategoricalDtype):
+                # already dictionary-encoded: the codes are there, only the categories need a string each (NaN = one more entry)
+                uniq = list(sample_df[fct].cat.categories) + [np.nan]
+                fc = sample_df[fct].cat.codes.to_numpy().astype(np.int64)
+                fc = np.where(fc < 0, len(uniq) - 1, fc)
+            else:
+                fc, uniq = pd.factorize(sample_df[fct], use_na_sentinel=False)
             dropped = set(str(x) for x in dummy_info["factor_dropped"][fct]) if len(dummy_info) > 0 else set()
-            if dropped:
-                col = col.where(~col.isin(dropped), OTHERS)
-            c = pd.Categorical(col, categories=self.levels[fct]).codes.astype(np.int32)
+            index = {lv: i for i, lv in enumerate(self.levels[fct])}
+            lut = np.empty(max(len(uniq), 1), dtype=np.int32)
+            lut[:] = -1
+            if sample_df[fct].dtype == object and len(uniq) and bool(pd.isna(np.asarray(uniq, dtype=object)).any()):
+                # None / NaN in an object column keep their own spellings under astype(str) ('None', 'nan'); factorize merges them
+                col = sample_df[fct].astype(str)
+                if dropped:
+                    col = col.where(~col.isin(dropped), OTHERS)
+                c = pd.Categorical(col, categories=self.levels[fct]).codes.astype(np.int32)
+            else:
+                for u, raw in enumerate(uniq):
+                    sv = str(raw)
+                    lut[u] = index.get(OTHERS if sv in dropped else sv, -1)
+                c = lut[fc]
             unknown |= bool((c < 0).any())
-            codes[:, fi] = c
+            cols.append(c)
+        codes = np.stack(cols, axis=1) if cols else np.zeros((n, 0), dtype=np.int32)
         return num, codes, unknown
 
     def onehot_plan(self):
@@ -183,7 +203,10 @@ class DesignSpec:
         if torch.is_tensor(codes):
             present = [set(torch.unique(codes[:, t]).cpu().tolist()) for t in range(codes.shape[1])]
         else:
-            present = [set(np.unique(codes[:, t]).tolist()) for t in range(codes.shape[1])]
+            present = []
+            for t in range(codes.shape[1]):
+                c = codes[:, t]
+                present.append(set(np.nonzero(np.bincount(c[c >= 0], minlength=1))[0].tolist()) | ({-1} if (c < 0).any() else set()))
         return [self.names[j] for j in self.dummy_cols if int(self.level[j]) not in present[int(self.src[j])]]
 
     def device_arrays(self, device):

@@ -80,3 +80,45 @@ def test_plain_frame_plan_keeps_frame_order():
     spec = DesignSpec.from_reference(["partition_id", "label", "x2", "x0", "x1"], "label", False)
     assert spec.names == ["x2", "x0", "x1"] and spec.kind.tolist() == [1, 1, 1] and spec.src.tolist() == [0, 1, 2]
     assert spec.shift.tolist() == [0, 0, 0] and spec.scale.tolist() == [1, 1, 1]
+
+
+def test_encode_level_codes_match_the_string_chain_for_every_column_type():
+    """DesignSpec.encode turns a factor into level codes with one hash pass (pd.factorize, or the codes of a categorical column)
+    and a lookup of the few distinct values; the result must be what the reference's per-row chain gives
+    (astype(str) -> fold dropped levels into 000_OTHERS -> position among the selected levels, models.py:56-66), for strings,
+    integers, floats with NaN, object columns holding None, categoricals (with and without NaN) and booleans."""
+    import numpy as np
+    import pandas as pd
+    from dlsa_amd.design import DesignSpec, OTHERS
+    rng = np.random.default_rng(0)
+    n = 2000
+    cases = {
+        "str": pd.Series(rng.choice(["a", "b", "c", "zz"], n)),
+        "int": pd.Series(rng.integers(0, 7, n)),
+        "float": pd.Series(rng.choice([1.0, 2.5, 3.0, np.nan], n)),
+        "objmix": pd.Series(rng.choice(np.array(["x", 1, 2.0, None], dtype=object), n)),
+        "cat": pd.Series(pd.Categorical(rng.choice(["u", "v", "w"], n))),
+        "catnan": pd.Series(pd.Categorical(rng.choice(np.array(["u", "v", None], dtype=object), n))),
+        "bool": pd.Series(rng.random(n) < 0.5),
+    }
+    for name, col in cases.items():
+        us = sorted(set(col.astype(str)))
+        sel = us[: max(1, len(us) - 1)]
+        drop = us[len(sel):]
+        dummy_info = {"factor_selected": {"f": sel}, "factor_dropped": {"f": drop},
+                      "factor_selected_names": {"f": ["f_" + v for v in ([OTHERS] if drop else []) + sel]}}
+        df = pd.DataFrame({"partition_id": 0, "label": 1, "f": col, "x": rng.random(n)})
+        spec = DesignSpec.from_reference(list(df.columns), "label", False, dummy_info, [], [])
+        _, codes, unknown = spec.encode(df, dummy_info)
+        chain = col.astype(str)
+        chain = chain.where(~chain.isin(set(drop)), OTHERS)
+        ref = pd.Categorical(chain, categories=spec.levels["f"]).codes.astype(np.int32)
+        assert np.array_equal(codes[:, 0], ref), name
+        assert not unknown and codes.dtype == np.int32 and codes.flags.c_contiguous
+    # a value that is neither selected nor dropped: code -1 and the flag
+    df = pd.DataFrame({"partition_id": 0, "label": 1, "f": ["a", "b", "q"], "x": [0.1, 0.2, 0.3]})
+    info = {"factor_selected": {"f": ["a", "b"]}, "factor_dropped": {"f": []}, "factor_selected_names": {"f": ["f_a", "f_b"]}}
+    spec = DesignSpec.from_reference(list(df.columns), "label", False, info, [], [])
+    _, codes, unknown = spec.encode(df, info)
+    assert codes[:, 0].tolist() == [0, 1, -1] and unknown
+    assert spec.missing_levels(codes) == [] and spec.missing_levels(codes[:1]) == ["f_b"]
