@@ -164,6 +164,53 @@ def test_mapred_rejects_empty(api):
         api.dlsa_mapred(empty)
 
 
+class _FakeSparkFrame:
+    """The slice of pyspark.sql.DataFrame that dlsa_mapred touches (dlsa.py:30-34,52), backed by pandas; counts what travels."""
+
+    def __init__(self, pdf, partitions):
+        self._pdf, self.columns, self.collected_rows = pdf, list(pdf.columns), []
+        self.rdd = type("rdd", (), {"getNumPartitions": staticmethod(lambda: partitions)})()
+
+    def groupby(self, key):
+        outer = self
+
+        class Grouped:
+            def sum(self, *cols):
+                g = outer._pdf.groupby(key, as_index=False)[list(cols)].sum()
+                g.columns = [key] + ["sum(%s)" % c for c in cols]
+                g = g.sample(frac=1.0, random_state=1)           # Spark returns the groups in no particular order
+                child = _FakeSparkFrame(g, 1)
+                child.collected_rows = outer.collected_rows
+                return child
+        return Grouped()
+
+    def toPandas(self):
+        self.collected_rows.append(len(self._pdf))
+        return self._pdf.copy()
+
+
+def test_mapred_on_a_spark_frame_sums_on_the_spark_side(api, orc):
+    """A Spark DataFrame goes through the reference's own calls -- groupby('par_id').sum(*columns[1:]).toPandas() -- so p rows
+    are collected, not K * p; the result equals the pandas route on the stacked frame, one-shot mean divided by
+    rdd.getNumPartitions() (dlsa.py:30-34,51-52)."""
+    X, y = orc.synth_logistic(3, 0, 9000, 12, orc.SYNTH_UNIFORM)
+    frames = []
+    for k in range(3):
+        df = pd.DataFrame(X[k::3], columns=["x%d" % i for i in range(12)])
+        df.insert(0, "label", y[k::3]); df.insert(0, "partition_id", k)
+        frames.append(api.logistic_model(df, "label"))
+    stacked = pd.concat(frames, ignore_index=True)
+    sdf = _FakeSparkFrame(stacked, 3)
+    out_spark = api.dlsa_mapred(sdf)
+    out_pandas = api.dlsa_mapred(stacked, num_partitions=3)
+    assert sdf.collected_rows == [12]                         # the grouped sums only
+    assert list(out_spark.columns) == list(out_pandas.columns)
+    assert rel_inf(out_spark.to_numpy(), out_pandas.to_numpy()) < 1e-12
+    empty = _FakeSparkFrame(stacked.iloc[:0], 3)
+    with pytest.raises(Exception, match="Zero-length"):
+        api.dlsa_mapred(empty)
+
+
 def test_driver_script_pickle_layout(api, orc, tmp_path):
     """projects/logistic_dlsa.py counterpart: call order map -> dlsa_mapred -> dlsa -> eval and the
     reference's result pickle [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time] (:411)."""
