@@ -24,23 +24,21 @@ def _blocks_from_frame(pdf):
     names = cols[3:]
     p = len(names)
     par_id = pdf.iloc[:, 0].to_numpy(dtype=np.int64)
-    vals = np.ascontiguousarray(pdf.iloc[:, 1:].to_numpy(dtype=np.float64))
+    vals = pdf.iloc[:, 1:].to_numpy(dtype=np.float64)                 # as pandas holds it (often column-major): no host reorder
     if vals.shape[0] == 0:
         raise Exception("Zero-length grouped pandas DataFrame obtained, check the input.")   # dlsa.py:36-39
-    # A stacked FRAME is host data: its blocks go to the device as they are ([K, p] / [K, p, p] when every par_id run is a
-    # whole block, the layout logistic_model emits) and dlsa_sum_blocks_f64 sums them; a frame in any other row order is
-    # grouped on the host first (numpy, the frame's own memory) and handed over as one block.  No torch arithmetic here:
-    # tensors are storage (north star).
+    # A stacked FRAME is host data: it goes to the device as it lies (engine.rows_to_device puts it in row order there) and is
+    # viewed as [K, p, 2 + p] blocks when every par_id run is a whole block (the layout logistic_model emits);
+    # dlsa_sum_blocks_f64 sums them.  A frame in any other row order is grouped on the host first (numpy, the frame's own
+    # memory) and handed over as one block.  No torch arithmetic here: tensors are storage (north star).
     K = vals.shape[0] // p if p else 0
     whole = K >= 1 and vals.shape[0] == K * p and np.array_equal(par_id, np.tile(np.arange(p), K))
     if not whole:
         summed = np.zeros((p, 2 + p))
         np.add.at(summed, par_id, vals)
         vals, K = summed, 1
-    blk = vals.reshape(K, p, 2 + p)
-    coef = torch.from_numpy(np.ascontiguousarray(blk[:, :, 0])).cuda()
-    smc = torch.from_numpy(np.ascontiguousarray(blk[:, :, 1])).cuda()
-    sig = torch.from_numpy(np.ascontiguousarray(blk[:, :, 2:])).cuda()
+    blk = engine.rows_to_device(vals).view(K, p, 2 + p)
+    coef, smc, sig = blk[:, :, 0].contiguous(), blk[:, :, 1].contiguous(), blk[:, :, 2:].contiguous()      # packed in HBM, not on the host
     # message layout [Sig_inv (p*p) | Sig_invMcoef (p) | coef (p)]
     return engine.sum_blocks(coef, smc, sig), names, p
 
