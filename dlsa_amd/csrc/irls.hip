@@ -24,6 +24,10 @@
 #include <stdlib.h>
 #include <functional>
 #include <vector>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 
 namespace dlsa {
 int gram_impl_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
@@ -590,8 +594,55 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
 
 // The partition loop shared by every data representation.  make_data(r0) gives the passes over the rows that start
 // at row r0; pass_bytes(rows) the scratch those passes need.
-static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data, const std::function<size_t(int64_t)>& pass_bytes,
-                         const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
+// Per-chain state of the partition loop: its buffers and what one partition hands to the next (warm start, inherited / pooled factor).
+struct IrlsChain {
+    IrlsBuffers b;
+    int inv_valid_flag = 0;
+    char* extra = nullptr;               // the data source's per-chain scratch (the gathered labels of a strided partition)
+    bool have_warm = false;
+    int64_t factor_rows = 0;             // rows behind the Hessian whose factor sits in b.L (0 = none usable)
+    int64_t factor_rows_sub = 0;
+    int pooled = 0;                      // partitions summed in b.Hpool
+    int64_t pooled_rows = 0;
+    int overall = DLSA_OK;
+    int rc = DLSA_OK;
+    std::string err;
+};
+
+// Independent partition CHAINS.  The partitions of one call are fitted one after the other because each starts from its
+// predecessor's MLE and factor -- but a fit of a SMALL partition is a string of launches that leave most of the GPU idle
+// (config 4's structured shard: 1e6 rows x 76 B per pass = 44 us, then a 31 us single-workgroup quasi-Newton step, ...).
+// So small partitions are dealt round-robin to up to four chains, each with its own stream, host thread, workspace slice and
+// warm-start state: chain c fits partitions c, c + S, c + 2S, ... in order, the chains overlap on the device.  Results do not
+// depend on the overlap (every chain is deterministic; the MLE is unique), only on S, which is a function of the shapes.
+constexpr int IRLS_MAX_CHAINS = 8;          // (the default cap is 4: irls_chain_cap)
+static int irls_chain_cap(int64_t max_rows, double bytes_per_row) {
+    const char* e = getenv("DLSA_IRLS_CHAINS");
+    if (e) return std::min(IRLS_MAX_CHAINS, std::max(1, atoi(e)));
+    // measured (bench/ab_chains.sh): 76 MB partitions 22.2 -> 14.4 ms with four chains (seven: 16.5), 0.8 GB 14.6 -> 12.3, 2.1 GB 67.8 -> 60.4;
+    // 4 GB partitions fill the GPU by themselves and only pay the extra cold starts (284 -> 297 ms)
+    return (double)max_rows * bytes_per_row <= 2.5e9 ? 4 : 1;
+}
+
+static std::mutex g_chain_mu;
+static std::map<std::pair<int, int>, hipStream_t> g_chain_streams;     // (device, chain) -> side stream, created once
+static int chain_stream(int dev, int c, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    auto key = std::make_pair(dev, c);
+    auto f = g_chain_streams.find(key);
+    if (f == g_chain_streams.end()) {
+        hipStream_t st;
+        DLSA_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        f = g_chain_streams.emplace(key, st).first;
+    }
+    *out = f->second;
+    return DLSA_OK;
+}
+
+using IrlsMakeData = std::function<IrlsData(int, int64_t, char*, hipStream_t)>;
+
+static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size_t(int64_t)>& pass_bytes, size_t extra_bytes,
+                         int chain_cap, const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
                          double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
                          void* ws, size_t ws_bytes, void* stream) {
     int64_t max_rows = 0;
@@ -600,29 +651,15 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
         max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
     }
     const IrlsLayout l = irls_layout(max_rows, p, pass_bytes(max_rows));
-    if (!ws || ws_bytes < l.total || ((uintptr_t)ws & 255)) {
-        set_error("irls_fit: workspace %zu bytes needed (256-aligned), got %zu", l.total, ws_bytes);
+    const size_t extra_al = align_up(extra_bytes, 256), chain_bytes = extra_al + align_up(l.total, 256);
+    if (!ws || ws_bytes < chain_bytes || ((uintptr_t)ws & 255)) {
+        set_error("irls_fit: workspace %zu bytes needed (256-aligned), got %zu", chain_bytes, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
-    char* base = (char*)ws;
-    IrlsBuffers b;
-    b.w = (double*)(base + l.w);
-    b.g = (double*)(base + l.g);
-    b.beta = (double*)(base + l.beta);
-    b.prev = (double*)(base + l.beta_prev);
-    b.delta = (double*)(base + l.delta);
-    b.stats = (double*)(base + l.stats);   // [0..2] solver stats, [3] loglik
-    b.L = (double*)(base + l.L);
-    b.Linv = (double*)(base + l.Linv);
-    b.Hinv = (double*)(base + l.Hinv);
-    b.Hpool = (double*)(base + l.Hpool);
-    int inv_valid_flag = 0;
-    b.inv_valid = &inv_valid_flag;
-    b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
-    b.qn_alpha = (double*)(base + l.qn_alpha); b.qn_q = (double*)(base + l.qn_q); b.qn_gprev = (double*)(base + l.qn_gprev);
-    b.ws_pass = base + l.pass;
-    b.ws_pass_bytes = l.pass_bytes;
+    // chains: at least two partitions each, as many as the workspace holds
+    int S = std::min<int64_t>(std::min(chain_cap, K / 2), (int64_t)(ws_bytes / chain_bytes));
+    S = std::max(S, 1);
+    hipStream_t s0 = (hipStream_t)stream;
     // tuning knobs for experiments (defaults are the production policy)
     const char* env_sub = getenv("DLSA_IRLS_SUBSAMPLE");
     const char* env_frz = getenv("DLSA_IRLS_FREEZE");
@@ -636,9 +673,6 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
     // (~n p bytes each): worth it once the Gram pass costs several logit passes, i.e. for p of a few hundred
     // (measured: 2.5e7 x 500 fit 0.41 -> 0.33 s; at p = 100 the extra iterations cost more than the Gram they save).
     const bool inherit_ok = env_inh ? atoi(env_inh) != 0 : (p >= 192);
-    bool have_warm = false;
-    int64_t factor_rows = 0;             // rows behind the Hessian whose factor sits in b.L (0 = none usable)
-    int64_t factor_rows_sub = 0;
     const char* env_fd = getenv("DLSA_IRLS_FACTOR_DIV");
     const int fac_div = env_fd ? atoi(env_fd) : 4;              // rows / fac_div feed the stand-in Hessian (0/1: the subsample's)
     // Pooled preconditioner: the exact Hessians of the finished partitions (their Sig_inv, evaluated at their MLEs) are
@@ -648,13 +682,36 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
     // first partition -- and the quasi-Newton iterations of every later partition get shorter for O(log K) factorizations.
     const char* env_pool = getenv("DLSA_IRLS_POOL");
     const bool pool_ok = (env_pool ? atoi(env_pool) != 0 : true) && inherit_ok && K > 1;
-    int pooled = 0;                      // partitions summed in b.Hpool
-    int64_t pooled_rows = 0;
-    int overall = DLSA_OK;
-    for (int k = 0; k < K; ++k) {
+
+    std::vector<IrlsChain> chains((size_t)S);
+    for (int c = 0; c < S; ++c) {
+        IrlsChain& cs = chains[(size_t)c];
+        char* cbase = (char*)ws + (size_t)c * chain_bytes;
+        cs.extra = cbase;
+        char* base = cbase + extra_al;
+        IrlsBuffers& b = cs.b;
+        b.w = (double*)(base + l.w);
+        b.g = (double*)(base + l.g);
+        b.beta = (double*)(base + l.beta);
+        b.prev = (double*)(base + l.beta_prev);
+        b.delta = (double*)(base + l.delta);
+        b.stats = (double*)(base + l.stats);   // [0..2] solver stats, [3] loglik
+        b.L = (double*)(base + l.L);
+        b.Linv = (double*)(base + l.Linv);
+        b.Hinv = (double*)(base + l.Hinv);
+        b.Hpool = (double*)(base + l.Hpool);
+        b.inv_valid = &cs.inv_valid_flag;
+        b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
+        b.qn_alpha = (double*)(base + l.qn_alpha); b.qn_q = (double*)(base + l.qn_q); b.qn_gprev = (double*)(base + l.qn_gprev);
+        b.ws_pass = base + l.pass;
+        b.ws_pass_bytes = l.pass_bytes;
+    }
+
+    // one partition on one chain (everything below is enqueued on the chain's stream s)
+    auto fit_partition = [&](int k, IrlsChain& cs, hipStream_t s) -> int {
         const int64_t r0 = part_offsets_host[k];
         const int64_t nk = part_offsets_host[k + 1] - r0;
-        const IrlsData d = make_data(k, r0);
+        const IrlsData d = make_data(k, r0, cs.extra, s);
         double* Hk = Sig_inv + (int64_t)k * p * p;
         double* ck = coef + (int64_t)k * p;
         double* sk = Sig_invMcoef + (int64_t)k * p;
@@ -673,27 +730,27 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
             // estimate the same theta, so the iterate starts O(sqrt(p/n_k)) from the answer and the
             // fit needs ~2 Gram passes instead of ~6.  The MLE is unique, so the result is the same;
             // a warm start that fails (status != OK) is repeated cold.
-            bool warm = have_warm;
-            if (warm && pool_ok && pooled > 0 && (pooled & (pooled - 1)) == 0) {
+            bool warm = cs.have_warm;
+            if (warm && pool_ok && cs.pooled > 0 && (cs.pooled & (cs.pooled - 1)) == 0) {
                 if (qn_enabled() && chol_small_ok(p)) {
-                    rc = launch_chol_small(b.Hpool, p, p, b.g, b.beta, b.Hinv, b.delta, b.stats, s);
-                    *b.inv_valid = 3;
+                    rc = launch_chol_small(cs.b.Hpool, p, p, cs.b.g, cs.b.beta, cs.b.Hinv, cs.b.delta, cs.b.stats, s);
+                    *cs.b.inv_valid = 3;
                 } else {
-                    rc = launch_chol_solve(b.Hpool, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
-                    *b.inv_valid = 0;
+                    rc = launch_chol_solve(cs.b.Hpool, p, 0, cs.b.g, 0, cs.b.beta, 0, p, 1, cs.b.L, cs.b.delta, 0, cs.b.stats, 0, s, 0);
+                    *cs.b.inv_valid = 0;
                 }
                 if (rc) return rc;
                 bool ok = false;
-                rc = factor_ok(b, s, &ok);
+                rc = factor_ok(cs.b, s, &ok);
                 if (rc) return rc;
-                factor_rows = ok ? pooled_rows : 0;          // a failed pooled factor: this partition takes its own Hessian
+                cs.factor_rows = ok ? cs.pooled_rows : 0;          // a failed cs.pooled factor: this partition takes its own Hessian
             }
             for (int attempt = 0; attempt < 2; ++attempt) {
                 st = DLSA_PART_OK; iters = 0; grams = 0;
-                double inherit = (warm && inherit_ok && factor_rows > 0) ? (double)nk / (double)factor_rows : 0.0;
+                double inherit = (warm && inherit_ok && cs.factor_rows > 0) ? (double)nk / (double)cs.factor_rows : 0.0;
                 if (!warm) {
-                    DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
-                    factor_rows = 0;
+                    DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
+                    cs.factor_rows = 0;
                     // cold start of a large partition: solve its leading 1/sub_div rows first
                     const int64_t nsub = sub_div > 1 ? nk / sub_div : 0;
                     if (nsub >= 200 * (int64_t)p && nsub >= 50000) {
@@ -703,17 +760,17 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
                         // iterations from zero, the expensive ones, run on the smallest sample that still pins the MLE
                         const int64_t nsub2 = nsub / sub_div;
                         if (nsub2 >= 100 * (int64_t)p && nsub2 >= 20000) {
-                            rc = newton_run(d, nsub2, p, 1e-3, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub, &gr_sub,
+                            rc = newton_run(d, nsub2, p, 1e-3, max_iter, freeze_at, Hk, cs.b, s, &st_sub, &it_sub, &gr_sub,
                                             &ll_sub, &fresh);
                             if (rc) return rc;
-                            if (st_sub != DLSA_PART_OK) DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
+                            if (st_sub != DLSA_PART_OK) DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
                             st_sub = 0; it_sub = 0; gr_sub = 0;
                         }
-                        rc = newton_run(d, nsub, p, 1e-6, max_iter, freeze_at, Hk, b, s, &st_sub, &it_sub,
+                        rc = newton_run(d, nsub, p, 1e-6, max_iter, freeze_at, Hk, cs.b, s, &st_sub, &it_sub,
                                         &gr_sub, &ll_sub, &fresh);
                         if (rc) return rc;
                         if (st_sub != DLSA_PART_OK) {   // degenerate subsample: plain cold start
-                            DLSA_HIP_CHECK(hipMemsetAsync(b.beta, 0, (size_t)p * sizeof(double), s));
+                            DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
                         } else if (inherit_ok) {
                             // Factor a Hessian AT the subsample MLE that will stand in for the full one.  The quasi-Newton
                             // contraction rate is the relative sampling error of that Hessian, ~2 sqrt(p / rows): on the
@@ -721,69 +778,116 @@ static int irls_fit_core(const std::function<IrlsData(int, int64_t)>& make_data,
                             // a quarter of the rows (a quarter of a full pass) brings it to 0.02 (six passes).
                             const int64_t nfac = fac_div > 1 ? std::max<int64_t>(nsub, nk / fac_div) : nsub;
                             if (nfac > nsub) {
-                                rc = d.logit(b.beta, nfac, b.w, nullptr, nullptr, b, s);
+                                rc = d.logit(cs.b.beta, nfac, cs.b.w, nullptr, nullptr, cs.b, s);
                                 if (rc) return rc;
                             }
-                            if (nfac > nsub || !fresh) {     // (b.w of the subsample run are the weights at exactly this beta)
-                                rc = d.gram(b.w, nfac, Hk, b, s);
+                            if (nfac > nsub || !fresh) {     // (cs.b.w of the subsample run are the weights at exactly this beta)
+                                rc = d.gram(cs.b.w, nfac, Hk, cs.b, s);
                                 if (rc) return rc;
                             }
-                            rc = launch_chol_solve(Hk, p, 0, b.g, 0, b.beta, 0, p, 1, b.L, b.delta, 0, b.stats, 0, s, 0);
+                            rc = launch_chol_solve(Hk, p, 0, cs.b.g, 0, cs.b.beta, 0, p, 1, cs.b.L, cs.b.delta, 0, cs.b.stats, 0, s, 0);
                             if (rc) return rc;
-                            *b.inv_valid = 0;
+                            *cs.b.inv_valid = 0;
                             bool ok = false;
-                            rc = factor_ok(b, s, &ok);
+                            rc = factor_ok(cs.b, s, &ok);
                             if (rc) return rc;
                             if (ok) {                        // a stand-in that does not factor is simply not inherited
                                 inherit = (double)nk / (double)nfac;
-                                factor_rows_sub = nfac;
+                                cs.factor_rows_sub = nfac;
                             }
                         }
                     }
                 }
-                rc = newton_run(d, nk, p, tol, max_iter, freeze_at, Hk, b, s, &st, &iters, &grams, &ll, &fresh,
+                rc = newton_run(d, nk, p, tol, max_iter, freeze_at, Hk, cs.b, s, &st, &iters, &grams, &ll, &fresh,
                                 inherit);
                 if (rc) return rc;
-                if (grams > 0) factor_rows = nk;         // b.L now factors a Hessian of this partition
-                else if (inherit > 0.0 && factor_rows == 0) factor_rows = factor_rows_sub;
+                if (grams > 0) cs.factor_rows = nk;         // cs.b.L now factors a Hessian of this partition
+                else if (inherit > 0.0 && cs.factor_rows == 0) cs.factor_rows = cs.factor_rows_sub;
                 if (st == DLSA_PART_OK || !warm) break;
                 warm = false;                            // warm start failed: repeat from zero
             }
-            if (st != DLSA_PART_OK) factor_rows = 0;
-            have_warm = (st == DLSA_PART_OK) && warm_ok;
+            if (st != DLSA_PART_OK) cs.factor_rows = 0;
+            cs.have_warm = (st == DLSA_PART_OK) && warm_ok;
             if (st == DLSA_PART_OK && !fresh) {
-                // Sig_inv must be the Hessian AT the returned coef: b.w holds the weights of the last logit pass, which ran
+                // Sig_inv must be the Hessian AT the returned coef: cs.b.w holds the weights of the last logit pass, which ran
                 // at exactly this beta -- or, after a predicted exit (newton_run), one step of <= 10 tol before it
-                rc = d.gram(b.w, nk, Hk, b, s);
+                rc = d.gram(cs.b.w, nk, Hk, cs.b, s);
                 if (rc) return rc;
             } else if (st == DLSA_PART_NOT_CONVERGED) {
                 // report the Hessian at the last iterate
-                rc = d.logit(b.beta, nk, b.w, nullptr, nullptr, b, s);
+                rc = d.logit(cs.b.beta, nk, cs.b.w, nullptr, nullptr, cs.b, s);
                 if (rc) return rc;
-                rc = d.gram(b.w, nk, Hk, b, s);
+                rc = d.gram(cs.b.w, nk, Hk, cs.b, s);
                 if (rc) return rc;
             }
-            DLSA_HIP_CHECK(hipMemcpyAsync(ck, b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
-            rc = launch_matvec(Hk, p, b.beta, p, sk, s);
+            DLSA_HIP_CHECK(hipMemcpyAsync(ck, cs.b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
+            rc = launch_matvec(Hk, p, cs.b.beta, p, sk, s);
             if (rc) return rc;
             if (pool_ok && st == DLSA_PART_OK) {
-                if (pooled == 0) DLSA_HIP_CHECK(hipMemcpyAsync(b.Hpool, Hk, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, s));
+                if (cs.pooled == 0) DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Hpool, Hk, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, s));
                 else {
-                    rc = launch_axpby(b.Hpool, Hk, 1.0, p * p, b.Hpool, s);
+                    rc = launch_axpby(cs.b.Hpool, Hk, 1.0, p * p, cs.b.Hpool, s);
                     if (rc) return rc;
                 }
-                ++pooled;
-                pooled_rows += nk;
+                ++cs.pooled;
+                cs.pooled_rows += nk;
             }
         }
         if (n_iter_host) n_iter_host[k] = iters;
         if (status_host) status_host[k] = st;
         if (loglik_host) loglik_host[k] = ll;
-        if (st == DLSA_PART_NOT_CONVERGED && overall == DLSA_OK) overall = DLSA_ERR_NOT_CONVERGED;
-        if (st == DLSA_PART_NOT_SPD && overall == DLSA_OK) overall = DLSA_ERR_NOT_SPD;
-        if (st == DLSA_PART_NAN && overall == DLSA_OK) overall = DLSA_ERR_NAN;
+        if (st == DLSA_PART_NOT_CONVERGED && cs.overall == DLSA_OK) cs.overall = DLSA_ERR_NOT_CONVERGED;
+        if (st == DLSA_PART_NOT_SPD && cs.overall == DLSA_OK) cs.overall = DLSA_ERR_NOT_SPD;
+        if (st == DLSA_PART_NAN && cs.overall == DLSA_OK) cs.overall = DLSA_ERR_NAN;
+        return DLSA_OK;
+    };
+    auto run_chain = [&](int c, hipStream_t s) -> int {
+        IrlsChain& cs = chains[(size_t)c];
+        for (int k = c; k < K; k += S) {
+            const int rc = fit_partition(k, cs, s);
+            if (rc) return rc;
+        }
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        return DLSA_OK;
+    };
+
+    int rc0 = DLSA_OK;
+    if (S == 1) {
+        rc0 = run_chain(0, s0);
+    } else {
+        int dev = 0;
+        DLSA_HIP_CHECK(hipGetDevice(&dev));
+        hipEvent_t fork;
+        DLSA_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        DLSA_HIP_CHECK(hipEventRecord(fork, s0));                       // the side chains start behind whatever the caller enqueued
+        std::vector<hipStream_t> st((size_t)S, s0);
+        for (int c = 1; c < S; ++c) {
+            int rc = chain_stream(dev, c, &st[(size_t)c]);
+            if (rc) { (void)hipEventDestroy(fork); return rc; }
+            DLSA_HIP_CHECK(hipStreamWaitEvent(st[(size_t)c], fork, 0));
+        }
+        std::vector<std::thread> workers;
+        for (int c = 1; c < S; ++c)
+            workers.emplace_back([&, c]() {
+                IrlsChain& cs = chains[(size_t)c];
+                if (hipSetDevice(dev) != hipSuccess) { cs.rc = DLSA_ERR_HIP; cs.err = "hipSetDevice failed in a chain thread"; return; }
+                cs.rc = run_chain(c, st[(size_t)c]);
+                if (cs.rc) { char buf[512]; dlsa_last_error(buf, (int)sizeof(buf)); cs.err = buf; }
+            });
+        rc0 = run_chain(0, s0);
+        for (auto& t : workers) t.join();
+        // (every chain has synchronised its stream: whatever the caller enqueues next on `stream` sees all results)
+        (void)hipEventDestroy(fork);
+        for (int c = 1; c < S && rc0 == DLSA_OK; ++c)
+            if (chains[(size_t)c].rc) { set_error("%s", chains[(size_t)c].err.c_str()); rc0 = chains[(size_t)c].rc; }
     }
-    DLSA_HIP_CHECK(hipStreamSynchronize(s));
+    if (rc0) return rc0;
+    int overall = DLSA_OK;
+    for (const IrlsChain& cs : chains) {
+        if (cs.overall == DLSA_ERR_NOT_CONVERGED && overall == DLSA_OK) overall = DLSA_ERR_NOT_CONVERGED;
+        if (cs.overall == DLSA_ERR_NOT_SPD && overall == DLSA_OK) overall = DLSA_ERR_NOT_SPD;
+        if (cs.overall == DLSA_ERR_NAN && overall == DLSA_OK) overall = DLSA_ERR_NAN;
+    }
     if (overall == DLSA_ERR_NOT_CONVERGED) set_error("irls_fit: at least one partition hit max_iter");
     if (overall == DLSA_ERR_NOT_SPD) set_error("irls_fit: a partition's Hessian is not positive definite");
     if (overall == DLSA_ERR_NAN) set_error("irls_fit: NaN/Inf in a partition's fit");
@@ -827,7 +931,9 @@ extern "C" {
 
 size_t dlsa_irls_workspace_bytes(int64_t max_rows_per_partition, int p) {
     if (p <= 0 || p > 2048 || max_rows_per_partition < 0) return 0;
-    return dlsa::irls_layout(max_rows_per_partition, p, dlsa::dense_pass_bytes(max_rows_per_partition, p)).total;
+    // one slice per partition chain (irls_fit_core): small partitions are fitted on up to four streams at once
+    return dlsa::align_up(dlsa::irls_layout(max_rows_per_partition, p, dlsa::dense_pass_bytes(max_rows_per_partition, p)).total, 256) *
+           (size_t)dlsa::irls_chain_cap(max_rows_per_partition, 8.0 * p);
 }
 
 int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_offsets_host,
@@ -846,7 +952,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
             return irls_small_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
                                   n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
     }
-    auto make_data = [=](int, int64_t r0) {
+    auto make_data = [=](int, int64_t r0, char*, hipStream_t) {
         const double* Xk = X + r0 * ldx;
         const double* yk = y + r0;
         IrlsData d;
@@ -862,16 +968,20 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, ldx, yk, nrows, p); };
         return d;
     };
-    return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, part_offsets_host, K, p, tol,
-                         max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
+    int64_t max_rows = 0;
+    for (int k = 0; k < K; ++k) max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
+    return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, 0, irls_chain_cap(max_rows, 8.0 * p),
+                         part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host,
+                         ws, ws_bytes, stream);
 }
 
 size_t dlsa_irls_ex_workspace_bytes(int64_t max_rows_per_partition, int p, int intercept, int64_t row_step) {
     if (p <= 0 || p + (intercept ? 1 : 0) > 2048 || max_rows_per_partition < 0 || row_step < 1) return 0;
     const int pe = p + (intercept ? 1 : 0);
     const size_t ybuf = row_step > 1 ? dlsa::align_up((size_t)std::max<int64_t>(max_rows_per_partition, 1) * sizeof(double), 256) : 0;
-    return ybuf + dlsa::irls_layout(max_rows_per_partition, pe, std::max(dlsa::dense_pass_bytes(max_rows_per_partition, p),
-                                                                         dlsa::dense_pass_bytes(max_rows_per_partition, pe))).total + (1 << 20);
+    const size_t chain = ybuf + dlsa::align_up(dlsa::irls_layout(max_rows_per_partition, pe, std::max(dlsa::dense_pass_bytes(max_rows_per_partition, p),
+                                                                         dlsa::dense_pass_bytes(max_rows_per_partition, pe))).total, 256);
+    return chain * (size_t)dlsa::irls_chain_cap(max_rows_per_partition, 8.0 * p) + (1 << 20);
 }
 
 int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const int64_t* part_first_host,
@@ -900,14 +1010,13 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         return irls_small_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv,
                               Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
     const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
-    double* ybuf = (double*)ws;
     const int64_t pitch = ldx * row_step;                     // rows first, first + step, ...: a strided view, no copy of X
-    hipStream_t st = (hipStream_t)stream;
-    auto make_data = [=](int k, int64_t) {
+    auto make_data = [=](int k, int64_t, char* extra, hipStream_t st) {
         const double* Xk = X + part_first_host[k] * ldx;
         const double* yk = y + part_first_host[k];
         const int64_t nk = part_rows_host[k];
-        if (row_step > 1 && nk > 0) {                         // the labels of the partition, gathered once (8 bytes per row)
+        if (row_step > 1 && nk > 0) {                         // the labels of the partition, gathered once (8 bytes per row) into the chain's slice
+            double* ybuf = (double*)extra;
             hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, y, part_first_host[k],
                                row_step, nk, ybuf);
             yk = ybuf;
@@ -929,8 +1038,8 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },
-                         offs.data(), K, pe, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host,
-                         (char*)ws + ybytes, ws_bytes - ybytes, stream);
+                         ybytes, irls_chain_cap(max_rows, 8.0 * p), offs.data(), K, pe, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
+                         n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
 // The same Hessian as a stand-alone entry: H = [1 | X]' diag(w) [1 | X], (p + 1) x (p + 1), intercept first (models.py:121-130).
@@ -952,8 +1061,9 @@ int dlsa_gram_icpt_f64(const double* X, int64_t ldx, const double* w, int64_t n,
 // One-hot designs: the same fit on raw numerics + level codes (onehot.hip), never materialising the dense matrix.
 size_t dlsa_onehot_irls_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition) {
     if (!plan || max_rows_per_partition < 0) return 0;
-    return dlsa::irls_layout(max_rows_per_partition, dlsa::onehot_plan_p(plan),
-                             dlsa::onehot_workspace_bytes_impl(plan, max_rows_per_partition)).total;
+    return dlsa::align_up(dlsa::irls_layout(max_rows_per_partition, dlsa::onehot_plan_p(plan),
+                                            dlsa::onehot_workspace_bytes_impl(plan, max_rows_per_partition)).total, 256) *
+           (size_t)dlsa::irls_chain_cap(max_rows_per_partition, 128.0);       // (raw rows: a few numerics + level codes)
 }
 
 int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
@@ -964,7 +1074,7 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
     DLSA_REQUIRE(plan && y && part_offsets_host && coef && Sig_inv && Sig_invMcoef, "onehot irls_fit: null argument");
     DLSA_REQUIRE(K > 0 && max_iter > 0 && tol > 0, "onehot irls_fit: bad K/tol/max_iter");
     const int p = onehot_plan_p(plan);
-    auto make_data = [=](int, int64_t r0) {
+    auto make_data = [=](int, int64_t r0, char*, hipStream_t) {
         const double* numk = num ? num + r0 * ldn : nullptr;
         const int32_t* codesk = codes ? codes + r0 * ldc : nullptr;
         const double* yk = y + r0;
@@ -977,8 +1087,11 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
         };
         return d;
     };
-    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, part_offsets_host, K,
-                         p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
+    int64_t max_rows = 0;
+    for (int k = 0; k < K; ++k) max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
+    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, 0,
+                         irls_chain_cap(max_rows, 128.0), part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
+                         n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
 // The same for partitions given as (first row, rows, common row step): partition_id = i % K (models.py:33) is first = 0..K-1,
@@ -987,7 +1100,7 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
 size_t dlsa_onehot_irls_ex_workspace_bytes(const dlsa_onehot_plan* plan, int64_t max_rows_per_partition, int64_t row_step) {
     if (!plan || max_rows_per_partition < 0 || row_step < 1) return 0;
     const size_t ybuf = row_step > 1 ? dlsa::align_up((size_t)std::max<int64_t>(max_rows_per_partition, 1) * sizeof(double), 256) : 0;
-    return ybuf + dlsa_onehot_irls_workspace_bytes(plan, max_rows_per_partition);
+    return ybuf * (size_t)dlsa::irls_chain_cap(max_rows_per_partition, 128.0) + dlsa_onehot_irls_workspace_bytes(plan, max_rows_per_partition);
 }
 
 int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
@@ -1011,15 +1124,14 @@ int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num,
         return DLSA_ERR_WORKSPACE;
     }
     const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
-    double* ybuf = (double*)ws;
-    hipStream_t st = (hipStream_t)stream;
     const int64_t pn = ldn * row_step, pc = ldc * row_step;
-    auto make_data = [=](int k, int64_t) {
+    auto make_data = [=](int k, int64_t, char* extra, hipStream_t st) {
         const double* numk = num ? num + part_first_host[k] * ldn : nullptr;
         const int32_t* codesk = codes ? codes + part_first_host[k] * ldc : nullptr;
         const double* yk = y + part_first_host[k];
         const int64_t nk = part_rows_host[k];
         if (row_step > 1 && nk > 0) {
+            double* ybuf = (double*)extra;
             hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, y, part_first_host[k],
                                row_step, nk, ybuf);
             yk = ybuf;
@@ -1033,9 +1145,9 @@ int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num,
         };
         return d;
     };
-    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, offs.data(), K, p, tol,
-                         max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host, (char*)ws + ybytes,
-                         ws_bytes - ybytes, stream);
+    return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, ybytes,
+                         irls_chain_cap(max_rows, 128.0), offs.data(), K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+                         status_host, loglik_host, ws, ws_bytes, stream);
 }
 
 }  // extern "C"
