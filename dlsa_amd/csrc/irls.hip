@@ -619,9 +619,17 @@ constexpr int IRLS_MAX_CHAINS = 8;          // (the default cap is 4: irls_chain
 static int irls_chain_cap(int64_t max_rows, double bytes_per_row) {
     const char* e = getenv("DLSA_IRLS_CHAINS");
     if (e) return std::min(IRLS_MAX_CHAINS, std::max(1, atoi(e)));
-    // measured (bench/ab_chains.sh): 76 MB partitions 22.2 -> 14.4 ms with four chains (seven: 16.5), 0.8 GB 14.6 -> 12.3, 2.1 GB 67.8 -> 60.4;
-    // 4 GB partitions fill the GPU by themselves and only pay the extra cold starts (284 -> 297 ms)
-    return (double)max_rows * bytes_per_row <= 2.5e9 ? 4 : 1;
+    // measured (bench/ab_chains.sh, same box, one chain -> four): 76 MB partitions (config 4 structured) 22.1 -> 14.5 ms, 0.8 GB (config 2,
+    // K = 10) 14.6 -> 12.2, 2.1 GB (config 4 dense) 67.3 -> 59.9, 4 GB (config 3, K = 25) 287.5 -> 256.4 seeded (unseeded: 300, the
+    // extra cold starts cost more than the overlap gives); partitions beyond 8 GB fill the GPU for milliseconds per launch
+    return (double)max_rows * bytes_per_row <= 8e9 ? 4 : 1;
+}
+// Seeding (partition 0 alone, its state copied to every chain) saves S - 1 cold starts but serialises one partition: it pays when
+// a cold start is expensive -- not for the 128 MB raw partitions of a structured design (config 4: 14.5 unseeded, 15.9 seeded).
+static bool irls_chain_seed(int64_t max_rows, double bytes_per_row) {
+    const char* e = getenv("DLSA_IRLS_SEED");
+    if (e) return atoi(e) != 0;
+    return (double)max_rows * bytes_per_row >= 2.56e8;
 }
 
 static std::mutex g_chain_mu;
@@ -642,7 +650,7 @@ static int chain_stream(int dev, int c, hipStream_t* out) {
 using IrlsMakeData = std::function<IrlsData(int, int64_t, char*, hipStream_t)>;
 
 static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size_t(int64_t)>& pass_bytes, size_t extra_bytes,
-                         int chain_cap, const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
+                         int chain_cap, bool chain_seed, const int64_t* part_offsets_host, int K, int p, double tol, int max_iter, double* coef,
                          double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host, double* loglik_host,
                          void* ws, size_t ws_bytes, void* stream) {
     int64_t max_rows = 0;
@@ -657,7 +665,7 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
         return DLSA_ERR_WORKSPACE;
     }
     // chains: at least two partitions each, as many as the workspace holds
-    int S = std::min<int64_t>(std::min(chain_cap, K / 2), (int64_t)(ws_bytes / chain_bytes));
+    int S = std::min<int64_t>(std::min(chain_cap, (K - 1) / 2), (int64_t)(ws_bytes / chain_bytes));
     S = std::max(S, 1);
     hipStream_t s0 = (hipStream_t)stream;
     // tuning knobs for experiments (defaults are the production policy)
@@ -841,9 +849,13 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
         if (st == DLSA_PART_NAN && cs.overall == DLSA_OK) cs.overall = DLSA_ERR_NAN;
         return DLSA_OK;
     };
+    // Seeded chains (irls_chain_seed): partition 0 is fitted alone, its MLE, factor, inverse and pooled Hessian are
+    // copied into every chain's slice, and the chains share out partitions 1 .. K - 1 -- ONE cold start per call instead of S.
+    const bool seeded = S > 1 && chain_seed;
+    const int k_first = seeded ? 1 : 0;
     auto run_chain = [&](int c, hipStream_t s) -> int {
         IrlsChain& cs = chains[(size_t)c];
-        for (int k = c; k < K; k += S) {
+        for (int k = k_first + c; k < K; k += S) {
             const int rc = fit_partition(k, cs, s);
             if (rc) return rc;
         }
@@ -857,9 +869,29 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
     } else {
         int dev = 0;
         DLSA_HIP_CHECK(hipGetDevice(&dev));
+        if (seeded) {
+            IrlsChain& c0 = chains[0];
+            const int rc = fit_partition(0, c0, s0);
+            if (rc) return rc;
+            const size_t pb = (size_t)p * sizeof(double), ppb = (size_t)p * p * sizeof(double);
+            for (int c = 1; c < S; ++c) {
+                IrlsChain& cs = chains[(size_t)c];
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.beta, c0.b.beta, pb, hipMemcpyDeviceToDevice, s0));
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.L, c0.b.L, ppb, hipMemcpyDeviceToDevice, s0));
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Linv, c0.b.Linv, ppb, hipMemcpyDeviceToDevice, s0));
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Hinv, c0.b.Hinv, ppb, hipMemcpyDeviceToDevice, s0));
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Hpool, c0.b.Hpool, ppb, hipMemcpyDeviceToDevice, s0));
+                cs.inv_valid_flag = c0.inv_valid_flag;
+                cs.have_warm = c0.have_warm;
+                cs.factor_rows = c0.factor_rows;
+                cs.factor_rows_sub = c0.factor_rows_sub;
+                cs.pooled = c0.pooled;
+                cs.pooled_rows = c0.pooled_rows;
+            }
+        }
         hipEvent_t fork;
         DLSA_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        DLSA_HIP_CHECK(hipEventRecord(fork, s0));                       // the side chains start behind whatever the caller enqueued
+        DLSA_HIP_CHECK(hipEventRecord(fork, s0));                       // the side chains start behind the seed (and whatever the caller enqueued)
         std::vector<hipStream_t> st((size_t)S, s0);
         for (int c = 1; c < S; ++c) {
             int rc = chain_stream(dev, c, &st[(size_t)c]);
@@ -971,7 +1003,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     int64_t max_rows = 0;
     for (int k = 0; k < K; ++k) max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
     return irls_fit_core(make_data, [=](int64_t rows) { return dense_pass_bytes(rows, p); }, 0, irls_chain_cap(max_rows, 8.0 * p),
-                         part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host,
+                         irls_chain_seed(max_rows, 8.0 * p), part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host, status_host, loglik_host,
                          ws, ws_bytes, stream);
 }
 
@@ -1038,7 +1070,7 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },
-                         ybytes, irls_chain_cap(max_rows, 8.0 * p), offs.data(), K, pe, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
+                         ybytes, irls_chain_cap(max_rows, 8.0 * p), irls_chain_seed(max_rows, 8.0 * p), offs.data(), K, pe, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
                          n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
@@ -1090,7 +1122,7 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
     int64_t max_rows = 0;
     for (int k = 0; k < K; ++k) max_rows = std::max(max_rows, part_offsets_host[k + 1] - part_offsets_host[k]);
     return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, 0,
-                         irls_chain_cap(max_rows, 128.0), part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
+                         irls_chain_cap(max_rows, 128.0), irls_chain_seed(max_rows, 128.0), part_offsets_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
                          n_iter_host, status_host, loglik_host, ws, ws_bytes, stream);
 }
 
@@ -1146,7 +1178,7 @@ int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num,
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return onehot_workspace_bytes_impl(plan, rows); }, ybytes,
-                         irls_chain_cap(max_rows, 128.0), offs.data(), K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+                         irls_chain_cap(max_rows, 128.0), irls_chain_seed(max_rows, 128.0), offs.data(), K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
                          status_host, loglik_host, ws, ws_bytes, stream);
 }
 

@@ -30,8 +30,9 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("layout", ["ranges", "strided+icpt"])
-def test_chained_fit_equals_single_chain_and_oracle(eng, orc, monkeypatch, layout):
+@pytest.mark.parametrize("layout,seed", [("ranges", "0"), ("strided+icpt", "0"), ("ranges", "1"), ("strided+icpt", "1")])
+def test_chained_fit_equals_single_chain_and_oracle(eng, orc, monkeypatch, layout, seed):
+    """seed = 1: partition 0 is fitted alone and its MLE / factor / pooled Hessian seed every chain (one cold start per call)."""
     n, p, K = 9 * 70000 + 5, 40, 9                        # partitions above the pooled small-partition kernel (<= 65536 rows)
     X, y = orc.synth_logistic(31, 0, n, p, orc.SYNTH_UNIFORM)
     Xd, yd = dev(X), dev(y)
@@ -44,15 +45,19 @@ def test_chained_fit_equals_single_chain_and_oracle(eng, orc, monkeypatch, layou
         parts = [(np.hstack([np.ones((rows[k], 1)), X[k::K]]), y[k::K]) for k in range(K)]
         return eng.irls_fit_ex(Xd, yd, list(range(K)), rows, row_step=K, fit_intercept=True), parts
 
+    monkeypatch.setenv("DLSA_IRLS_SEED", seed)
     monkeypatch.setenv("DLSA_IRLS_CHAINS", "1")
     r1, parts = fit()
     monkeypatch.setenv("DLSA_IRLS_CHAINS", "4")
     r4, _ = fit()
     r4b, _ = fit()
     monkeypatch.delenv("DLSA_IRLS_CHAINS")
-    rd, _ = fit()                                          # the default policy: small partitions -> four chains
+    rd, _ = fit()                                          # the default count: four chains for partitions of this size
     assert r1["status"] == [0] * K and r4["status"] == [0] * K and rd["status"] == [0] * K
-    assert r4["n_iter"] != r1["n_iter"] or K < 8           # four cold starts instead of one: the chains really were separate
+    if seed == "0":
+        assert r4["n_iter"] != r1["n_iter"]                # four cold starts instead of one: the chains really were separate
+    else:
+        assert r4["n_iter"][0] == r1["n_iter"][0]          # the seed partition is the one-chain run's first partition
     for key in ("coef", "Sig_inv", "Sig_invMcoef"):
         assert torch.equal(r4[key], r4b[key]) and torch.equal(r4[key], rd[key]), key        # bit-reproducible
         assert rel_inf(r4[key].cpu().numpy(), r1[key].cpu().numpy()) < 1e-10, key
