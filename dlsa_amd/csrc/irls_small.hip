@@ -282,7 +282,14 @@ bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
     if (nmax > 65536) return false;
     const double rounds = (double)((K + kNumCU - 1) / kNumCU);
-    const double t_small = (1.0 + 1.9e-4 * (double)nmax * std::max(0.5, pe / 50.0)) * rounds, t_host = 0.55 * K;
+    // the host-driven path fits such partitions on up to four concurrent chains (irls.hip, irls_fit_core): 0.55 ms per partition on one
+    // chain, 0.23 on four (K = 20, p = 50, 10000 .. 60000 rows: 4.5 ms whatever the row count; this kernel 2.6 / 4.5 / 6.4 / 9.5 ms
+    // at 10000 / 20000 / 30000 / 45000 rows -- bench/ab_small_vs_chains.sh)
+    const char* e = getenv("DLSA_IRLS_CHAINS");
+    const int cap = e ? std::min(8, std::max(1, atoi(e))) : 4;
+    const int S = std::max(1, std::min(cap, (K - 1) / 2));
+    static const double per_partition_ms[5] = {0.55, 0.55, 0.37, 0.29, 0.23};
+    const double t_small = (1.0 + 1.9e-4 * (double)nmax * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
     return t_small < t_host;
 }
 
