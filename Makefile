@@ -13,7 +13,7 @@ SRCS  := $(CSRC)/error.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.h
 # each compiled from gram_plan_unit.hip with the plans tools/gen_gram_plan_asm.py writes into $(BUILD)/gen at build time
 PLAN_UNITS := 1_8_17 2_18_24 4_25_28 4_29_32 4_33_35
 GEN   := $(BUILD)/gen
-OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS)) $(patsubst %,$(BUILD)/gram_plan_unit_%.o,$(PLAN_UNITS))
+OBJS  := $(patsubst $(CSRC)/%,$(BUILD)/%.o,$(SRCS)) $(patsubst %,$(BUILD)/gram_plan_unit_%.o,$(PLAN_UNITS)) $(BUILD)/lars_t512.o
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-function $(EXTRA)
 # -Wno-inline-asm ONLY for the translation units whose generated MFMA blocks name AGPRs beyond a127 in kernels bounded to
 # two waves per SIMD: hipcc calls them "reserved" but allocates them.  What the warning would have guarded is checked after
@@ -27,6 +27,11 @@ all: $(OUT)
 $(BUILD)/%.o: $(CSRC)/% $(CSRC)/common.h $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.h) include/dlsa_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
+
+# the LARS path kernels a second time with 512-thread workgroups (lars.hip: the C ABI entry picks the build by p)
+$(BUILD)/lars_t512.o: $(CSRC)/lars.hip $(CSRC)/common.h include/dlsa_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(FLAGS) -DDLSA_LARS_THREADS=512 -DDLSA_LARS_SECONDARY -x hip -c $< -o $@
 
 $(GEN)/gram_plan_common.inc: tools/gen_gram_plan_asm.py
 	@mkdir -p $(GEN)

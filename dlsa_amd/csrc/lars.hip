@@ -27,17 +27,7 @@
 
 namespace dlsa {
 
-#ifndef DLSA_LARS_THREADS
-#define DLSA_LARS_THREADS 1024
-#endif
-constexpr int LARS_THREADS = DLSA_LARS_THREADS;
-constexpr int LARS_WAVES = LARS_THREADS / 64;
-constexpr int LARS_ROWGROUPS = LARS_THREADS / 16;
-#ifndef DLSA_LARS_TRIP
-#define DLSA_LARS_TRIP 2
-#endif
-constexpr int LARS_TRIP = DLSA_LARS_TRIP;      // loads per row, lane and trip in the triangular mat-vecs (four rows at a time)
-constexpr int LARS_SLACK = 256;                // zeroed elements after each factor matrix: the last rows' trips run into them
+[[maybe_unused]] constexpr int LARS_SLACK = 256;                // zeroed elements after each factor matrix: the last rows' trips run into them
 constexpr int LARS_MAX_WGS = 32;               // workgroups of the grid kernel (the barrier costs ~35 ns per workgroup beyond 16)
 
 struct LarsArgs {
@@ -61,6 +51,28 @@ struct LarsArgs {
     double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
     unsigned* bar;    // grid barrier counter (zero at launch)
 };
+
+// The kernels are compiled TWICE (Makefile: lars.hip and lars_t512 from the same source): workgroups of 1024 threads for wide
+// paths, of 512 for p <= 768 -- every phase of a step ends in a workgroup barrier or a block reduction, and those cost by the
+// number of waves (same box, 1024 -> 512 threads: p = 50 0.58 -> 0.44 ms, p = 100 1.10 -> 0.89, p = 260 3.91 -> 3.62, p = 500
+// 8.40 -> 7.90; p = 1000 equal; p = 2000 73.7 -> 99.7: there the mat-vecs want the waves).
+#ifndef DLSA_LARS_THREADS
+#define DLSA_LARS_THREADS 1024
+#endif
+#if DLSA_LARS_THREADS == 512
+#define LARS_NS lars_t512
+#else
+#define LARS_NS lars_t1024
+#endif
+namespace LARS_NS {
+constexpr int LARS_THREADS = DLSA_LARS_THREADS;
+constexpr int LARS_WAVES = LARS_THREADS / 64;
+constexpr int LARS_ROWGROUPS = LARS_THREADS / 16;
+#ifndef DLSA_LARS_TRIP
+#define DLSA_LARS_TRIP 2
+#endif
+constexpr int LARS_TRIP = DLSA_LARS_TRIP;      // loads per row, lane and trip in the triangular mat-vecs (four rows at a time)
+
 
 // Optional phase timer (-DDLSA_LARS_PROF): thread 0 accumulates wall-clock ticks (100 MHz) per phase and prints them.
 #ifdef DLSA_LARS_PROF
@@ -886,13 +898,46 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
 // at 8; p=1000 22 ms at 16; p=2000 74 ms at 32; the grid kernel with ONE workgroup is slower than lars_kernel:
 // 4.0 vs 2.6 ms at p=200).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
 static int lars_workgroups(int p) {
-    int wgs = p < 256 ? 1 : (p < 384 ? 4 : (p < 768 ? 8 : (p < 1536 ? 16 : 32)));
+    int wgs = p < 256 ? 1 : (p < 384 ? (LARS_THREADS == 512 ? 8 : 4) : (p < 768 ? 8 : (p < 1536 ? 16 : 32)));   // (512-thread build, p = 260: 3.78 ms at 4, 3.59 at 8)
     if (const char* e = getenv("DLSA_LARS_WGS")) wgs = atoi(e);
     return std::max(1, std::min(wgs, LARS_MAX_WGS));
 }
 
+
+// launch of this build's kernels (the C ABI entry below picks the build by p)
+int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
+    const size_t mm = (size_t)(p - (intercept ? 1 : 0));
+    int wgs = lars_workgroups(p);
+    // the grid kernel replicates more vectors in LDS; beyond its limit (m ~ 2440) the single-workgroup kernel still fits
+    if (wgs > 1 && (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64 > (size_t)kLdsBytes) wgs = 1;
+    if (wgs > 1) {
+        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64;
+        if (shm > 48 * 1024)
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
+        void* args[] = {&a};
+        // cooperative launch: all workgroups are resident together (the grid barrier spins), or the launch fails
+        DLSA_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lars_grid_kernel), dim3(wgs), dim3(LARS_THREADS),
+                                                  args, (unsigned)shm, s));
+    } else {
+        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 44 + 64;
+        DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
+        if (shm > 48 * 1024)
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
+    return DLSA_OK;
+}
+
+}  // namespace LARS_NS
+namespace lars_t512 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s); }
+namespace lars_t1024 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s); }
+
 }  // namespace dlsa
 
+#ifndef DLSA_LARS_SECONDARY
 extern "C" {
 
 size_t dlsa_lars_workspace_bytes(int p) {
@@ -934,28 +979,11 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
     DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
     DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
-    const size_t mm = (size_t)(p - (intercept ? 1 : 0));
-    int wgs = lars_workgroups(p);
-    // the grid kernel replicates more vectors in LDS; beyond its limit (m ~ 2440) the single-workgroup kernel still fits
-    if (wgs > 1 && (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64 > (size_t)kLdsBytes) wgs = 1;
-    if (wgs > 1) {
-        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64;
-        if (shm > 48 * 1024)
-            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
-        void* args[] = {&a};
-        // cooperative launch: all workgroups are resident together (the grid barrier spins), or the launch fails
-        DLSA_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lars_grid_kernel), dim3(wgs), dim3(LARS_THREADS),
-                                                  args, (unsigned)shm, s));
-    } else {
-        const size_t shm = (size_t)LARS_THREADS * 16 + mm * 44 + 64;
-        DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
-        if (shm > 48 * 1024)
-            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
-        DLSA_HIP_CHECK(hipGetLastError());
-    }
+    // 512-thread workgroups up to p = 768, 1024-thread ones beyond (DLSA_LARS_THREADS=512|1024 forces a build)
+    bool small_wg = p <= 768;
+    if (const char* e = getenv("DLSA_LARS_THREADS")) small_wg = atoi(e) == 512;
+    const int rc = small_wg ? lars_t512::lars_run(a, p, intercept, s) : lars_t1024::lars_run(a, p, intercept, s);
+    if (rc) return rc;
     int steps = 0;
     DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
     DLSA_HIP_CHECK(hipStreamSynchronize(s));
@@ -964,3 +992,4 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
 }
 
 }  // extern "C"
+#endif  // DLSA_LARS_SECONDARY
