@@ -468,7 +468,13 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 *b.inv_valid |= 2;
             }
             const size_t shm = ((size_t)2 * p + 48) * sizeof(double);
-#define DLSA_QN_STEP(EPT) hipLaunchKernelGGL(qn_step_kernel<EPT>, dim3(1), dim3(1024), shm, s, (const double*)b.beta, \
+            // One element per thread up to 1024 columns.  Fewer waves make the kernel's ~20 block reductions cheaper, more waves its
+            // mat-vec: 512 threads for p <= 512 (bench/qn_threads_ab.sh, average duration inside chained fits: p = 100 58 -> 45 us,
+            // p = 260 82 -> 73, p = 500 335 -> 189; 256 threads: 51 / 94 / 357).  DLSA_QN_THREADS overrides.
+            static const int qn_threads_env = getenv("DLSA_QN_THREADS") ? atoi(getenv("DLSA_QN_THREADS")) : 0;
+            const int qn_default = p <= 512 ? 512 : 1024;
+            const int qn_threads = qn_threads_env >= 64 && qn_threads_env <= 1024 && (p <= qn_threads_env || p > 1024) ? qn_threads_env : qn_default;
+#define DLSA_QN_STEP(EPT) hipLaunchKernelGGL(qn_step_kernel<EPT>, dim3(1), dim3(qn_threads), shm, s, (const double*)b.beta, \
                                              (const double*)b.prev, b.qn_gprev, (const double*)b.g, b.qn_s, b.qn_y, b.qn_rho, ord, \
                                              push_slot, p, gscale, (const double*)b.Hinv, b.delta, b.stats)
             if (p <= 1024) DLSA_QN_STEP(1);

@@ -916,10 +916,13 @@ int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
             DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
-        void* args[] = {&a};
-        // cooperative launch: all workgroups are resident together (the grid barrier spins), or the launch fails
-        DLSA_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lars_grid_kernel), dim3(wgs), dim3(LARS_THREADS),
-                                                  args, (unsigned)shm, s));
+        // A PLAIN launch: at most 32 workgroups on 256 CUs are resident together as soon as the CUs they need are free (whatever
+        // else runs terminates without waiting for this kernel), which is all the spinning grid barrier needs.
+        // hipLaunchCooperativeKernel would guarantee it, but (measured) every HIP stream CREATED after a process's first cooperative
+        // launch is serialised with the others -- the partition chains of a later fit (irls.hip) then lose their overlap
+        // (config 4 structured: 14.4 -> 22.2 ms) -- and the cooperative launch costs 15-19 us of host time per call.
+        hipLaunchKernelGGL(lars_grid_kernel, dim3(wgs), dim3(LARS_THREADS), shm, s, a);
+        DLSA_HIP_CHECK(hipGetLastError());
     } else {
         const size_t shm = (size_t)LARS_THREADS * 16 + mm * 44 + 64;
         DLSA_REQUIRE(shm <= (size_t)kLdsBytes, "lars_lsa: p=%d needs %zu bytes of LDS (limit %d)", p, shm, kLdsBytes);
