@@ -23,6 +23,9 @@ for c in range(cases):
     X, y = engine.synth(int(rng.integers(1, 1 << 30)), 0, n, p, kind=kind)
     strided = K > 1 and rng.random() < 0.5
     icpt = bool(rng.random() < 0.4)
+    print_case = lambda: print("CASE %d: n=%d p=%d K=%d strided=%s icpt=%s kind=%d" % (c, n, p, K, strided, icpt, kind), flush=True)
+    if os.environ.get("FIT_FUZZ_VERBOSE"):
+        print_case()
     if strided:
         first, rows = list(range(K)), [(n - k + K - 1) // K for k in range(K)]
         r = engine.irls_fit_ex(X, y, first, rows, row_step=K, fit_intercept=icpt)

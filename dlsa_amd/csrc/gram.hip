@@ -740,6 +740,20 @@ static void choose_slabs(int64_t n, int nitems, int& nslab, int64_t& rows_per_sl
     nslab = (int)ns;
 }
 
+// Upper bound of choose_slabs' slab count that is MONOTONE in n.  A workspace sized for the largest partition of a fit is reused for
+// every smaller row count (other partitions, subsample levels), and the exact count is not monotone: the rounding of rows_per_slab to
+// whole chunks makes 319489 rows take 504 slabs and 319488 rows 512 (found by bench/fit_fuzz.py: the smaller partition of an
+// i % 2 split did not fit the workspace of the larger one).
+static int slab_bound(int64_t n, int nitems) {
+    const int64_t resident = (int64_t)DLSA_GRAM_OCC * kNumCU;
+    nitems = std::max(1, nitems);
+    int64_t rounds = (n * nitems + resident * 16384) / (resident * 32768);
+    rounds = std::min<int64_t>(std::max<int64_t>(rounds, 1), nitems);
+    int64_t ns = std::max<int64_t>(1, resident * rounds / nitems);
+    ns = std::min(ns, std::max<int64_t>(1, (n + 255) / 256));
+    return (int)((ns + kNumXCD - 1) / kNumXCD * kNumXCD);          // the final count never exceeds the first estimate, rounded up to the XCDs
+}
+
 // gram_wide.hip: the 256-column-panel fp32 kernel for wide p
 bool gram_wide_f32_shape_ok(int64_t n, int p);
 bool gram_wide_f32_eligible(const float* X, int64_t ldx, const float* w, int64_t n, int p);
@@ -773,9 +787,7 @@ static size_t gram_ws_bytes(int64_t n, int p, int elem_bytes) {
     std::vector<GramItem> items, listed;
     int nt_list = 0;
     build_plan_items(p, items, listed, nt_list);      // host-only, cheap: the exact item counts
-    int nslab, nslab2 = 0; int64_t rps;
-    choose_slabs(n, (int)items.size(), nslab, rps);
-    if (nt_list) choose_slabs(n, (int)listed.size(), nslab2, rps);
+    const int nslab = slab_bound(n, (int)items.size()), nslab2 = nt_list ? slab_bound(n, (int)listed.size()) : 0;
     const size_t PP = ((size_t)ntile * TILE + 63) / 64 * 64;
     size_t bytes = align_up((size_t)std::max(nslab, nslab2) * PP * PP * elem_bytes, 256);
     if (elem_bytes == 4 && gram_wide_f32_shape_ok(n, p)) bytes = std::max(bytes, gram_wide_f32_ws_bytes(n, p));

@@ -336,8 +336,11 @@ bool gram_narrow_eligible(const double* X, int64_t ldx, const double* w, int64_t
 }
 
 size_t gram_narrow_ws_bytes(int64_t n, int p) {
-    int64_t rps;
-    const int ns = narrow_slabs(n, p, rps);
+    // the first estimate of narrow_slabs: an upper bound of its result that is monotone in n (a workspace sized for the largest
+    // partition serves every smaller row count; the exact count is not monotone, see slab_bound in gram.hip)
+    int nt, g;
+    gram_narrow_shape(p + (p & 1), nt, g);
+    const int64_t ns = std::min<int64_t>((int64_t)kNumCU * narrow_wgs_per_cu(nt, g), std::max<int64_t>(1, n / 1024));
     const size_t PP = ((size_t)(p + 15) / 16 * 16 + 63) / 64 * 64;
     return align_up((size_t)ns * PP * PP * 8, 256) + kGramProbeBytes;
 }

@@ -509,13 +509,13 @@ bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int
 }
 
 static size_t fp_fused_ws_bytes(int64_t n, int p) {
-    int64_t rps;
-    const int ns = fp_slabs(n, rps);
     int nt, g;
     fp_shape(p, nt, g);
     const int ntc = nt + (g > 0 ? 1 : 0);
-    int64_t rps2;
-    const int ns_logit = fp_slabs(n, rps2, fp_logit_wgs(ntc));          // the logit-only launch of short rows: two workgroups per CU
+    // first estimates of fp_slabs: upper bounds of its results that are monotone in n (one workspace serves every row count up to n)
+    const int64_t base = std::max<int64_t>(1, n / 2048);
+    const int ns = (int)std::min<int64_t>(kNumCU, base);
+    const int ns_logit = (int)std::min<int64_t>((int64_t)kNumCU * fp_logit_wgs(ntc), base);    // the logit-only launch of short rows: two workgroups per CU
     return align_up((size_t)ns * fp_pp(p) * fp_pp(p) * 8, 256) + align_up((size_t)std::max(ns, ns_logit) * fp_gp(ntc) * 8, 256) + kGramProbeBytes;
 }
 

@@ -107,3 +107,24 @@ def test_engine_refuses_cpu_tensors():
         import dlsa_amd
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             dlsa_amd.fit_linear_chunks([(0, np.zeros((4, 2)), np.zeros(4))], 2)
+
+
+def test_workspace_queries_are_monotone_in_the_row_count():
+    """A workspace sized for the largest partition of a fit is reused for every smaller row count (the other partitions, the
+    subsample levels), so every *_workspace_bytes query must be non-decreasing in n.  The slab counts behind them are not
+    (319489 rows: 504 slabs, 319488 rows: 512): the queries return monotone bounds.  Host-only calls, no GPU."""
+    import numpy as np
+    from dlsa_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    queries = [("dlsa_gram_workspace_bytes", lambda n, p: lib.dlsa_gram_workspace_bytes(ctypes.c_int64(n), p, 8)),
+               ("dlsa_irls_pass_workspace_bytes", lambda n, p: lib.dlsa_irls_pass_workspace_bytes(ctypes.c_int64(n), p))]
+    # (dlsa_irls_workspace_bytes is a multiple of these per-pass bounds: one slice per partition chain, four up to 8 GB partitions,
+    #  one beyond -- it is asked for the largest partition of the call it serves, not reused across calls)
+    for p in (5, 6, 37, 64, 100, 118, 260, 500):
+        sizes = sorted(set([319488, 319489, 8192, 65535, 65536, 1 << 20] + [int(v) for v in rng.integers(1, 3_000_000, 60)]))
+        for name, q in queries:
+            vals = [q(n, p) for n in sizes]
+            assert all(v > 0 for v in vals), (name, p)
+            bad = [(sizes[i], sizes[i + 1], vals[i], vals[i + 1]) for i in range(len(vals) - 1) if vals[i] > vals[i + 1]]
+            assert not bad, (name, p, bad[:3])

@@ -82,3 +82,16 @@ def test_chained_structured_fit_and_an_empty_partition(eng, monkeypatch):
     assert float(r3["Sig_inv"][3].abs().max()) == 0.0 and float(r3["coef"][3].abs().max()) == 0.0
     for key in ("coef", "Sig_inv", "Sig_invMcoef"):
         assert rel_inf(r3[key].cpu().numpy(), r1[key].cpu().numpy()) < 1e-9, key
+
+
+def test_partitions_one_row_apart_share_the_workspace_of_the_larger(eng, orc):
+    """Found by bench/fit_fuzz.py: with i % 2 partitions of 319489 and 319488 rows the SMALLER one needed 512 Gram slabs where
+    the workspace, sized for the larger, held 504 (slab counts are not monotone in the row count; the workspace bounds now are)."""
+    n, p = 638977, 5
+    X, y = eng.synth(20261002, 0, n, p, kind=eng.SYNTH_UNIFORM)
+    r = eng.irls_fit_ex(X, y, [0, 1], [(n + 1) // 2, n // 2], row_step=2, fit_intercept=True)
+    assert r["status"] == [0, 0]
+    for k in (0, 1):
+        Ak = np.hstack([np.ones(((n - k + 1) // 2, 1)), X[k::2].cpu().numpy()])
+        c, smc, sig = orc.logistic_model_block(Ak, y[k::2].cpu().numpy())
+        assert rel_inf(r["coef"][k].cpu().numpy(), c) < 1e-10 and rel_inf(r["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
