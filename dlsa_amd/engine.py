@@ -90,9 +90,10 @@ release_workspaces = release_workspace
 
 
 def _rowmajor(X):
-    if X.dim() != 2 or X.stride(1) != 1:
+    # (a single column is row-major whatever stride(1) says: torch and numpy keep the parent's pitch on a size-1 dimension)
+    if X.dim() != 2 or (X.shape[1] > 1 and X.stride(1) != 1):
         raise ValueError("X must be a 2-D row-major tensor (stride(1) == 1)")
-    return X.stride(0) if X.shape[0] > 1 else max(X.stride(0), X.shape[1])
+    return max(X.stride(0), X.shape[1]) if X.shape[0] > 1 else max(X.stride(0), X.shape[1])
 
 
 def rows_to_device(a, device="cuda"):
@@ -101,10 +102,14 @@ def rows_to_device(a, device="cuda"):
     (76 ms for 1e6 x 100 doubles), so a column-major array goes over the link as it lies and is transposed in HBM."""
     if isinstance(a, np.ndarray) and a.ndim == 2 and a.size > 0 and not a.flags.c_contiguous and a.flags.f_contiguous:
         t = torch.from_numpy(a.T).to(device).t()
-        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)           # (.contiguous() keeps a size-1 dimension's stride)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    if t.dim() == 2 and (t.stride(1) != 1 or t.stride(0) != t.shape[1]) and t.numel() > 0:
+        # (a size-1 dimension counts as contiguous with ANY stride, for numpy and torch alike: an [n, 1] column view keeps its parent's pitch)
+        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
         out.copy_(t)
         return out
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return t
 
 
 def empty_rows(n, p, dtype=torch.float64, device="cuda"):

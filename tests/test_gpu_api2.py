@@ -153,3 +153,25 @@ def test_logistic_model_same_block_for_columnar_and_row_major_frames(api):
     for o in outs[1:]:
         assert list(o.columns) == list(outs[0].columns)
         assert np.array_equal(o.to_numpy(), outs[0].to_numpy())
+
+
+def test_single_numeric_column_frames_and_column_views(api):
+    """A size-1 dimension is 'contiguous' with any stride (numpy and torch keep the parent's pitch on it): a one-feature frame and a
+    one-column view of a wider device matrix must both go through (found by bench/frame_fuzz.py: the row-major check refused them)."""
+    import numpy as np
+    import pandas as pd
+    from dlsa_amd import engine
+    rng = np.random.default_rng(4)
+    n = 70000                                        # above the 2^16-element threshold of the per-column upload
+    x = rng.random(n) - 0.5
+    y = (rng.random(n) < 1 / (1 + np.exp(-2 * x))).astype(np.int64)
+    wide = np.column_stack([np.zeros(n), y.astype(np.float64), x])               # one row-major parent: the feature is a strided [n, 1] view
+    frames = [pd.DataFrame({"partition_id": 0, "label": y, "x0": x}), pd.DataFrame(wide, columns=["partition_id", "label", "x0"])]
+    outs = [api.logistic_model(df, "label", fit_intercept=True) for df in frames]
+    assert np.array_equal(outs[0].to_numpy(), outs[1].to_numpy())
+    Xw = torch.from_numpy(np.column_stack([x, rng.random(n), rng.random(n)])).cuda()
+    yd = torch.from_numpy(y.astype(np.float64)).cuda()
+    r_view = engine.irls_fit_ex(Xw[:, 0:1], yd, [0], [n], row_step=1, fit_intercept=True)       # pitch 3, one column
+    r_col = engine.irls_fit_ex(torch.from_numpy(x[:, None].copy()).cuda(), yd, [0], [n], row_step=1, fit_intercept=True)
+    assert r_view["status"] == [0] and torch.equal(r_view["coef"], r_col["coef"]) and torch.equal(r_view["Sig_inv"], r_col["Sig_inv"])
+    assert np.allclose(outs[0]["coef"].to_numpy(), r_col["coef"][0].cpu().numpy(), rtol=1e-10, atol=0)
