@@ -677,7 +677,19 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
     // tuning knobs for experiments (defaults are the production policy)
     const char* env_sub = getenv("DLSA_IRLS_SUBSAMPLE");
     const char* env_frz = getenv("DLSA_IRLS_FREEZE");
-    const int sub_div = env_sub ? atoi(env_sub) : 16;          // 0/1 disables the warm start
+    // 0/1 disables the warm start.  Wide designs (p >= 384) start from the smallest of 1/64, 1/32, 1/16 of the rows that still pins the
+    // MLE (>= 200 p rows): at p = 500 the 1/16 subsample's own Newton run (Gram passes over 1.5e6 rows) costs more than its slightly
+    // better start buys (bench/ab_subsample.sh, 2.5e7 x 500: 254-255 ms at 16, 241-242 at 64; p = 100: 11.3 ms at 16, 11.8-11.9 at 32-64)
+    const int sub_div = env_sub ? atoi(env_sub) : 16;
+    auto subsample_rows = [&](int64_t nk) -> int64_t {
+        if (sub_div <= 1) return 0;
+        if (!env_sub && p >= 384)
+            for (int d = 64; d > 16; d /= 2) {
+                const int64_t ns = nk / d;
+                if (ns >= 200 * (int64_t)p && ns >= 50000) return ns;
+            }
+        return nk / sub_div;
+    };
     const double freeze_at = env_frz ? atof(env_frz) : 1.0;    // 0 disables the frozen Hessian
 
     const char* env_warm = getenv("DLSA_IRLS_WARM");
@@ -766,7 +778,7 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
                     DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
                     cs.factor_rows = 0;
                     // cold start of a large partition: solve its leading 1/sub_div rows first
-                    const int64_t nsub = sub_div > 1 ? nk / sub_div : 0;
+                    const int64_t nsub = subsample_rows(nk);
                     if (nsub >= 200 * (int64_t)p && nsub >= 50000) {
                         int st_sub = 0, it_sub = 0, gr_sub = 0;
                         double ll_sub = 0.0;
