@@ -688,6 +688,11 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
                 const int64_t ns = nk / d;
                 if (ns >= 200 * (int64_t)p && ns >= 50000) return ns;
             }
+        if (!env_sub && p >= 192)          // a partition too short for 1/16 (1e6 x 500: 62500 < 200 p rows) still profits from a larger share
+            for (int d = 16; d >= 4; d /= 2) {
+                const int64_t ns = nk / d;
+                if (ns >= 200 * (int64_t)p && ns >= 50000) return ns;
+            }
         return nk / sub_div;
     };
     const double freeze_at = env_frz ? atof(env_frz) : 1.0;    // 0 disables the frozen Hessian
