@@ -8,7 +8,10 @@ Same call sequence and result objects as the reference driver --
     -> pickle [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time] (:411-412)
 -- but the Spark partitions are contiguous row ranges of a device-resident shard and the reduce is
 one all-reduce.  Settings are module-level constants in the reference (:66-175); here they are
-command-line flags with the reference's "simulated_pdf" defaults (n=1e5, K=20, p=200).
+command-line flags with the reference's "simulated_pdf" defaults (n=1e5, K=20, p=200).  `--csv FILE...` is the reference's
+real-data branch (:100-175, 218-237): read the CSV(s), keep usecols_x + [Y], drop NAs, binarise Y > 0, select / load the dummy
+levels (dummy_keep_top, 000_OTHERS), load / compute the standardisation table, partition_id = row % ceil(n / 1e6), and fit the
+dummy design from level codes on the device (the one-hot matrix is never built on the host; the airline defaults are built in).
 
   python projects/logistic_dlsa.py                                   # 1 GPU
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 projects/logistic_dlsa.py ...
@@ -37,6 +40,14 @@ def main():
     ap.add_argument("--fit-intercept", action="store_true")         # reference :80 (True for the airline data)
     ap.add_argument("--gaussian", action="store_true", help="N(0,1/12) features instead of U(-0.5,0.5)")
     ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--csv", nargs="+", default=[], help="real-data mode: CSV file(s) with a header (reference file_path, :107)")
+    ap.add_argument("--y-name", default="", help="response column, binarised as Y > 0 (default ArrDelay, :172)")
+    ap.add_argument("--usecols-x", default="", help="comma-separated feature columns (default: the airline usecols_x, :109-110)")
+    ap.add_argument("--dummy-columns", default=None, help="comma-separated categorical columns (default: the airline dummy_columns, :156)")
+    ap.add_argument("--dummy-keep-top", default="", help="comma-separated cumulative shares kept per dummy column (default 1,1,0.8,0.9,0.9, :164)")
+    ap.add_argument("--dummy-info", default="", help="pickle of the dummy_info dictionary: loaded when it exists, else created and saved there (:142-153)")
+    ap.add_argument("--data-info", default="", help="CSV of describe() (count / mean / stddev rows): loaded when it exists, else created and saved (:263-275)")
+    ap.add_argument("--sample-size-per-partition", type=int, default=1000000)      # reference :169
     ap.add_argument("--save", default="", help="pickle path for [Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time]")
     ap.add_argument("--coef-csv", default="", help="write the coefficient table Var, MLE, DLSA_AIC, DLSA_BIC, WLSE, ONE_SHOT "
                     "(projects/results/plot_coef.py:43-51); the MLE column is the global fit of all rows as one partition per rank, combined")
@@ -48,39 +59,110 @@ def main():
     n, K, p = args.sample_size, args.partition_num, args.p
     Y_name = "label"
 
-    # ---- this rank's partitions: k % world == rank, each a contiguous row range (repartition, :295)
-    tictoc["repartition"] = [time.perf_counter()]
-    mine = distributed.owned_partitions(K, world, rank)
-    sizes = [len(range(k, n, K)) for k in mine]                     # partition_id = i % K  (models.py:33)
-    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    n_local = int(offs[-1])
-    kind = engine.SYNTH_GAUSSIAN if args.gaussian else engine.SYNTH_UNIFORM
-    # rows of partition k are the global rows k, k+K, k+2K, ...: generate the full stream once per rank in
-    # chunks and keep this rank's rows grouped by partition (device gather)
-    Xl = torch.empty((n_local, p), dtype=torch.float64, device="cuda")
-    yl = torch.empty((n_local,), dtype=torch.float64, device="cuda")
-    fill = [int(o) for o in offs[:-1]]
-    chunk = max(K, (1 << 22) // max(1, p) // K * K)
-    for r0 in range(0, n, chunk):
-        m = min(chunk, n - r0)
-        Xc, yc = engine.synth(args.seed, r0, m, p, kind=kind)
-        pid = (torch.arange(r0, r0 + m, device="cuda") % K)
-        for j, k in enumerate(mine):
-            sel = (pid == k).nonzero().flatten()
-            Xl[fill[j]: fill[j] + sel.numel()] = Xc[sel]
-            yl[fill[j]: fill[j] + sel.numel()] = yc[sel]
-            fill[j] += sel.numel()
-    torch.cuda.synchronize()
-    tictoc["repartition"].append(time.perf_counter())
-    memsize_total = n * (p + 2) * 8
+    if args.csv:
+        # ---- real data (reference :218-237, 263-275): host parsing, then level codes + numerics on the device
+        from dlsa_amd import dummies, ingest
+        Y_name = args.y_name or ingest.AIRLINE_Y
+        usecols_x = args.usecols_x.split(",") if args.usecols_x else list(ingest.AIRLINE_USECOLS_X)
+        dummy_columns = (args.dummy_columns.split(",") if args.dummy_columns else []) if args.dummy_columns is not None \
+            else [c for c in ingest.AIRLINE_DUMMY_COLUMNS if c in usecols_x]
+        keep_top = [float(v) for v in args.dummy_keep_top.split(",")] if args.dummy_keep_top else [1, 1, 0.8, 0.9, 0.9][:len(dummy_columns)]
+        if len(keep_top) != len(dummy_columns):
+            raise SystemExit("--dummy-keep-top needs one share per dummy column")
+        tictoc["repartition"] = [time.perf_counter()]
+        pdf = pd.concat([ingest.read_csv_frame(os.path.expanduser(f), usecols_x, Y_name, dummy_columns) for f in args.csv], ignore_index=True)
+        n = len(pdf)
+        if dummy_columns:
+            path = os.path.expanduser(args.dummy_info) if args.dummy_info else ""
+            if path and os.path.exists(path):
+                with open(path, "rb") as f:
+                    dummy_info = pickle.load(f)
+            else:
+                dummy_info = dummies.select_dummy_factors(dummies.dummy_factors_counts(pdf, dummy_columns), keep_top, "000_OTHERS",
+                                                          pickle_file=(path if (path and rank == 0) else None))
+            # baselines when fitting the intercept (:158-162): the folded level where there is one, else the first selected level
+            baseline = [(c + "_000_OTHERS") if len(dummy_info["factor_dropped"][c]) > 0 else sorted(dummy_info["factor_selected_names"][c])[0]
+                        for c in dummy_columns] if args.fit_intercept else []
+        else:
+            dummy_info, baseline = [], []
+        numeric_cols = [c for c in usecols_x if c not in dummy_columns]
+        path = os.path.expanduser(args.data_info) if args.data_info else ""
+        if path and os.path.exists(path):
+            data_info = pd.read_csv(path)
+        else:
+            data_info = ingest.data_info_from_frame(pdf, numeric_cols)
+            if path and rank == 0:
+                data_info.to_csv(path, index=False)
+        sh = ingest.shard_from_frame(pdf, Y_name, dummy_info, baseline, data_info, args.fit_intercept,
+                                     sample_size_per_partition=args.sample_size_per_partition, world=world, rank=rank)
+        del pdf
+        K, spec = sh["partition_num"], sh["spec"]
+        p = len(spec.names) - int(args.fit_intercept)
+        torch.cuda.synchronize()
+        tictoc["repartition"].append(time.perf_counter())
+        memsize_total = n * (len(usecols_x) + 2) * 8
+        tictoc["mapred"] = [time.perf_counter()]
+        mapped = dlsa_amd.fit_logistic_design(sh["num"], sh["codes"], sh["y"], spec, part_offsets=sh["part_offsets"])
+        bad = [s_ for s_ in mapped.status if s_ != 0]
+        if bad and rank == 0:
+            print("warning: partitions with status", mapped.status)
+        names = list(spec.names)
 
-    # ---- map + reduce (dlsa part 1)
-    tictoc["mapred"] = [time.perf_counter()]
-    names = ["x" + str(i) for i in range(p)]
-    mapped = dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=offs, fit_intercept=args.fit_intercept, names=names)
-    bad = [s for s in mapped.status if s != 0]
-    if bad and rank == 0:
-        print("warning: partitions with status", mapped.status)
+        def evaluate(out_par):
+            # model_eval.py:10-42 on the device: the design matrix of a row chunk (intercept column included) and one pass per 8 estimators
+            par = torch.from_numpy(out_par.to_numpy(dtype=np.float64)).cuda()
+            tot = torch.zeros(par.shape[1], dtype=torch.float64, device="cuda")
+            m = int(sh["y"].numel())
+            for a in range(0, m, 1 << 21):
+                b = min(m, a + (1 << 21))
+                Xc, _ = spec.build(sh["num"][a:b] if sh["num"] is not None else None, sh["codes"][a:b])
+                for c0 in range(0, par.shape[1], 8):
+                    tot[c0:c0 + 8] += engine.loglik(Xc, sh["y"][a:b].contiguous(), par[:, c0:c0 + 8].contiguous())
+            return distributed.allreduce_message(tot)
+
+        def global_fit():
+            return dlsa_amd.fit_logistic_design(sh["num"], sh["codes"], sh["y"], spec, part_offsets=[0, int(sh["y"].numel())])
+    else:
+        # ---- this rank's partitions: k % world == rank, each a contiguous row range (repartition, :295)
+        tictoc["repartition"] = [time.perf_counter()]
+        mine = distributed.owned_partitions(K, world, rank)
+        sizes = [len(range(k, n, K)) for k in mine]                     # partition_id = i % K  (models.py:33)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n_local = int(offs[-1])
+        kind = engine.SYNTH_GAUSSIAN if args.gaussian else engine.SYNTH_UNIFORM
+        # rows of partition k are the global rows k, k+K, k+2K, ...: generate the full stream once per rank in
+        # chunks and keep this rank's rows grouped by partition (device gather)
+        Xl = torch.empty((n_local, p), dtype=torch.float64, device="cuda")
+        yl = torch.empty((n_local,), dtype=torch.float64, device="cuda")
+        fill = [int(o) for o in offs[:-1]]
+        chunk = max(K, (1 << 22) // max(1, p) // K * K)
+        for r0 in range(0, n, chunk):
+            m = min(chunk, n - r0)
+            Xc, yc = engine.synth(args.seed, r0, m, p, kind=kind)
+            pid = (torch.arange(r0, r0 + m, device="cuda") % K)
+            for j, k in enumerate(mine):
+                sel = (pid == k).nonzero().flatten()
+                Xl[fill[j]: fill[j] + sel.numel()] = Xc[sel]
+                yl[fill[j]: fill[j] + sel.numel()] = yc[sel]
+                fill[j] += sel.numel()
+        torch.cuda.synchronize()
+        tictoc["repartition"].append(time.perf_counter())
+        memsize_total = n * (p + 2) * 8
+
+        # ---- map + reduce (dlsa part 1)
+        tictoc["mapred"] = [time.perf_counter()]
+        names = ["x" + str(i) for i in range(p)]
+        mapped = dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=offs, fit_intercept=args.fit_intercept, names=names)
+        bad = [s for s in mapped.status if s != 0]
+        if bad and rank == 0:
+            print("warning: partitions with status", mapped.status)
+
+        def evaluate(out_par):
+            return dlsa_amd.loglik_partitions(Xl, yl, out_par, fit_intercept=args.fit_intercept)      # model_eval.py:10-42, one all-reduce
+
+        def global_fit():
+            return dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=[0, n_local], fit_intercept=args.fit_intercept, names=names)
+
     Sig_inv_beta = dlsa_amd.dlsa_mapred(mapped, num_partitions=K)      # K = partitions of the whole job (dlsa.py:51-52)
     torch.cuda.synchronize()
     tictoc["mapred"].append(time.perf_counter())
@@ -97,7 +179,7 @@ def main():
     out_par = out_dlsa.copy()
     out_par["beta_byOLS"] = Sig_inv_beta["beta_byOLS"]
     out_par["beta_byONESHOT"] = Sig_inv_beta["beta_byONESHOT"]
-    ll = dlsa_amd.loglik_partitions(Xl, yl, out_par, fit_intercept=args.fit_intercept)      # model_eval.py:10-42, one all-reduce
+    ll = evaluate(out_par)
     out_model_eval = pd.DataFrame({c: [float(v)] for c, v in zip(out_par.columns, ll.cpu().numpy())})
     tictoc["model_eval"].append(time.perf_counter())
 
@@ -113,8 +195,7 @@ def main():
     if args.coef_csv:
         # the table's MLE column (plot_coef.py:20-41 takes it from a separate global fit): every rank fits ITS rows as one
         # partition, the WLS combine of those fits is the global estimate up to O(1/n^2)
-        g = dlsa_amd.dlsa_mapred(dlsa_amd.fit_logistic_partitions(Xl, yl, part_offsets=[0, n_local],
-                                                                 fit_intercept=args.fit_intercept, names=names))
+        g = dlsa_amd.dlsa_mapred(global_fit())
         if rank == 0:
             from dlsa_amd import results
             results.write_coef_csv(args.coef_csv, out_par, list(Sig_inv_beta.columns[2:]), beta_byMLE=g["beta_byOLS"].to_numpy())

@@ -175,3 +175,53 @@ def test_single_numeric_column_frames_and_column_views(api):
     r_col = engine.irls_fit_ex(torch.from_numpy(x[:, None].copy()).cuda(), yd, [0], [n], row_step=1, fit_intercept=True)
     assert r_view["status"] == [0] and torch.equal(r_view["coef"], r_col["coef"]) and torch.equal(r_view["Sig_inv"], r_col["Sig_inv"])
     assert np.allclose(outs[0]["coef"].to_numpy(), r_col["coef"][0].cpu().numpy(), rtol=1e-10, atol=0)
+
+
+def test_driver_real_data_mode_from_csv(api, tmp_path):
+    """projects/logistic_dlsa.py --csv: the reference's real-data branch (logistic_dlsa.py:100-175, 218-237) -- CSV -> select /
+    dropna / binarise -> dummy levels (created and pickled, then LOADED on the second run) -> standardisation table -> level codes ->
+    structured fit per partition -> dlsa_mapred -> dlsa -> evaluation -> pickle [Sig_inv_beta, out_dlsa, out_par, out_model_eval,
+    out_time].  Checked against the library calls made directly on the same frame."""
+    import pickle
+    from dlsa_amd import dummies, ingest
+    rng = np.random.default_rng(21)
+    n = 12000
+    raw = pd.DataFrame({"Distance": rng.normal(700, 300, n), "DepTime": rng.uniform(0, 2400, n),
+                        "UniqueCarrier": rng.choice(["AA", "UA", "DL", "WN", "HP", "TW"], n, p=[.35, .25, .2, .12, .05, .03]),
+                        "DayOfWeek": rng.integers(1, 8, n), "FlightNum": rng.integers(1, 999, n)})
+    eta = 0.5 * (raw["Distance"] - 700) / 300 - 0.4 * (raw["UniqueCarrier"] == "UA") + 0.3 * (raw["DayOfWeek"] == 5)
+    raw["ArrDelay"] = np.where(rng.random(n) < 1 / (1 + np.exp(-eta)), rng.uniform(1, 60, n), -rng.uniform(0, 30, n))
+    raw.loc[rng.choice(n, 50, replace=False), "Distance"] = np.nan
+    path = str(tmp_path / "air.csv")
+    raw.to_csv(path, index=False, na_rep="NA")
+    usecols, dcols = ["Distance", "DepTime", "UniqueCarrier", "DayOfWeek"], ["UniqueCarrier", "DayOfWeek"]
+    common = [sys.executable, os.path.join(ROOT, "projects", "logistic_dlsa.py"), "--csv", path, "--y-name", "ArrDelay",
+              "--usecols-x", ",".join(usecols), "--dummy-columns", ",".join(dcols), "--dummy-keep-top", "0.93,1", "--fit-intercept",
+              "--sample-size-per-partition", "4000", "--dummy-info", str(tmp_path / "dummy_info.pkl"), "--data-info", str(tmp_path / "data_info.csv")]
+    outs = []
+    for run in range(2):                                  # second run: dummy_info / data_info are loaded from the files the first wrote
+        save = str(tmp_path / ("res%d.pkl" % run))
+        pr = subprocess.run(common + ["--save", save], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        with open(save, "rb") as f:
+            outs.append(pickle.load(f))
+    assert os.path.exists(tmp_path / "dummy_info.pkl") and os.path.exists(tmp_path / "data_info.csv")
+    Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time = outs[0]
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+    # the same steps through the library
+    pdf = ingest.read_csv_frame(path, usecols, "ArrDelay", dummy_columns=dcols)
+    info = dummies.select_dummy_factors(dummies.dummy_factors_counts(pdf, dcols), [0.93, 1], "000_OTHERS")
+    baseline = ["UniqueCarrier_000_OTHERS", sorted(info["factor_selected_names"]["DayOfWeek"])[0]]
+    data_info = ingest.data_info_from_frame(pdf, ["Distance", "DepTime"])
+    sh = ingest.shard_from_frame(pdf, "ArrDelay", info, baseline, data_info, True, sample_size_per_partition=4000)
+    K = sh["partition_num"]
+    assert K == 3 and int(out_time["partition_num"][0]) == 3 and int(out_time["sample_size"][0]) == len(pdf) == n - 50
+    ref = api.dlsa_mapred(api.fit_logistic_design(sh["num"], sh["codes"], sh["y"], sh["spec"], part_offsets=sh["part_offsets"]), num_partitions=K)
+    assert list(Sig_inv_beta.columns) == ["beta_byOLS", "beta_byONESHOT"] + sh["spec"].names and sh["spec"].names[0] == "intercept"
+    assert rel_inf(Sig_inv_beta.to_numpy(), ref.to_numpy()) < 1e-12
+    assert list(out_par.columns) == ["beta_byAIC", "beta_byBIC", "beta_byOLS", "beta_byONESHOT"]
+    # evaluation: the log-likelihood of each estimator over all rows, against the frame-level evaluation of the same frame
+    pdf.insert(0, "partition_id", np.arange(len(pdf)) % K)
+    ev = api.logistic_model_eval_sdf(pdf, out_par, True, "ArrDelay", info, baseline, data_info)
+    assert rel_inf(out_model_eval.to_numpy(), ev.to_numpy()) < 1e-10
