@@ -21,7 +21,11 @@ def dummy_factors_counts(pdf, dummy_columns):
         names = [cols[c] for c in dummy_columns]
     else:
         names = list(dummy_columns)
-    return {c: pdf[c].value_counts().to_dict() for c in names}
+    out = {}
+    for c in names:
+        vc = pdf[c].value_counts()
+        out[c] = vc[vc > 0].to_dict()           # (a categorical column also lists levels that no row holds any more)
+    return out
 
 
 def cumsum_dicts(dict1, dict2):

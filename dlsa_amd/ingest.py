@@ -19,18 +19,40 @@ AIRLINE_DUMMY_COLUMNS = ["Month", "DayOfWeek", "UniqueCarrier", "Origin", "Dest"
 AIRLINE_Y = "ArrDelay"                                                                     # logistic_dlsa.py:172
 
 
-def read_csv_frame(path, usecols_x, Y_name, dummy_columns=(), binarize=True, nrows=None):
+def read_csv_frame(path, usecols_x, Y_name, dummy_columns=(), binarize=True, nrows=None, engine="auto"):
     """select(usecols_x + [Y_name]).dropna() and the 0/1 response (logistic_dlsa.py:222-231).  Categorical columns are read
-    as strings (integer-looking levels keep their text, e.g. Month '1'), the rest as float64."""
-    dtypes = {c: "str" for c in dummy_columns}
-    pdf = pd.read_csv(path, usecols=list(usecols_x) + [Y_name], dtype=dtypes, nrows=nrows, engine="c", na_values=["NA"])
-    pdf = pdf.dropna().reset_index(drop=True)
-    for c in usecols_x:
-        if c not in dummy_columns:
-            pdf[c] = pdf[c].astype(np.float64)
+    as strings (integer-looking levels keep their text, e.g. Month '1'), the rest as float64.
+    engine: "pyarrow" parses with Arrow's multi-threaded CSV reader and hands the categorical columns over DICTIONARY-ENCODED
+    (pandas `category`: DesignSpec.encode then takes their codes as they are, no per-row string hashing); "pandas" is the
+    single-threaded C parser with object columns; "auto" = pyarrow when importable and nrows is None.  Same rows, same values,
+    same level strings either way (tests/test_host_api_cpu.py)."""
+    cols = list(usecols_x) + [Y_name]
+    use_arrow = engine == "pyarrow"
+    if engine == "auto" and nrows is None:
+        try:
+            import pyarrow  # noqa: F401
+            use_arrow = True
+        except ImportError:
+            use_arrow = False
+    if use_arrow:
+        import pyarrow as pa
+        import pyarrow.csv as pacsv
+        # dictionary types AT READ TIME: the parser builds the dictionaries block by block on its threads (3e6 rows x 6 columns here:
+        # 1.9 s against 4.3 s for read + dictionary_encode, 8.6 s for pandas' parser with exact float conversion)
+        types = {c: (pa.dictionary(pa.int32(), pa.string()) if c in dummy_columns else pa.float64()) for c in cols}
+        tab = pacsv.read_csv(path, convert_options=pacsv.ConvertOptions(include_columns=cols, column_types=types,
+                                                                          null_values=["NA", ""], strings_can_be_null=True))
+        pdf = tab.drop_null().unify_dictionaries().to_pandas()   # dictionary columns -> pandas category, doubles stay columnar
+    else:
+        dtypes = {c: "str" for c in dummy_columns}
+        pdf = pd.read_csv(path, usecols=cols, dtype=dtypes, nrows=nrows, engine="c", na_values=["NA"], float_precision="round_trip")
+        pdf = pdf.dropna().reset_index(drop=True)
+        for c in usecols_x:
+            if c not in dummy_columns:
+                pdf[c] = pdf[c].astype(np.float64)
     if binarize:
         pdf[Y_name] = (pdf[Y_name].astype(np.float64) > 0).astype(np.float64)          # F.when(Y > 0, 1).otherwise(0)
-    return pdf[list(usecols_x) + [Y_name]]
+    return pdf[cols]
 
 
 def data_info_from_frame(pdf, numeric_cols):
