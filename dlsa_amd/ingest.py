@@ -71,12 +71,18 @@ def shard_from_frame(pdf, Y_name, dummy_info, dummy_factors_baseline, data_info,
     n = len(pdf)
     K = max(1, int(math.ceil(n / float(sample_size_per_partition))))
     spec = DesignSpec.from_reference(list(pdf.columns), Y_name, fit_intercept, dummy_info, dummy_factors_baseline, data_info)
-    num, codes, unknown = spec.encode(pdf, dummy_info)
-    y = pdf[Y_name].to_numpy(dtype=np.float64)
+    # the frame goes to the device as pandas holds it (DesignSpec.numeric_to_device: per column / one strided window), the rows of this
+    # rank's partitions are then grouped THERE (an HBM gather instead of a host fancy-index over every column)
+    _, codes, unknown = spec.encode(pdf, dummy_info, numeric=False)
+    num_d = spec.numeric_to_device(pdf, device)
+    codes_d = torch.from_numpy(codes).to(device)
+    y_d = torch.from_numpy(np.ascontiguousarray(pdf[Y_name].to_numpy(dtype=np.float64))).to(device)
     mine = [k for k in range(K) if k % world == rank]
     # partition_id = row % K: the rows of partition k are k, k + K, k + 2K, ... (O(n) in all, not one pass over the ids per partition)
-    order = np.concatenate([np.arange(k, n, K, dtype=np.int64) for k in mine]) if mine else np.zeros(0, dtype=np.int64)
+    order = torch.cat([torch.arange(k, n, K, dtype=torch.int64, device=device) for k in mine]) if mine else torch.zeros(0, dtype=torch.int64, device=device)
     offs = np.concatenate([[0], np.cumsum([len(range(k, n, K)) for k in mine])]).astype(np.int64)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    return {"num": t(num[order]), "codes": t(codes[order]), "y": t(y[order]), "part_offsets": offs, "spec": spec,
+    if num_d is None:
+        num_d = torch.zeros((n, 0), dtype=torch.float64, device=device)
+    t = lambda a: a.index_select(0, order).contiguous()
+    return {"num": t(num_d), "codes": t(codes_d), "y": t(y_d), "part_offsets": offs, "spec": spec,
             "partition_num": K, "sample_size": n, "partitions": mine, "unknown_levels": bool(unknown)}
