@@ -19,4 +19,4 @@ PY
 ls -la $D/air.csv | awk '{print "csv bytes", $5}'
 rm -f $D/dummy_info.pkl $D/data_info.csv
 python3 projects/logistic_dlsa.py --csv $D/air.csv --fit-intercept --dummy-info $D/dummy_info.pkl --data-info $D/data_info.csv --save $D/res.pkl 2>&1 | grep -v amdgpu | head -12
-rm -f $D/air.csv
+[ -n "$KEEP_CSV" ] || rm -f $D/air.csv

@@ -70,7 +70,9 @@ def main():
         if len(keep_top) != len(dummy_columns):
             raise SystemExit("--dummy-keep-top needs one share per dummy column")
         tictoc["repartition"] = [time.perf_counter()]
-        pdf = pd.concat([ingest.read_csv_frame(os.path.expanduser(f), usecols_x, Y_name, dummy_columns) for f in args.csv], ignore_index=True)
+        frames = [ingest.read_csv_frame(os.path.expanduser(f), usecols_x, Y_name, dummy_columns) for f in args.csv]
+        pdf = frames[0] if len(frames) == 1 else pd.concat(frames, ignore_index=True)
+        del frames
         n = len(pdf)
         if dummy_columns:
             path = os.path.expanduser(args.dummy_info) if args.dummy_info else ""
