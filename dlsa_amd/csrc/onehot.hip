@@ -40,9 +40,11 @@ static int oh_logit_rep(int p) {
 }
 constexpr int OH_MAX_BLOCKS = 512;          // two workgroups per CU; every workgroup flushes its tables once
 
-struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts)
+struct OhTable {                      // one factor-pair table of a Gram role (t <= u; t == u: the diagonal counts), or a BAND of its rows
     int t, u;                         // factor indices
-    int lds_off;                      // offset (doubles) of its L_t x L_u (or L_t) cells in the role's LDS image
+    int lds_off;                      // offset (doubles) of its ltn x L_u (or ltn) cells in the role's LDS image
+    int lt0, ltn;                     // the levels lt0 .. lt0 + ltn - 1 of factor t: a table larger than the LDS budget is cut into
+                                      // row bands that go to different roles (300 x 300 levels: five bands of 64 rows)
 };
 
 struct OhRole {
@@ -323,6 +325,8 @@ __global__ __launch_bounds__(OH_GRAM_THREADS) void oh_gram_kernel(OhDesc ds, con
 #pragma unroll
                 for (int t = 0; t < OH_MAXF; ++t) { lt = (t == tb.t) ? lv[t] : lt; lu = (t == tb.u) ? lv[t] : lu; }
                 if (lt < 0 || lu < 0 || DLSA_DBG_WRONG(ds.dbg, 2)) return;
+                lt -= tb.lt0;
+                if (lt < 0 || lt >= tb.ltn) return;                         // another band's row
                 if (tb.t == tb.u) add_cell(tab + tb.lds_off + lt, wi);
                 else add_cell(tab + tb.lds_off + lt * (ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u]) + lu, wi);
             }
@@ -403,11 +407,11 @@ __global__ __launch_bounds__(256) void oh_gram_finish_kernel(OhDesc ds, const Oh
     } else {
         for (int q = 0; q < role.ntab; ++q) {
             const OhTable tb = role.tab[q];
-            const int Lt = ds.lvl_off[tb.t + 1] - ds.lvl_off[tb.t], Lu = ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u];
-            const int sz = tb.t == tb.u ? Lt : Lt * Lu;
+            const int Lu = ds.lvl_off[tb.u + 1] - ds.lvl_off[tb.u];
+            const int sz = tb.t == tb.u ? tb.ltn : tb.ltn * Lu;
             if (c >= tb.lds_off && c < tb.lds_off + sz) {
                 const int k = c - tb.lds_off;
-                const int lt = tb.t == tb.u ? k : k / Lu, lu = tb.t == tb.u ? k : k % Lu;
+                const int lt = tb.lt0 + (tb.t == tb.u ? k : k / Lu), lu = tb.t == tb.u ? lt : k % Lu;
                 r0 = level_col[ds.lvl_off[tb.t] + lt];
                 c0 = level_col[ds.lvl_off[tb.u] + lu];
                 break;
@@ -573,13 +577,22 @@ int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const 
     }
     for (int j = 0; j < p; ++j) if (!used[j]) return fail("a design column has no source");
     // roles: the dense role (H_DD, H_D,dummy and as many pair tables as fit), then first-fit roles for the rest
-    auto tab_cells = [&](int t, int u) { return t == u ? nlevels[t] : nlevels[t] * nlevels[u]; };
-    struct Pend { int t, u, cells; };
+    const int budget = OH_LDS_BUDGET / (int)sizeof(double);
+    struct Pend { int t, u, cells, lt0, ltn; };
     std::vector<Pend> pend;
     for (int t = 0; t < nfactor; ++t)
-        for (int u = t; u < nfactor; ++u) pend.push_back(Pend{t, u, tab_cells(t, u)});
+        for (int u = t; u < nfactor; ++u) {
+            const int row = t == u ? 1 : nlevels[u];                              // cells per level of factor t
+            if (row > budget) return fail("a factor has too many levels for the structured path: use the dense path");
+            // a table beyond the LDS budget is cut into bands of whole rows, as even as possible; every band is a table of its own
+            int nband = (int)(((int64_t)nlevels[t] * row + budget - 1) / budget);
+            while ((int64_t)((nlevels[t] + nband - 1) / nband) * row > budget) ++nband;       // (the largest band holds ceil(L_t / nband) rows)
+            for (int b = 0; b < nband; ++b) {
+                const int lo = (int)((int64_t)nlevels[t] * b / nband), hi = (int)((int64_t)nlevels[t] * (b + 1) / nband);
+                if (hi > lo) pend.push_back(Pend{t, u, (hi - lo) * row, lo, hi - lo});
+            }
+        }
     std::sort(pend.begin(), pend.end(), [](const Pend& a, const Pend& b) { return a.cells > b.cells; });
-    const int budget = OH_LDS_BUDGET / (int)sizeof(double);
     OhRole first; memset(&first, 0, sizeof(first));
     first.with_dense = 1; first.dense_off = 0; first.cells = ds.nlev_total * OH_MAXD;
     if (first.cells > budget) return fail("too many factor levels for the structured path");
@@ -589,11 +602,12 @@ int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const 
     const int first_extra = (first.dense_rep - 1) * first.cells;
     pl->roles.push_back(first);
     for (auto& pd : pend) {
-        if (pd.cells > budget) return fail("a factor-pair table exceeds the LDS budget: use the dense path");
+        constexpr int max_tab = (int)(sizeof(((OhRole*)nullptr)->tab) / sizeof(OhTable));
         OhRole* dst = nullptr;
-        for (auto& r : pl->roles) if (r.cells + (r.with_dense ? first_extra : 0) + pd.cells <= budget) { dst = &r; break; }
+        for (auto& r : pl->roles)
+            if (r.ntab < max_tab && r.cells + (r.with_dense ? first_extra : 0) + pd.cells <= budget) { dst = &r; break; }
         if (!dst) { OhRole nr; memset(&nr, 0, sizeof(nr)); pl->roles.push_back(nr); dst = &pl->roles.back(); }
-        dst->tab[dst->ntab++] = OhTable{pd.t, pd.u, dst->cells};
+        dst->tab[dst->ntab++] = OhTable{pd.t, pd.u, dst->cells, pd.lt0, pd.ltn};
         dst->cells += pd.cells;
     }
     if (hipMalloc((void**)&pl->d_level_col, std::max<size_t>(1, pl->h_level_col.size()) * sizeof(int32_t)) != hipSuccess ||

@@ -138,7 +138,8 @@ class DesignSpec:
 
     def onehot_plan(self):
         """engine.OnehotPlan for the structured passes (gather / histogram instead of dense rows), or None when the
-        design does not qualify: more than 8 dense columns or 8 factors, or a factor-pair table too large for LDS."""
+        design does not qualify: more than 8 dense columns or 8 factors, or so many levels that the dense-by-level block alone
+        exceeds LDS (pair tables larger than LDS are cut into row bands by the plan)."""
         if getattr(self, "_oh_plan", False) is not False:
             return self._oh_plan
         self._oh_plan = None

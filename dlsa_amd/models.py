@@ -169,7 +169,7 @@ def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=No
                         max_iter=100):
     """Tensor fast path of the map step for a design given by its RAW columns: num [n, q] fp64 (columns in
     spec.numeric_cols order) and codes [n, f] int32 level codes (DesignSpec.encode), both on the GPU.
-    With structured=True and a qualifying design (<= 8 dense columns, factor-pair tables that fit LDS) the fit runs on
+    With structured=True and a qualifying design (<= 8 dense columns, <= 8 factors; pair tables larger than LDS are cut into bands) the fit runs on
     the raw representation -- gather / histogram passes, the dense [n, p] matrix is never built (config 4: 76 B
     instead of 2080 B per row and pass); otherwise the matrix is built once by the design kernel and the dense
     kernels run.  Same MappedBlocks either way."""

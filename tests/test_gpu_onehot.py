@@ -177,15 +177,33 @@ def test_onehot_gram_exact_mode_agrees_with_float_modes_and_falls_back_on_overfl
     assert not bool(torch.isfinite(engine.onehot_gram(plan, dn, dc, dev(wn))).all())
 
 
-def test_onehot_plan_refuses_tables_beyond_lds(api):
+def test_onehot_plan_refuses_what_the_structured_path_cannot_hold(api):
     from dlsa_amd import engine, _lib
     rng = np.random.default_rng(0)
-    p, num, codes, desc, nl, level_col = _random_design(rng, 10, 1, (300, 300))
-    with pytest.raises(_lib.DlsaError, match="LDS budget"):
+    p, num, codes, desc, nl, level_col = _random_design(rng, 10, 1, (2500,))
+    with pytest.raises(_lib.DlsaError, match="bad p"):              # more columns than any kernel here holds (p <= 2048)
         _plan(api, p, desc, nl, level_col)
     p, num, codes, desc, nl, level_col = _random_design(rng, 10, 9, (3,))
     with pytest.raises(_lib.DlsaError, match="dense columns"):
         _plan(api, p, desc, nl, level_col)
+
+
+@pytest.mark.parametrize("n,q,nlevels", [(30000, 2, (300, 300)), (20000, 0, (170, 160, 5)), (9000, 3, (700, 40))])
+def test_onehot_pair_tables_beyond_lds_are_cut_into_row_bands(api, orc, n, q, nlevels):
+    """A factor-pair table larger than the LDS budget (300 x 300 levels = 703 KB) is cut into bands of whole rows that go to
+    different workgroup roles; passes and fit must equal the dense path on the design kernel's matrix."""
+    from dlsa_amd import engine
+    rng = np.random.default_rng(n)
+    p, num, codes, desc, nl, level_col = _random_design(rng, n, q, nlevels)
+    plan = _plan(api, p, desc, nl, level_col)
+    assert plan.roles >= 2
+    X, _ = orc.design_matrix(num, codes, *desc)
+    w = rng.random(n) * 0.25
+    H = engine.onehot_gram(plan, dev(num) if q else None, dev(codes), dev(w)).cpu().numpy()
+    Ho = orc.gram(X, w)
+    assert np.max(np.abs(H - Ho)) < 1e-12 * np.max(np.abs(Ho)) and np.array_equal(H, H.T)
+    H2 = engine.onehot_gram(plan, dev(num) if q else None, dev(codes), dev(w)).cpu().numpy()
+    assert np.array_equal(H, H2)                                       # exact accumulation: bit-reproducible
 
 
 def test_structured_fit_matches_reference_dummy_path(api):
