@@ -86,10 +86,11 @@ def test_onehot_plan_validates_its_descriptor_without_a_gpu(lib):
     k = np.ones(9, i32); z = np.zeros(9, f64); o = np.ones(9, f64); col = np.arange(9, dtype=i32)
     rc = lib.dlsa_onehot_plan_create(9, 9, P(k), P(col), P(z), P(o), P(col), 0, None, None, ctypes.byref(h))
     assert rc == 1 and "dense columns" in _lib.last_error()
-    # two 300-level factors: the 300 x 300 pair table does not fit the LDS budget
-    nl = np.array([300, 300], i32); lc = np.arange(600, dtype=i32)
-    rc = lib.dlsa_onehot_plan_create(600, 0, None, None, None, None, None, 2, P(nl), P(lc), ctypes.byref(h))
-    assert rc == 1 and "LDS budget" in _lib.last_error()
+    # 3000 levels (one of them with a column): the dense-by-level block alone exceeds the LDS budget
+    # (a pair table beyond the budget is no refusal any more: it is cut into row bands)
+    nl = np.array([3000], i32); lc = np.full(3000, -1, dtype=i32); lc[0] = 0
+    rc = lib.dlsa_onehot_plan_create(1, 0, None, None, None, None, None, 1, P(nl), P(lc), ctypes.byref(h))
+    assert rc == 1 and "too many factor levels" in _lib.last_error()
     # a design column without a source
     nl = np.array([3], i32); lc = np.array([-1, 0, 1], i32)
     rc = lib.dlsa_onehot_plan_create(3, 0, None, None, None, None, None, 1, P(nl), P(lc), ctypes.byref(h))
