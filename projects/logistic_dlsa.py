@@ -115,6 +115,14 @@ def main():
             par = torch.from_numpy(out_par.to_numpy(dtype=np.float64)).cuda()
             tot = torch.zeros(par.shape[1], dtype=torch.float64, device="cuda")
             m = int(sh["y"].numel())
+            plan = spec.onehot_plan()
+            if plan is not None and m > 0:
+                # a qualifying dummy design: one structured logit pass per estimator on the raw numerics + level codes (no matrix)
+                for c0 in range(par.shape[1]):
+                    _, _, ll_c = engine.onehot_logit_pass(plan, sh["num"] if sh["num"].shape[1] else None, sh["codes"], sh["y"],
+                                                          par[:, c0].contiguous(), want_w=False, want_g=False)
+                    tot[c0] = ll_c.reshape(-1)[0]
+                return distributed.allreduce_message(tot)
             for a in range(0, m, 1 << 21):
                 b = min(m, a + (1 << 21))
                 Xc, _ = spec.build(sh["num"][a:b] if sh["num"] is not None else None, sh["codes"][a:b])
