@@ -122,3 +122,40 @@ def test_encode_level_codes_match_the_string_chain_for_every_column_type():
     _, codes, unknown = spec.encode(df, info)
     assert codes[:, 0].tolist() == [0, 1, -1] and unknown
     assert spec.missing_levels(codes) == [] and spec.missing_levels(codes[:1]) == ["f_b"]
+
+
+def test_numeric_columns_reach_the_device_tensor_unchanged_for_every_frame_layout():
+    """DesignSpec.numeric_to_device (run here with device="cpu": the upload logic is plain torch): frames built column by column,
+    from one row-major array, with scattered / mixed-dtype columns or a single feature must all give the [n, q] row-major fp64 matrix
+    of the numeric columns in spec order."""
+    import numpy as np
+    import pandas as pd
+    import torch
+    from dlsa_amd import engine
+    from dlsa_amd.design import DesignSpec
+    rng = np.random.default_rng(9)
+    for n, p in ((70000, 3), (3000, 30), (66000, 1), (50, 4)):            # above and below the 2^16-element fast paths
+        X = rng.random((n, p)) - 0.5
+        y = (rng.random(n) < 0.5).astype(np.int64)
+        names = ["x%d" % i for i in range(p)]
+        frames = {
+            "row_major": pd.DataFrame(np.column_stack([np.zeros(n), y.astype(np.float64), X]), columns=["partition_id", "label"] + names),
+            "columnar": pd.DataFrame({"partition_id": 0, "label": y, **{c: np.ascontiguousarray(X[:, i]) for i, c in enumerate(names)}}),
+        }
+        order = list(rng.permutation(names))
+        frames["scattered"] = frames["columnar"][["partition_id"] + order[: p // 2] + ["label"] + order[p // 2:]]
+        mixed = frames["columnar"].copy()
+        mixed[names[0]] = mixed[names[0]].astype(np.float32)
+        frames["mixed"] = mixed
+        for layout, df in frames.items():
+            spec = DesignSpec.from_reference(list(df.columns), "label", False, [], [], [])
+            t = spec.numeric_to_device(df, "cpu")
+            ref = df[spec.numeric_cols].to_numpy(dtype=np.float64)
+            assert tuple(t.shape) == (n, p) and t.dtype == torch.float64, (layout, n, p)
+            assert t.stride(0) == p and (p == 1 or t.stride(1) == 1), (layout, t.stride())
+            assert np.array_equal(t.numpy(), ref), (layout, n, p)
+    # engine.rows_to_device: column-major arrays and single-column views
+    a = np.asfortranarray(rng.random((100, 7)))
+    for arr in (a, a[:, 2:3], np.ascontiguousarray(a)[:, 4:5], a[:0]):
+        t = engine.rows_to_device(arr, "cpu")
+        assert np.array_equal(t.numpy(), arr) and (t.numel() == 0 or (t.stride(0) == arr.shape[1] and (arr.shape[1] == 1 or t.stride(1) == 1)))
