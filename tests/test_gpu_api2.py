@@ -225,3 +225,25 @@ def test_driver_real_data_mode_from_csv(api, tmp_path):
     pdf.insert(0, "partition_id", np.arange(len(pdf)) % K)
     ev = api.logistic_model_eval_sdf(pdf, out_par, True, "ArrDelay", info, baseline, data_info)
     assert rel_inf(out_model_eval.to_numpy(), ev.to_numpy()) < 1e-10
+
+
+def test_the_ctypes_stub_printed_in_integration_md_runs_as_written():
+    """INTEGRATION.md section 3 shows the ctypes binding a reference maintainer would add; the block is executed here as printed
+    (only the library path is made absolute) and its fit compared with the oracle."""
+    import re
+    from oracle import dlsa_oracle as orc
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\nimport ctypes, numpy as np, torch\n(.*?)```", text, re.S)
+    assert m, "the stub moved"
+    code = "import ctypes, numpy as np, torch\n" + m.group(1)
+    code = code.replace('ctypes.CDLL("libdlsa_hip.so")', 'ctypes.CDLL(%r)' % os.path.join(ROOT, "dlsa_amd", "libdlsa_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(0)
+    n, p = 20000, 12
+    X = rng.random((n, p)) - 0.5
+    beta = np.zeros(p); beta[:5] = 1.0
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(np.float64)
+    coef, smc, sig = ns["fit_block"](X, y)
+    c, s2, S = orc.logistic_model_block(X, y)
+    assert rel_inf(coef, c) < 1e-10 and rel_inf(sig, S) < 1e-10 and rel_inf(smc, s2) < 1e-10
