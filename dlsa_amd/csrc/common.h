@@ -61,8 +61,10 @@ struct Arena {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
-                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+    // old = 0 with bound_ctrl: every lane is written (full masks, in-range sources), and hipcc then emits the bare v_mov_b32_dpp;
+    // with old = the source it copied the register first (v_mov + s_nop + v_mov_dpp per dword)
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true));
 }
 template <int M>
 __device__ __forceinline__ double dpp_xor_f64(double v) {      // value of lane ^ M, M in {1, 2, 4, 8}

@@ -48,6 +48,9 @@ constexpr int NARROW_KC = DLSA_NARROW_KC;         // rows per chunk: a multiple 
 #define DLSA_NARROW_STAGES 3          // experiment: 2 = two 32-row stages (half the barriers per row, the DMA one chunk ahead) where two workgroups share a CU
 #endif
 constexpr int NARROW_STAGES = DLSA_NARROW_STAGES;
+#ifndef DLSA_NARROW_PRIVATE
+#define DLSA_NARROW_PRIVATE 1         // 1: every wave stages the rows (and weights) of ITS OWN k-steps, so nothing in the chunk loop crosses waves and the loop has no s_barrier (round 4); 0: rows dealt round-robin, one barrier per chunk
+#endif
 constexpr int NARROW_AHEAD = NARROW_STAGES - 1;      // chunks the DMA runs ahead
 constexpr int NARROW_MIN_P = 49, NARROW_MAX_P = 120;      // 3..7 tiles (+ tail groups while the triangle fits the 256 AGPRs: 7 tiles + 2 groups)
 constexpr int64_t NARROW_MIN_ROWS = 8192;
@@ -210,17 +213,33 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     __syncthreads();
 
     const bool col_in = 2 * lane < a.p;                 // a.p is even: both columns of the lane's 16 bytes are loaded
+    // Row ps (of KC / 4) this wave stages.  PRIVATE: the rows of its own k-steps (k-step wave + 4 kk = rows 4 (wave + 4 kk) .. + 3), so
+    // a wave's MFMAs read only what its own DMA wrote: its own counted s_waitcnt vmcnt orders everything, no barrier in the loop,
+    // and the four waves drift freely (their non-MFMA stretches stop coinciding).
+    auto own_row = [&](int ps) { return DLSA_NARROW_PRIVATE ? 4 * (wave + 4 * (ps >> 2)) + (ps & 3) : wave + NWAVES * ps; };
+    // the chunk's weights.  PRIVATE: this wave's KC / 4 values only, into its own corner of the w slot ([wave][kk][4]): lane L
+    // fetches the two weights 2 (L & 1) .. + 1 of k-step L >> 1.  Else every wave fetches all of them (same bytes to the same place).
+    auto stage_w = [&](int chunk, int buf) {
+        if constexpr (HASW) {
+            double* wdst = lds + buf * BUF + KC * LDP;
+#if DLSA_NARROW_PRIVATE
+            if (lane < KC / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(wdst + (KC / 4) * wave), 16,
+                                                         (4 * (wave + 4 * (lane >> 1)) + 2 * (lane & 1)) * 8, chunk * KC * 8, 0, 0);
+#else
+            if (lane < KC / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)wdst, 16, lane * 16, chunk * KC * 8, 0, 0);
+#endif
+        }
+    };
     auto stage = [&](int chunk, int buf) {
         double* base = lds + buf * BUF;
 #pragma unroll
         for (int ps = 0; ps < KC / NWAVES; ++ps) {
-            const int row = wave + NWAVES * ps;
+            const int row = own_row(ps);
             const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
             if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
-        // every wave fetches the chunk's w (same bytes to the same place): the in-order count is then the same in all waves
-        if (HASW && lane < KC / 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + KC * LDP), 16, lane * 16, chunk * KC * 8, 0, 0);
+        stage_w(chunk, buf);
     };
 
     // the same DMA in five parts: rows wave + 4 ps for ps in [q RQ, (q + 1) RQ), q < 4; then w
@@ -230,14 +249,10 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
         double* base = lds + buf * BUF;
 #pragma unroll
         for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
-            const int row = wave + NWAVES * ps;
+            const int row = own_row(ps);
             const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
             if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
-    };
-    auto stage_w = [&](int chunk, int buf) {
-        if (HASW && lane < KC / 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(lds + buf * BUF + KC * LDP), 16, lane * 16, chunk * KC * 8, 0, 0);
     };
 
     narrow_acc_zero<narrow_nreg(NT, G)>();
@@ -245,7 +260,9 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
 #pragma unroll
     for (int ch = 0; ch < NARROW_AHEAD; ++ch) stage(ch, ch);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NARROW_AHEAD - 1) * DMA_PER_CHUNK) : "memory");
+#if !DLSA_NARROW_PRIVATE
     asm volatile("s_barrier" ::: "memory");
+#endif
 
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);      // the 4 tail columns, broadcast to the 4 blocks
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             for (int t = 0; t < NTC; ++t) f[kk][t] = kb[frag_off + t * 16];
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) bt[kk][gi] = kb[tail_off + 4 * gi];
-            if (HASW) wv[kk] = base[KC * LDP + ks * 4 + (lane >> 4)];
+            if (HASW) wv[kk] = base[KC * LDP + (DLSA_NARROW_PRIVATE ? (KC / 4) * wave + 4 * kk : ks * 4) + (lane >> 4)];
         }
 #pragma unroll
         for (int kk = 0; kk < KC / 16; ++kk) {
@@ -291,7 +308,9 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]), "v"(btw[0]));
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NARROW_AHEAD - 1) * DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
+#if !DLSA_NARROW_PRIVATE
         asm volatile("s_barrier" ::: "memory");
+#endif
         cur = (cur == NARROW_STAGES - 1) ? 0 : cur + 1;
         nxt2 = (nxt2 == NARROW_STAGES - 1) ? 0 : nxt2 + 1;
     }

@@ -24,6 +24,18 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef DLSA_FUSED_PRIVATE
+#define DLSA_FUSED_PRIVATE 1        // 1: the fused pass's waves stage their own rows / labels and run without a barrier in the chunk loop (round 4); 0: round-robin rows, one barrier per chunk
+#endif
+#ifndef DLSA_FUSED_EARLY_FRAGS
+#define DLSA_FUSED_EARLY_FRAGS 1    // 1: the next chunk's fragments are requested behind segment 1 of the second k-step instead of at the iteration's end
+#endif
+#ifndef FP_ABL
+#define FP_ABL 0                    // ABLATION builds only (wrong results; bench/build_variant.sh ... -DFP_ABL=n): 1 no log1p / loglik, 2 no logistic terms, 4 no DMA in the loop, 8 no MFMAs
+#endif
+#ifndef DLSA_FUSED_SCONST
+#define DLSA_FUSED_SCONST 1         // 1: polynomial coefficients of the logistic terms in SGPRs (no v_mov per Horner step)
+#endif
 #ifndef DLSA_STREAM_AUX
 #define DLSA_STREAM_AUX 2           // nt on the LDS-DMA row stream (each row is read by one workgroup, once): ring logit pass -7..-8 % at p = 100-112, narrow Gram +3 % at p = 64, neutral at p = 100; 0 = default policy
 #endif
@@ -41,6 +53,33 @@ size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 
 #include "logistic.h"
 #include "gram_narrow_asm.inc"
+
+// q * r + C with the fp64 coefficient C as a SCALAR operand.  hipcc turns fma(q, r, literal) into v_mov_b64 + v_fmac_f64 (and
+// an SGPR-held coefficient into s_mov + v_mov + v_fmac): two or three VALU slots per Horner step -- and next to fp64 MFMAs EVERY
+// VALU instruction, a move included, costs ~4.7 cycles of the matrix pipe while SALU instructions cost nothing
+// (bench/ubench_gap.hip, profiles/r04_ubench_gap.txt).  The asm form is one VALU slot: v_fma_f64 with the coefficient in the one
+// scalar operand a VOP3 instruction may have (the s_mov_b32 pair that fills it is SALU).  Same arithmetic, same bits.
+__device__ __forceinline__ double fp_fma_sc2(double a, double c, double b) {      // a * C + b
+#if DLSA_FUSED_SCONST
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(c), "v"(b));
+    return d;
+#else
+    return fma(a, c, b);
+#endif
+}
+// a 32-bit / 64-bit constant pinned in VGPRs (opaque to hipcc: it cannot re-create it with a v_mov inside the loop)
+__device__ __forceinline__ int fp_pin32(int v) { int d; asm("v_mov_b32 %0, %1" : "=v"(d) : "s"(v)); return d; }
+__device__ __forceinline__ double fp_pin64(double v) { double d; asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(v)); return d; }
+__device__ __forceinline__ double fp_fma_sc(double q, double r, double c) {
+#if DLSA_FUSED_SCONST
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), "s"(c));
+    return d;
+#else
+    return fma(q, r, c);
+#endif
+}
 
 constexpr int FP_KC = 32;                 // rows per chunk: two k-steps per wave
 constexpr int FP_NST = 4;                 // LDS stages of the fused pass: the DMA runs three chunks ahead of the MFMAs, two ahead of the logistic terms
@@ -138,7 +177,8 @@ template <int NT, int G, int SEG, typename F>
 __device__ __forceinline__ void fp_kstep_spread(const double (&f)[NT + (G > 0 ? 1 : 0)], const double (&g)[NT],
                                                 const double (&bt)[G > 0 ? G : 1], F&& between) {
     if constexpr (SEG < NARROW_NSEG) {
-        narrow_kstep_seg<NT, G, SEG>(f, g, bt);
+        if constexpr (!(FP_ABL & 8)) narrow_kstep_seg<NT, G, SEG>(f, g, bt);
+        else asm volatile("" ::"v"(f[0]), "v"(g[NT - 1]), "v"(bt[0]));
         __builtin_amdgcn_sched_barrier(0);
         between(std::integral_constant<int, SEG>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -172,6 +212,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     static_assert(3 * MEETN >= NTRI, "the tiles meet in at most three passes");
     static_assert((size_t)3 * (NT + 1) * G * 64 <= (size_t)FP_NST * BUF, "tail meeting fits the ring");
     static_assert(NARROW_NSEG == 5 && KC == 32, "piece schedule below: two k-steps of five segments per chunk");
+    // (the logistic terms ride behind segments 1 and 3 of the first k-step and 0, 2 and 4 of the second: five VALU groups per chunk --
+    // a group costs ~11 pipe cycles whatever its size -- with the LDS reads one segment ahead of their use)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,22 +234,42 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 
     const bool col_in = 2 * lane < a.p;
     constexpr int RQ = KC / NWAVES / 4;                               // rows per wave and DMA part (two)
+    // PRIVATE (HESS): a wave stages the rows and labels of ITS OWN two k-steps (rows 4 wave .. + 3 and 16 + 4 wave .. + 3), which are
+    // also the rows whose logistic terms it evaluates -- nothing in the chunk loop crosses waves, so the loop carries no s_barrier
+    // and the four waves drift freely.  The logit-only ring keeps the round-robin rows and its barrier.
+    constexpr bool PRIV = HESS && DLSA_FUSED_PRIVATE;
     auto stage_rows = [&](int chunk, int buf, int q) {
         double* base = lds + buf * BUF;
+        // (the row pitch goes through an opaque copy: hipcc otherwise keeps row * pitch for every row of the chunk in SGPRs across the
+        // loop -- 16 registers this kernel needs for the polynomial coefficients -- instead of one s_mul per DMA; 32-bit: the slab's
+        // bytes fit, irls_pass_fused_eligible)
+        int pitch_b = (int)a.ldx * 8, wrow = PRIV ? 4 * wave : wave;       // (the wave's first row likewise: its LDS offsets per row stay out of SGPRs)
+        asm volatile("" : "+s"(pitch_b), "+s"(wrow));
 #pragma unroll
         for (int ps = q * RQ; ps < (q + 1) * RQ; ++ps) {
-            const int row = wave + NWAVES * ps;
-            const int soff = (int)(((int64_t)chunk * KC + row) * a.ldx * 8);
-            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + row * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
+            const int rrow = PRIV ? 16 * (ps >> 2) + (ps & 3) : NWAVES * ps;          // row = wrow + rrow
+            const int soff = (chunk * KC + wrow + rrow) * pitch_b;
+            if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + wrow * LDP + rrow * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
     };
-    auto stage_y = [&](int chunk, int buf) {      // every wave fetches the chunk's y: the same in-order count in all waves
-        if (lane < KC / 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_ptr_t)(lds + buf * BUF + YOFF), 16, lane * 16, chunk * KC * 8, 0, 0);
+    // the chunk's labels.  PRIVATE: this wave's eight only, into its own corner of the y slot ([wave][8]: lane L fetches the two labels
+    // 2 (L & 1) .. + 1 of k-step wave + 4 (L >> 1)).  Else every wave fetches all 32 (same bytes to the same place, the same count).
+    auto stage_y = [&](int chunk, int buf) {
+        if constexpr (PRIV) {
+            if (lane < 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_ptr_t)(lds + buf * BUF + YOFF + 8 * wave), 16,
+                                                         (4 * (wave + 4 * (lane >> 1)) + 2 * (lane & 1)) * 8, chunk * KC * 8, 0, 0);
+        } else {
+            if (lane < KC / 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_ptr_t)(lds + buf * BUF + YOFF), 16, lane * 16, chunk * KC * 8, 0, 0);
+        }
     };
 
-    // ---- the lane's share of beta and of g (columns 16 q + 2 s + {0, 1}); loglik
-    const int lj = lane >> 3, ls = lane & 7;
+    // ---- the lane's share of beta and of g (columns 16 q + 2 s + {0, 1}); loglik.
+    // Lane (j, s): row slot j = 0..7 of the wave's eight rows of a chunk, s = 0..7 the eighth of the row.  s sits on lane bits 0, 1, 3 and
+    // j on bits 2, 4, 5, so that the three butterfly steps over a row's lanes are xor 1, xor 2 (quad_perm) and xor 8 (row_ror:8): one
+    // DPP move per dword each (xor 4 would need two).
+    const int ls = (lane & 3) | ((lane >> 1) & 4), lj = ((lane >> 2) & 1) | ((lane >> 3) & 6);
     double bq[NTC][2], gacc[NTC][2];
 #pragma unroll
     for (int q = 0; q < NTC; ++q)
@@ -217,12 +279,26 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             bq[q][e] = col < a.p ? a.beta[col] : 0.0;
             gacc[q][e] = 0.0;
         }
+    // every lane of a row accumulates the row's loglik term (the eight copies are thinned out after the loop); rows past the slab's
+    // end arrive as zeros (x and y: the descriptors' bounds check), add nothing to g and exactly -softplus(0) each to loglik, which
+    // the epilogue takes out again -- no per-row validity test in the loop
     double llacc = 0.0;
     // own rows of a chunk: k-step `wave` holds rows 4 wave .. + 3 (j < 4), k-step wave + 4 rows 16 + 4 wave .. + 3 (j >= 4)
     const int own_row = (lj < 4 ? 4 * wave + lj : 16 + 4 * wave + (lj - 4));
+    const int own_slot = PRIV ? 8 * wave + lj : own_row;  // the row's place in the stage's w and y slots
     const int xoff = own_row * LDP + 2 * ls;              // + 16 q: the lane's b128 of tile column q
+    // leading coefficients of the two polynomials, pinned in VGPRs for the whole kernel (the asm keeps hipcc from re-creating them
+    // with a v_mov_b64 per evaluation)
+    const double c_exp13 = fp_pin64(1.6059043836821613e-10), c_log21 = fp_pin64(1.0 / 21.0), c_sqrt2m1 = fp_pin64(0.41421356237309503),
+                 c_ln2 = fp_pin64(6.931471805599453094e-01);
+    const int k_half = fp_pin32(0x3fe00000), k_one = fp_pin32(0x3ff00000), k_mhalf = fp_pin32((int)0xbfe00000), k_zero = fp_pin32(0),
+              k_1p5 = fp_pin32(0x3ff80000), k_two = fp_pin32(0x40000000);
 
     LogitState<NTC> L;
+    // The pieces below are the operations of logistic.h (exp_neg, logistic_terms) in the same order on the same values -- w and mu
+    // come out to the last bit as logit.hip's pass gives them -- written so that every step is ONE VALU instruction: next to fp64
+    // MFMAs each VALU instruction, a move included, costs ~4.7 cycles of the matrix pipe and each separate group of them ~11 more
+    // (bench/ubench_gap.hip), so coefficients are scalar operands (fp_fma_sc), selects pick one dword, and the pieces form few groups.
     // piece 0: the row's columns and its label out of LDS (chunk `chunk` in stage `buf`)
     auto lp_read = [&](int chunk, int buf) {
         const double* base = lds + buf * BUF;
@@ -231,86 +307,82 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             const d2 v = *(const d2*)(base + xoff + 16 * q);
             L.x[q][0] = v.x; L.x[q][1] = v.y;
         }
-        L.yv = base[YOFF + own_row];
-        L.valid = chunk * KC + own_row < nrows;
+        L.yv = base[YOFF + own_slot];
+        if constexpr (WOUT) L.valid = chunk * KC + own_row < nrows;
     };
-    auto lp_dot = [&]() {
-        double s0 = 0.0, s1 = 0.0;
+    auto lp_dot = [&]() {                         // eta over the 8 lanes of the row (every lane ends with it), then the exponent split
+        double s0 = L.x[0][0] * bq[0][0], s1 = L.x[0][1] * bq[0][1];
 #pragma unroll
-        for (int q = 0; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
-        L.eta = s0 + s1;
-    };
-    auto lp_reduce = [&]() {                      // over the 8 lanes of the row: every lane ends with the row's eta
-        double s = L.eta;
+        for (int q = 1; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
+        double s = s0 + s1;
         s += dpp_xor_f64<1>(s);
         s += dpp_xor_f64<2>(s);
-        s += dpp_xor_f64<4>(s);
+        s += dpp_xor_f64<8>(s);
         L.eta = s;
-        const double aabs = fmin(fabs(s), 745.2);
-        L.kf = rint(aabs * 1.4426950408889634);
-        double r = fma(L.kf, 6.93147180369123816490e-01, -aabs);
-        L.rr = fma(L.kf, 1.90821492927058770002e-10, r);
+        double aabs;
+        asm("v_min_f64 %0, |%1|, %2" : "=v"(aabs) : "v"(s), "s"(745.2));
+        double t;
+        asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(aabs), "s"(1.4426950408889634));
+        L.kf = rint(t);
+        double r;
+        asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "v"(L.kf), "s"(6.93147180369123816490e-01), "v"(aabs));
+        L.rr = fp_fma_sc2(L.kf, 1.90821492927058770002e-10, r);
     };
-    auto lp_exp_a = [&]() {                       // exp(-|eta|): degree-13 polynomial, first half (logistic.h: exp_neg)
+    auto lp_exp = [&]() {                         // e = exp(-|eta|): degree-13 polynomial, ldexp (logistic.h: exp_neg)
         const double r = L.rr;
-        double q = 1.6059043836821613e-10;
-        q = fma(q, r, 2.08767569878681e-09);
-        q = fma(q, r, 2.505210838544172e-08);
-        q = fma(q, r, 2.755731922398589e-07);
-        q = fma(q, r, 2.7557319223985893e-06);
-        q = fma(q, r, 2.48015873015873e-05);
-        q = fma(q, r, 1.984126984126984e-04);
-        L.q = q;
-    };
-    auto lp_exp_b = [&]() {
-        const double r = L.rr;
-        double q = L.q;
-        q = fma(q, r, 1.388888888888889e-03);
-        q = fma(q, r, 8.333333333333333e-03);
-        q = fma(q, r, 4.1666666666666664e-02);
-        q = fma(q, r, 1.6666666666666666e-01);
+        double q = c_exp13;
+        q = fp_fma_sc(q, r, 2.08767569878681e-09);
+        q = fp_fma_sc(q, r, 2.505210838544172e-08);
+        q = fp_fma_sc(q, r, 2.755731922398589e-07);
+        q = fp_fma_sc(q, r, 2.7557319223985893e-06);
+        q = fp_fma_sc(q, r, 2.48015873015873e-05);
+        q = fp_fma_sc(q, r, 1.984126984126984e-04);
+        q = fp_fma_sc(q, r, 1.388888888888889e-03);
+        q = fp_fma_sc(q, r, 8.333333333333333e-03);
+        q = fp_fma_sc(q, r, 4.1666666666666664e-02);
+        q = fp_fma_sc(q, r, 1.6666666666666666e-01);
         q = fma(q, r, 0.5);
         q = fma(q, r, 1.0);
         q = fma(q, r, 1.0);
-        L.e = ldexp(q, -(int)L.kf);
+        int kneg;
+        asm("v_cvt_i32_f64 %0, -%1" : "=v"(kneg) : "v"(L.kf));
+        L.e = ldexp(q, kneg);
     };
     auto lp_mu = [&](int buf) {                   // mu, w -> the stage's w slot (read back by this wave's MFMA part next chunk)
         const double inv = rcp_newton(1.0 + L.e);
-        L.mu = L.eta >= 0.0 ? inv : L.e * inv;
-        L.wgt = L.e * inv * inv;
+        const double einv = L.e * inv;
+        L.mu = L.eta >= 0.0 ? inv : einv;
+        L.wgt = einv * inv;
         L.resid = L.yv - L.mu;
-        if (HESS && ls == 0) lds[buf * BUF + WOFF + own_row] = L.wgt;
+        if (HESS && ls == 0) lds[buf * BUF + WOFF + own_slot] = L.wgt;
     };
-    auto lp_log_a = [&]() {                       // log1p(e), logistic.h: logistic_terms
-        L.big = L.e > 0.41421356237309503;
-        L.num = L.big ? fma(0.5, L.e, -0.5) : L.e;
-        L.den = L.big ? fma(0.5, L.e, 1.5) : 2.0 + L.e;
-        L.sv = L.num * rcp_newton(L.den);
-    };
-    auto lp_log_b = [&]() {
-        const double z = L.sv * L.sv;
-        double q = 1.0 / 21.0;
-        q = fma(q, z, 1.0 / 19.0);
-        q = fma(q, z, 1.0 / 17.0);
-        q = fma(q, z, 1.0 / 15.0);
-        q = fma(q, z, 1.0 / 13.0);
-        q = fma(q, z, 1.0 / 11.0);
-        L.q = q; L.num = z;
-    };
-    auto lp_log_c = [&](int chunk) {
-        const double z = L.num;
-        double q = L.q;
-        q = fma(q, z, 1.0 / 9.0);
-        q = fma(q, z, 1.0 / 7.0);
-        q = fma(q, z, 1.0 / 5.0);
-        q = fma(q, z, 1.0 / 3.0);
+    auto lp_log = [&](int chunk) {                // log1p(e) and the row's loglik term (logistic.h: logistic_terms)
+        // t' = h (1 + e) with h = 1/2 above sqrt 2: num = t' - 1 = h e + (h - 1), den = t' + 1 = h e + (h + 1) -- the same values as
+        // logistic.h's selects between fma(0.5, e, -0.5) / e and fma(0.5, e, 1.5) / 2 + e, from three one-dword selects
+        const bool big = L.e > c_sqrt2m1;
+        const double h = __hiloint2double(big ? k_half : k_one, 0);
+        const double hm1 = __hiloint2double(big ? k_mhalf : k_zero, 0);
+        const double hp1 = __hiloint2double(big ? k_1p5 : k_two, 0);
+        const double num = fma(h, L.e, hm1), den = fma(h, L.e, hp1);
+        const double sv = num * rcp_newton(den);
+        const double z = sv * sv;
+        double q = c_log21;
+        q = fp_fma_sc(q, z, 1.0 / 19.0);
+        q = fp_fma_sc(q, z, 1.0 / 17.0);
+        q = fp_fma_sc(q, z, 1.0 / 15.0);
+        q = fp_fma_sc(q, z, 1.0 / 13.0);
+        q = fp_fma_sc(q, z, 1.0 / 11.0);
+        q = fp_fma_sc(q, z, 1.0 / 9.0);
+        q = fp_fma_sc(q, z, 1.0 / 7.0);
+        q = fp_fma_sc(q, z, 1.0 / 5.0);
+        q = fp_fma_sc(q, z, 1.0 / 3.0);
         q = fma(q, z, 1.0);
-        const double l1p = fma(2.0 * L.sv, q, L.big ? 6.931471805599453094e-01 : 0.0);
-        const double softplus = fmax(L.eta, 0.0) + l1p;
-        // one lane per row counts; rows past the slab's end (zero-filled by the DMA's bounds check) do not
-        if (ls == 0 && L.valid) llacc += fma(L.yv, L.eta, -softplus);
-        if (!L.valid) L.resid = 0.0;
-        if (WOUT) {
+        const double l1p = fma(sv + sv, q, big ? c_ln2 : 0.0);
+        double pos;
+        asm("v_max_f64 %0, %1, 0" : "=v"(pos) : "v"(L.eta));              // (fmax() puts a canonicalising v_max in front)
+        const double softplus = pos + l1p;
+        llacc += fma(L.yv, L.eta, -softplus);
+        if constexpr (WOUT) {
             if (ls == 0 && L.valid) a.w_out[rbeg + (int64_t)chunk * KC + own_row] = L.wgt;
         }
     };
@@ -321,8 +393,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             gacc[q][1] = fma(L.resid, L.x[q][1], gacc[q][1]);
         }
     };
-    auto logit_all = [&](int chunk, int buf) {    // the whole of it in one go (prologue: chunk 0)
-        lp_read(chunk, buf); lp_dot(); lp_reduce(); lp_exp_a(); lp_exp_b(); lp_mu(buf); lp_log_a(); lp_log_b(); lp_log_c(chunk); lp_grad();
+    auto logit_all = [&](int chunk, int buf) {    // the whole of it in one go (prologue: chunk 0; the logit-only ring)
+        lp_read(chunk, buf); lp_dot(); lp_exp(); lp_mu(buf); lp_log(chunk); lp_grad();
     };
 
     if constexpr (HESS) narrow_acc_zero<fp_nreg(NT, G)>();
@@ -336,7 +408,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         stage_y(ch, ch);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * DMA_PER_CHUNK) : "memory");
-    asm volatile("s_barrier" ::: "memory");
+    if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");
     logit_all(0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!HESS) asm volatile("s_barrier" ::: "memory");       // the loop's first DMA overwrites chunk 0, which every wave must have left
@@ -372,7 +444,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             for (int t = 0; t < NTC; ++t) fr.f[kk][t] = kb[frag_off + t * 16];
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) fr.bt[kk][gi] = kb[tail_off + 4 * gi];
-            fr.wv[kk] = base[WOFF + ks * 4 + (lane >> 4)];
+            fr.wv[kk] = base[WOFF + (PRIV ? 8 * wave + 4 * kk : ks * 4) + (lane >> 4)];
         }
     };
     auto iteration = [&](int c, const Frags& fr, Frags& fnext) {
@@ -389,28 +461,29 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
                 // whose stage it overwrites) and the first half of the logistic terms of chunk c + 1
                 fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
                     constexpr int q = decltype(qc)::value;
-                    if constexpr (q < 4) stage_rows(c + 3, nxt3, q); else stage_y(c + 3, nxt3);
-                    if constexpr (q == 0) lp_read(c + 1, nxt);
+                    if constexpr (!(FP_ABL & 4)) { if constexpr (q < 4) stage_rows(c + 3, nxt3, q); else stage_y(c + 3, nxt3); }
+                    if constexpr (FP_ABL & 2) return;
+                    if constexpr (q == 0) lp_read(c + 1, nxt);        // (LDS reads only: their latency passes under segment 1)
                     else if constexpr (q == 1) lp_dot();
-                    else if constexpr (q == 2) lp_reduce();
-                    else if constexpr (q == 3) lp_exp_a();
-                    else lp_exp_b();
+                    else if constexpr (q == 3) lp_exp();
                 });
             } else {
                 fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
                     constexpr int q = decltype(qc)::value;
+                    // the NEXT chunk's fragments and the weights lp_mu has just stored for it are requested here, three segments before
+                    // the iteration ends: without a barrier to wait at, a request at the very end would be waited for with the pipe idle
+                    if constexpr (q == 1 && DLSA_FUSED_EARLY_FRAGS) load_frags(nxt, fnext);
+                    if constexpr (FP_ABL & 2) return;
                     if constexpr (q == 0) lp_mu(nxt);
-                    else if constexpr (q == 1) lp_log_a();
-                    else if constexpr (q == 2) lp_log_b();
-                    else if constexpr (q == 3) lp_log_c(c + 1);
-                    else lp_grad();
+                    else if constexpr (q == 2) { if constexpr (!(FP_ABL & 1)) lp_log(c + 1); }
+                    else if constexpr (q == 4) lp_grad();
                 });
             }
         }
-        load_frags(nxt, fnext);
+        if constexpr (!DLSA_FUSED_EARLY_FRAGS) load_frags(nxt, fnext);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 2 has landed (c + 3 is in flight)
-        asm volatile("s_barrier" ::: "memory");
+        if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");
         cur = nxt;
     };
     if constexpr (HESS) {
@@ -435,26 +508,34 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         fp_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
     }
 
-    // ---- g and loglik: over the 8 rows of a wave (lanes with the same s: xor 8, 16, 32), then over the four waves in LDS
+    // ---- g and loglik: over the 8 rows of a wave (lanes with the same s: the row bits are lane bits 2, 4, 5), then over the four waves in LDS
 #pragma unroll
     for (int q = 0; q < NTC; ++q)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             double s = gacc[q][e], u, v;
-            s += dpp_xor_f64<8>(s);
+            s += dpp_xor_f64<4>(s);
             swap_f64<16>(s, s, u, v); s = u + v;
             swap_f64<32>(s, s, u, v); s = u + v;
             gacc[q][e] = s;
         }
+    // loglik: one lane per row counts.  The zero rows evaluated past the slab's end -- chunks 0 .. nch_eval - 1 were evaluated -- each
+    // added fma(0, 0, -softplus(0)) = -ln 2: taken out again (to the rounding of that one product).
+    {
+        const int nch_eval = (HESS ? ((nchunks + 1) & ~1) : nchunks) + 1;
+        const int first_bad = nrows > own_row ? (nrows - own_row + KC - 1) / KC : 0;      // first chunk whose row `own_row` lies past the end
+        const int nbad = nch_eval > first_bad ? nch_eval - first_bad : 0;
+        llacc = ls == 0 ? fma((double)nbad, 6.931471805599453094e-01, llacc) : 0.0;
+    }
     llacc = wave_allreduce_sum(llacc);
     constexpr int GP = fp_gp(NTC);
-    if (lane < 8) {
+    if (lj == 0) {                                // the eight lanes of row slot 0 hold the wave's sums for their s
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
-            lds[wave * GP + 16 * q + 2 * lane] = gacc[q][0];
-            lds[wave * GP + 16 * q + 2 * lane + 1] = gacc[q][1];
+            lds[wave * GP + 16 * q + 2 * ls] = gacc[q][0];
+            lds[wave * GP + 16 * q + 2 * ls + 1] = gacc[q][1];
         }
-        if (lane == 0) lds[wave * GP + 16 * NTC] = llacc;
+        if (ls == 0) lds[wave * GP + 16 * NTC] = llacc;
     }
     __syncthreads();
     if (tid <= 16 * NTC)

@@ -24,11 +24,18 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 namespace dlsa {
 
 [[maybe_unused]] constexpr int LARS_SLACK = 256;                // zeroed elements after each factor matrix: the last rows' trips run into them
 constexpr int LARS_MAX_WGS = 32;               // workgroups of the grid kernel (the barrier costs ~35 ns per workgroup beyond 16)
+#ifndef DLSA_LARS_SECONDARY
+std::mutex g_lars_grid_mu;                                     // serialises this process's grid-kernel launches (dlsa_lars_lsa_f64)
+std::atomic<long long> g_lars_barrier_timeout_ticks{200000000ll};   // 2 s of the 100 MHz wall clock
+std::atomic<int> g_lars_grid_aborts{0};
+#endif
 
 struct LarsArgs {
     const double* Sigma0;   // p x p
@@ -49,7 +56,8 @@ struct LarsArgs {
     double* rbuf;     // m: r = R^{-T} x of the current append, gathered from the row owners
     double* wbuf;     // m: equiangular weights, gathered from the row owners
     double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
-    unsigned* bar;    // grid barrier counter (zero at launch)
+    unsigned* bar;    // grid barrier: [0] arrival counter, [1] abort word (both zero at launch)
+    long long bar_timeout;   // ticks of the 100 MHz wall clock a workgroup waits at a grid barrier before it aborts the launch
 };
 
 // The kernels are compiled TWICE (Makefile: lars.hip and lars_t512 from the same source): workgroups of 1024 threads for wide
@@ -537,15 +545,41 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_kernel(LarsArgs a) {
 // XCDs): confining them to one XCD makes the exchanged vectors L2 hits but was measured slower overall
 // (p=1000, 16 workgroups: 29.9 vs 22.2 ms) -- eight L2s hold more of Sigma and R^{-1} than one.
 
-__device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned nwg, unsigned& phase) {
-    __syncthreads();                 // this workgroup's global stores have reached L2 (vmcnt(0) before the barrier)
+// bar[0] counts arrivals, bar[1] is the ABORT word.  The barrier is hand-rolled and the launch is a plain one (lars_run), so nothing
+// guarantees that all G workgroups are resident together: with other kernels holding CUs (more concurrent grid-LARS calls than the
+// chip has room for, a CU-masked or shared device) a resident workgroup could wait for one that is queued behind it.  Every wait
+// is therefore BOUNDED: a workgroup that has waited `timeout` ticks of the 100 MHz wall clock sets bar[1] and leaves; every
+// workgroup that sees bar[1] leaves (a late starter at its first barrier); the kernel reports n_steps = -1 and the host reruns the
+// path on the single-workgroup kernel (dlsa_lars_lsa_f64).  Polling is a relaxed agent-scope load + s_sleep with ONE acquire
+// after the match (an acquire per poll invalidates the CU's L1 every iteration: 2-3x slower per hop, guide G16).
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned nwg, unsigned& phase, long long timeout) {
+    __shared__ int gb_ok;
+    __syncthreads();                 // this workgroup's global stores have been issued by every wave
     if (threadIdx.x == 0) {
         ++phase;
         const unsigned target = phase * nwg;
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the write-back has completed before the arrival is visible)
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                if (wall_clock64() - t0 > timeout) {
+                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        gb_ok = ok ? 1 : 0;
     }
     __syncthreads();
+    return gb_ok != 0;
 }
 
 // y_i over the stored part of row i for the rows i = first, first + stride, ... < n this workgroup owns: one wave per
@@ -577,6 +611,7 @@ struct LarsGridState {
     double* __restrict__ RinvT;
     double* rbuf;
     unsigned* bar;
+    long long bar_timeout;
     int ld, g, G;
     // LDS, replicated in every workgroup
     int* act; float* sgn; double* t; double* xu; double* rw;
@@ -585,12 +620,13 @@ struct LarsGridState {
 };
 
 // Append variable `inew` with sign `sg` at position na.  All workgroups call it with the same arguments and get the
-// same answer; `dirty` says that column writes of an earlier append have not been followed by a grid barrier yet.
+// same answer (1 = appended, 0 = rank did not grow, -1 = the launch was aborted at a grid barrier); `dirty` says that column writes
+// of an earlier append have not been followed by a grid barrier yet.
 __device__ int append_column_grid(const LarsGridState& f, int na, int inew, double sg, double eps, double& tsq,
                                   unsigned& phase, bool& dirty) {
     const int tid = threadIdx.x;
     LARS_TICK(0);
-    if (dirty) { grid_barrier(f.bar, f.G, phase); dirty = false; }
+    if (dirty) { if (!grid_barrier(f.bar, f.G, phase, f.bar_timeout)) return -1; dirty = false; }
     const double* __restrict__ srow = f.S + (int64_t)inew * f.ld;
     for (int i = tid; i < na; i += LARS_THREADS) f.xu[i] = srow[f.act[i]];
     __syncthreads();
@@ -598,7 +634,7 @@ __device__ int append_column_grid(const LarsGridState& f, int na, int inew, doub
     double* __restrict__ rbuf = f.rbuf;
     tri_matvec_rows<true>(f.RinvT, f.ld, na, f.xu, f.g, f.G, [&](int i, double s) { rbuf[i] = s; });
     LARS_TICK(2);
-    grid_barrier(f.bar, f.G, phase);
+    if (!grid_barrier(f.bar, f.G, phase, f.bar_timeout)) return -1;      // aborted launch (see grid_barrier)
     LARS_TICK(3);
     double acc[2] = {0.0, 0.0};
     for (int i = tid; i < na; i += LARS_THREADS) {
@@ -640,6 +676,9 @@ __device__ int append_column_grid(const LarsGridState& f, int na, int inew, doub
     return 1;
 }
 
+// an aborted launch (grid_barrier timed out somewhere in the grid): every workgroup reports -1 steps and leaves
+#define LARS_GRID_ABORT() do { if (threadIdx.x == 0) *a.n_steps = -1; return; } while (0)
+#define LARS_GRID_SYNC() do { if (!grid_barrier(a.bar, G, phase, a.bar_timeout)) LARS_GRID_ABORT(); } while (0)
 __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
     __shared__ double red[4 * LARS_WAVES];
     __shared__ int sh_i[4];
@@ -676,7 +715,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
     unsigned phase = 0;
     bool dirty = false;
     LARS_PROF_DECL;
-    const LarsGridState fac{S, a.Rinv, a.RinvT, a.rbuf, a.bar, ld, g, G, act, sgn, tv, xu, rw, gi1, red};
+    const LarsGridState fac{S, a.Rinv, a.RinvT, a.rbuf, a.bar, a.bar_timeout, ld, g, G, act, sgn, tv, xu, rw, gi1, red};
 
     // ---- prologue: intercept Schur complement (lsa.py:98-104) and rescaling (lsa.py:108-109).
     // |b0|, a12 and sign(b0) are staged in LDS (rw, tv, beta) for the build of S; workgroup 0 keeps global copies.
@@ -711,7 +750,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
     __syncthreads();
     // Cvec = b' Sigma (lsa.py:114) from the rows each workgroup just wrote
     sym_matvec(S, ld, m, nown, own_w, own_act, upart, sh_part, JT2, GS);
-    grid_barrier(a.bar, G, phase);
+    LARS_GRID_SYNC();
     for (int j = tid; j < m; j += LARS_THREADS) {
         double s = 0.0;
         for (int q = 0; q < G; ++q) s += a.upart[(int64_t)q * ld + j];
@@ -760,6 +799,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
                 if (inew >= m) break;
                 const double c = Cvec[inew];
                 const int grew = append_column_grid(fac, na, inew, (c > 0.0) ? 1.0 : ((c < 0.0) ? -1.0 : 0.0), eps, tsq, phase, dirty);
+                if (grew < 0) LARS_GRID_ABORT();
                 if (tid == 0) {
                     state[inew] = grew ? 1 : 2;      // 2: machine-singular, ignored (lsa.py:139-144)
                     sh_i[0] = m; sh_i[2] = 0;
@@ -786,7 +826,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
         // ---- partial u = Sigma[own active rows, :]' w_own
         sym_matvec(S, ld, m, nown, own_w, own_act, upart, sh_part, JT2, GS);
         LARS_TICK(6);
-        grid_barrier(a.bar, G, phase);
+        LARS_GRID_SYNC();
         LARS_TICK(7);
         dirty = false;
         for (int i = tid; i < na; i += LARS_THREADS) rw[i] = a.wbuf[i];
@@ -855,7 +895,8 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
             tsq = block_sum(part, red);
             tri_matvec_rows<false>(a.Rinv, ld, first, tv, g, G, [&](int i, double sum) { gi1[i] = sum; });
             __syncthreads();
-            for (int i = first; i < keep; ++i) append_column_grid(fac, i, act[i], (double)sgn[i], 0.0, tsq, phase, dirty);
+            for (int i = first; i < keep; ++i)
+                if (append_column_grid(fac, i, act[i], (double)sgn[i], 0.0, tsq, phase, dirty) < 0) LARS_GRID_ABORT();
             na = keep;
         }
         LARS_TICK(9);
@@ -905,9 +946,10 @@ static int lars_workgroups(int p) {
 
 
 // launch of this build's kernels (the C ABI entry below picks the build by p)
-int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
+int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used) {
     const size_t mm = (size_t)(p - (intercept ? 1 : 0));
-    int wgs = lars_workgroups(p);
+    int wgs = std::min(lars_workgroups(p), std::max(1, max_wgs));
+    if (wgs > kNumCU) wgs = 1;                   // (the spinning barrier needs a CU per workgroup)
     // the grid kernel replicates more vectors in LDS; beyond its limit (m ~ 2440) the single-workgroup kernel still fits
     if (wgs > 1 && (size_t)LARS_THREADS * 16 + mm * 60 + (mm / wgs + 2) * 12 + 64 > (size_t)kLdsBytes) wgs = 1;
     if (wgs > 1) {
@@ -916,11 +958,13 @@ int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
             DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_grid_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
-        // A PLAIN launch: at most 32 workgroups on 256 CUs are resident together as soon as the CUs they need are free (whatever
-        // else runs terminates without waiting for this kernel), which is all the spinning grid barrier needs.
-        // hipLaunchCooperativeKernel would guarantee it, but (measured) every HIP stream CREATED after a process's first cooperative
-        // launch is serialised with the others -- the partition chains of a later fit (irls.hip) then lose their overlap
-        // (config 4 structured: 14.4 -> 22.2 ms) -- and the cooperative launch costs 15-19 us of host time per call.
+        // A PLAIN launch: at most 32 workgroups on 256 CUs are resident together as soon as the CUs they need are free (kernels of
+        // other streams end without waiting for this one).  hipLaunchCooperativeKernel would check co-residency at launch, but
+        // (measured) every HIP stream CREATED after a process's first cooperative launch is serialised with the others -- the
+        // partition chains of a later fit (irls.hip) then lose their overlap (config 4 structured: 14.4 -> 22.2 ms) -- and it
+        // costs 15-19 us of host time per call.  What the plain launch cannot promise -- several grid kernels each partly
+        // resident and waiting for their queued workgroups -- is covered twice: grid launches of one process are serialised
+        // (g_lars_grid_mu in dlsa_lars_lsa_f64) and every barrier wait is bounded (grid_barrier: abort + single-workgroup rerun).
         hipLaunchKernelGGL(lars_grid_kernel, dim3(wgs), dim3(LARS_THREADS), shm, s, a);
         DLSA_HIP_CHECK(hipGetLastError());
     } else {
@@ -931,12 +975,13 @@ int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
         hipLaunchKernelGGL(lars_kernel, dim3(1), dim3(LARS_THREADS), shm, s, a);
         DLSA_HIP_CHECK(hipGetLastError());
     }
+    if (wgs_used) *wgs_used = wgs;
     return DLSA_OK;
 }
 
 }  // namespace LARS_NS
-namespace lars_t512 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s); }
-namespace lars_t1024 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s); }
+namespace lars_t512 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used); }
+namespace lars_t1024 { int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used); }
 
 }  // namespace dlsa
 
@@ -979,19 +1024,45 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.upart = (double*)ar.take((size_t)LARS_MAX_WGS * ld * 8);
     a.bar = (unsigned*)ar.take(256);
     a.beta_path = beta_path; a.beta0 = beta0; a.aic = aic; a.bic = bic;
-    // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
-    DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
-    DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
     // 512-thread workgroups up to p = 768, 1024-thread ones beyond (DLSA_LARS_THREADS=512|1024 forces a build)
     bool small_wg = p <= 768;
     if (const char* e = getenv("DLSA_LARS_THREADS")) small_wg = atoi(e) == 512;
-    const int rc = small_wg ? lars_t512::lars_run(a, p, intercept, s) : lars_t1024::lars_run(a, p, intercept, s);
-    if (rc) return rc;
-    int steps = 0;
-    DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
-    DLSA_HIP_CHECK(hipStreamSynchronize(s));
+    // ticks of the 100 MHz wall clock a workgroup of the grid kernel waits at one grid barrier (normally microseconds) before it
+    // gives the launch up: 2 s
+    a.bar_timeout = g_lars_barrier_timeout_ticks.load();
+    int steps = 0, wgs_used = 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
+        DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
+        DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));
+        // grid launches of this process run one at a time (launch .. completion): two of them could each hold part of the CUs the
+        // other's queued workgroups need.  Other processes on the same GPU are covered by the barrier's timeout alone.
+        std::unique_lock<std::mutex> grid_lock(g_lars_grid_mu, std::defer_lock);
+        const int max_wgs = attempt == 0 ? LARS_MAX_WGS : 1;
+        if (max_wgs > 1 && p >= 256) grid_lock.lock();
+        const int rc = small_wg ? lars_t512::lars_run(a, p, intercept, s, max_wgs, &wgs_used) : lars_t1024::lars_run(a, p, intercept, s, max_wgs, &wgs_used);
+        if (rc) return rc;
+        DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        if (steps >= 0) break;
+        // the grid kernel gave up at a barrier (its workgroups were not all resident within the timeout): the single-workgroup
+        // kernel needs no co-residency -- same path, slower
+        g_lars_grid_aborts.fetch_add(1);
+        if (attempt == 1 || wgs_used == 1) {
+            set_error("lars_lsa: the path kernel aborted (grid barrier timeout with %d workgroups)", wgs_used);
+            return DLSA_ERR_HIP;
+        }
+    }
     if (n_steps_host) *n_steps_host = steps;
     return DLSA_OK;
+}
+
+// Test / diagnostics hook for the bounded grid barrier of lars_grid_kernel (not a reference entry: the reference's lars_lsa,
+// dlsa/lsa.py:90-212, is host numpy and has no such state): sets the barrier timeout in seconds (<= 0 restores the 2 s default)
+// and returns how many grid launches of this process have aborted and been rerun on the single-workgroup kernel.
+int dlsa_lars_grid_barrier_timeout(double seconds) {
+    dlsa::g_lars_barrier_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 200000000ll);
+    return dlsa::g_lars_grid_aborts.load();
 }
 
 }  // extern "C"
