@@ -59,8 +59,10 @@ size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 // VALU instruction, a move included, costs ~4.7 cycles of the matrix pipe while SALU instructions cost nothing
 // (bench/ubench_gap.hip, profiles/r04_ubench_gap.txt).  The asm form is one VALU slot: v_fma_f64 with the coefficient in the one
 // scalar operand a VOP3 instruction may have (the s_mov_b32 pair that fills it is SALU).  Same arithmetic, same bits.
+template <bool SC = true>
 __device__ __forceinline__ double fp_fma_sc2(double a, double c, double b) {      // a * C + b
 #if DLSA_FUSED_SCONST
+    if constexpr (!SC) return fma(a, c, b);
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(c), "v"(b));
     return d;
@@ -69,10 +71,13 @@ __device__ __forceinline__ double fp_fma_sc2(double a, double c, double b) {    
 #endif
 }
 // a 32-bit / 64-bit constant pinned in VGPRs (opaque to hipcc: it cannot re-create it with a v_mov inside the loop)
-__device__ __forceinline__ int fp_pin32(int v) { int d; asm("v_mov_b32 %0, %1" : "=v"(d) : "s"(v)); return d; }
-__device__ __forceinline__ double fp_pin64(double v) { double d; asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(v)); return d; }
+// (PIN = false: the plain constant -- the widest shape, 7 tiles + 2 tail groups with w_out, has no 14 registers to spare)
+template <bool PIN> __device__ __forceinline__ int fp_pin32(int v) { if constexpr (!PIN) return v; int d; asm("v_mov_b32 %0, %1" : "=v"(d) : "s"(v)); return d; }
+template <bool PIN> __device__ __forceinline__ double fp_pin64(double v) { if constexpr (!PIN) return v; double d; asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(v)); return d; }
+template <bool SC = true>
 __device__ __forceinline__ double fp_fma_sc(double q, double r, double c) {
 #if DLSA_FUSED_SCONST
+    if constexpr (!SC) return fma(q, r, c);
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), "s"(c));
     return d;
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     constexpr int LDP = fp_pitch(NTC), BUF = fp_buf(NTC), NTRI = NT * (NT + 1) / 2;
     constexpr int GA = G > 0 ? G : 1;
     constexpr int WOFF = KC * LDP, YOFF = KC * LDP + KC;               // the stage's w and y slots
+    constexpr bool PIN = fp_nreg(NT, G) <= 224;                        // registers to spare (all shapes but 7 tiles + 1 or 2 tail groups, 240 / 256 accumulators): pinned constants, scalar coefficients, early fragment loads
     constexpr int DMA_PER_CHUNK = KC / NWAVES + 1;                    // 8 row pieces + the y piece, per wave
     constexpr int MEETN_FIT = (int)((size_t)FP_NST * BUF * 8 / (3 * 2048));
     constexpr int MEETN = MEETN_FIT < NTRI ? MEETN_FIT : NTRI;
@@ -289,10 +295,10 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     const int xoff = own_row * LDP + 2 * ls;              // + 16 q: the lane's b128 of tile column q
     // leading coefficients of the two polynomials, pinned in VGPRs for the whole kernel (the asm keeps hipcc from re-creating them
     // with a v_mov_b64 per evaluation)
-    const double c_exp13 = fp_pin64(1.6059043836821613e-10), c_log21 = fp_pin64(1.0 / 21.0), c_sqrt2m1 = fp_pin64(0.41421356237309503),
-                 c_ln2 = fp_pin64(6.931471805599453094e-01);
-    const int k_half = fp_pin32(0x3fe00000), k_one = fp_pin32(0x3ff00000), k_mhalf = fp_pin32((int)0xbfe00000), k_zero = fp_pin32(0),
-              k_1p5 = fp_pin32(0x3ff80000), k_two = fp_pin32(0x40000000);
+    const double c_exp13 = fp_pin64<PIN>(1.6059043836821613e-10), c_log21 = fp_pin64<PIN>(1.0 / 21.0), c_sqrt2m1 = fp_pin64<PIN>(0.41421356237309503),
+                 c_ln2 = fp_pin64<PIN>(6.931471805599453094e-01);
+    const int k_half = fp_pin32<PIN>(0x3fe00000), k_one = fp_pin32<PIN>(0x3ff00000), k_mhalf = fp_pin32<PIN>((int)0xbfe00000), k_zero = fp_pin32<PIN>(0),
+              k_1p5 = fp_pin32<PIN>(0x3ff80000), k_two = fp_pin32<PIN>(0x40000000);
 
     LogitState<NTC> L;
     // The pieces below are the operations of logistic.h (exp_neg, logistic_terms) in the same order on the same values -- w and mu
@@ -331,16 +337,16 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     auto lp_exp = [&]() {                         // e = exp(-|eta|): degree-13 polynomial, ldexp (logistic.h: exp_neg)
         const double r = L.rr;
         double q = c_exp13;
-        q = fp_fma_sc(q, r, 2.08767569878681e-09);
-        q = fp_fma_sc(q, r, 2.505210838544172e-08);
-        q = fp_fma_sc(q, r, 2.755731922398589e-07);
-        q = fp_fma_sc(q, r, 2.7557319223985893e-06);
-        q = fp_fma_sc(q, r, 2.48015873015873e-05);
-        q = fp_fma_sc(q, r, 1.984126984126984e-04);
-        q = fp_fma_sc(q, r, 1.388888888888889e-03);
-        q = fp_fma_sc(q, r, 8.333333333333333e-03);
-        q = fp_fma_sc(q, r, 4.1666666666666664e-02);
-        q = fp_fma_sc(q, r, 1.6666666666666666e-01);
+        q = fp_fma_sc<PIN>(q, r, 2.08767569878681e-09);
+        q = fp_fma_sc<PIN>(q, r, 2.505210838544172e-08);
+        q = fp_fma_sc<PIN>(q, r, 2.755731922398589e-07);
+        q = fp_fma_sc<PIN>(q, r, 2.7557319223985893e-06);
+        q = fp_fma_sc<PIN>(q, r, 2.48015873015873e-05);
+        q = fp_fma_sc<PIN>(q, r, 1.984126984126984e-04);
+        q = fp_fma_sc<PIN>(q, r, 1.388888888888889e-03);
+        q = fp_fma_sc<PIN>(q, r, 8.333333333333333e-03);
+        q = fp_fma_sc<PIN>(q, r, 4.1666666666666664e-02);
+        q = fp_fma_sc<PIN>(q, r, 1.6666666666666666e-01);
         q = fma(q, r, 0.5);
         q = fma(q, r, 1.0);
         q = fma(q, r, 1.0);
@@ -367,15 +373,15 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         const double sv = num * rcp_newton(den);
         const double z = sv * sv;
         double q = c_log21;
-        q = fp_fma_sc(q, z, 1.0 / 19.0);
-        q = fp_fma_sc(q, z, 1.0 / 17.0);
-        q = fp_fma_sc(q, z, 1.0 / 15.0);
-        q = fp_fma_sc(q, z, 1.0 / 13.0);
-        q = fp_fma_sc(q, z, 1.0 / 11.0);
-        q = fp_fma_sc(q, z, 1.0 / 9.0);
-        q = fp_fma_sc(q, z, 1.0 / 7.0);
-        q = fp_fma_sc(q, z, 1.0 / 5.0);
-        q = fp_fma_sc(q, z, 1.0 / 3.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 19.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 17.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 15.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 13.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 11.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 9.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 7.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 5.0);
+        q = fp_fma_sc<PIN>(q, z, 1.0 / 3.0);
         q = fma(q, z, 1.0);
         const double l1p = fma(sv + sv, q, big ? c_ln2 : 0.0);
         double pos;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
                     constexpr int q = decltype(qc)::value;
                     // the NEXT chunk's fragments and the weights lp_mu has just stored for it are requested here, three segments before
                     // the iteration ends: without a barrier to wait at, a request at the very end would be waited for with the pipe idle
-                    if constexpr (q == 1 && DLSA_FUSED_EARLY_FRAGS) load_frags(nxt, fnext);
+                    if constexpr (q == 1 && DLSA_FUSED_EARLY_FRAGS && PIN) load_frags(nxt, fnext);
                     if constexpr (FP_ABL & 2) return;
                     if constexpr (q == 0) lp_mu(nxt);
                     else if constexpr (q == 2) { if constexpr (!(FP_ABL & 1)) lp_log(c + 1); }
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
                 });
             }
         }
-        if constexpr (!DLSA_FUSED_EARLY_FRAGS) load_frags(nxt, fnext);
+        if constexpr (!(DLSA_FUSED_EARLY_FRAGS && PIN)) load_frags(nxt, fnext);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");      // chunk c + 2 has landed (c + 3 is in flight)
         if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");

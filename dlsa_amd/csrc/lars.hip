@@ -566,7 +566,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned nwg, unsign
         unsigned spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0u) {
+            if ((spins++ & 255u) == 0u) {        // (checked at the first failed poll too: a timeout of one tick aborts at once -- the tests' way in)
                 if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
                 if (wall_clock64() - t0 > timeout) {
                     __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -213,14 +213,23 @@ int dlsa_sym_pinv_solve_f64(const double* S, int64_t lds, const double* v, int p
  * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
  * aic, bic (max_steps+1 each); n_steps_host = number of steps taken (path has n_steps+1
  * rows).  Runs as one persistent kernel on the device: a single workgroup for p < 256, a
- * cooperative launch of 4..32 workgroups (two grid barriers per step) above; the device must
- * be able to hold them at once (any gfx950 can).  p is bounded by the LDS per workgroup:
- * about 2400 columns for the grid kernel, 3300 for the single workgroup it falls back to. */
+ * grid of 4..32 workgroups (two grid barriers per step) above.  The grid kernel is a PLAIN
+ * launch whose hand-rolled barrier needs its workgroups resident together: its launches are
+ * serialised inside a process, every barrier wait is bounded (2 s), and a launch that gives
+ * up (CUs held by other work: another process on the GPU, a CU-masked device) is rerun on
+ * the single-workgroup kernel -- slower, same path; DLSA_ERR_HIP only if that is impossible.
+ * p is bounded by the LDS per workgroup: about 2400 columns for the grid kernel, 3300 for
+ * the single workgroup it falls back to. */
 size_t dlsa_lars_workspace_bytes(int p);
 int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p,
                       int intercept, double n, int type, double eps, int max_steps,
                       double* beta_path, double* beta0, double* aic, double* bic,
                       int* n_steps_host, void* ws, size_t ws_bytes, void* stream);
+
+/* Diagnostics / test hook of the grid kernel's bounded barrier (no reference counterpart: lars_lsa, dlsa/lsa.py:90-212,
+ * is host numpy): sets the per-barrier timeout in seconds (<= 0 restores the 2 s default) and returns how many grid
+ * launches of this process have been given up and rerun on the single-workgroup kernel so far. */
+int dlsa_lars_grid_barrier_timeout(double seconds);
 
 /* ---- design matrix (N2) ----
  * Replaces pd.get_dummies + drop(baselines) + standardise + reindex (dlsa/models.py:56-104) and the

@@ -442,6 +442,28 @@ def test_lars_lasso_drops_wide_matches_oracle(eng, orc, p, rho, seed, intercept)
     assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
 
 
+def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc):
+    """The grid kernel's hand-rolled barrier is bounded: a workgroup that waits longer than the timeout aborts the
+    launch, every workgroup leaves, and the host reruns the path on the single-workgroup kernel.  With a timeout of one tick every
+    wait is 'too long', so the rerun is what produces the result here -- same path as the oracle's; nothing hangs."""
+    from dlsa_amd import _lib
+    lib = _lib.load()
+    S, b, n = _correlated_lsa_problem(300, 0.9, 3)
+    ro = orc.lars_lsa(S, b, False, n, type="lasso")
+    before = lib.dlsa_lars_grid_barrier_timeout(1e-9)
+    try:
+        r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
+        after = lib.dlsa_lars_grid_barrier_timeout(0.0)
+    finally:
+        lib.dlsa_lars_grid_barrier_timeout(0.0)
+    assert after > before                                          # the grid launch was given up and rerun
+    assert r["beta"].shape == ro["beta"].shape
+    assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
+    r2 = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")      # default timeout again: the grid kernel completes
+    assert lib.dlsa_lars_grid_barrier_timeout(0.0) == after
+    assert rel_inf(r2["beta"].cpu().numpy(), r["beta"].cpu().numpy()) < 1e-7
+
+
 @pytest.mark.parametrize("wgs", [1, 5, 16, 32])
 def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypatch, wgs):
     """The multi-workgroup path kernel (cooperative launch, grid barriers) and the single-workgroup one walk the
