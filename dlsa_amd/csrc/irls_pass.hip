@@ -30,6 +30,9 @@
 #ifndef DLSA_FUSED_EARLY_FRAGS
 #define DLSA_FUSED_EARLY_FRAGS 1    // 1: the next chunk's fragments are requested behind segment 1 of the second k-step instead of at the iteration's end
 #endif
+#ifndef DLSA_FUSED_BATCH
+#define DLSA_FUSED_BATCH 1          // 1: the transcendentals of a wave's own rows are evaluated once per TWO chunks, 16 rows x 4 copies instead of 8 rows x 8 copies (round 4); needs a fifth LDS stage
+#endif
 #ifndef FP_ABL
 #define FP_ABL 0                    // ABLATION builds only (wrong results; bench/build_variant.sh ... -DFP_ABL=n): 1 no log1p / loglik, 2 no logistic terms, 4 no DMA in the loop, 8 no MFMAs
 #endif
@@ -115,6 +118,12 @@ constexpr int fp_pitch(int ntc) { return (ntc % 2) ? ntc * 16 : ntc * 16 + 16; }
 constexpr int fp_buf(int ntc) { return FP_KC * fp_pitch(ntc) + 2 * FP_KC; }            // a chunk + its w (computed) + its y (DMA)
 constexpr int fp_nreg(int nt, int g) { return 8 * (nt * (nt + 1) / 2) + 2 * (nt + 1) * g; }
 constexpr int fp_gp(int ntc) { return 16 * ntc + 8; }
+// BATCHED logistic terms (fused pass only): five stages + a scratch corner per wave (eight partial sums of 16 rows at a pitch of
+// ten doubles -- conflict-free 16-byte reads -- and the 16 residuals)
+constexpr int FP_NST_B = 5, FP_SCR = 192;
+constexpr bool fp_batch_ok(int ntc) { return DLSA_FUSED_BATCH && DLSA_FUSED_PRIVATE && (size_t)(FP_NST_B * fp_buf(ntc) + 4 * FP_SCR) * 8 <= (size_t)kLdsBytes; }
+constexpr int fp_hess_stages(int ntc) { return fp_batch_ok(ntc) ? FP_NST_B : FP_NST; }
+constexpr size_t fp_hess_lds(int ntc) { return (size_t)(fp_hess_stages(ntc) * fp_buf(ntc) + (fp_batch_ok(ntc) ? 4 * FP_SCR : 0)) * 8; }
 
 template <int T, int TEND, typename F>
 __device__ __forceinline__ void fp_for_tiles(F&& fn) {
@@ -197,6 +206,7 @@ template <int NTC>
 struct LogitState {
     double x[NTC][2];         // the lane's columns of its row
     double yv, eta, e, inv, mu, wgt, sv, num, den, q, kf, rr, resid;
+    double ps[8];             // batched form: the eight partial sums of the lane's row
     bool big, valid;
 };
 
@@ -213,10 +223,13 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     constexpr int WOFF = KC * LDP, YOFF = KC * LDP + KC;               // the stage's w and y slots
     constexpr bool PIN = fp_nreg(NT, G) <= 224;                        // registers to spare (all shapes but 7 tiles + 1 or 2 tail groups, 240 / 256 accumulators): pinned constants, scalar coefficients, early fragment loads
     constexpr int DMA_PER_CHUNK = KC / NWAVES + 1;                    // 8 row pieces + the y piece, per wave
-    constexpr int MEETN_FIT = (int)((size_t)FP_NST * BUF * 8 / (3 * 2048));
+    // BATCH: the logistic terms of the wave's own rows of TWO chunks in one evaluation (lane = row (lane & 15), four copies)
+    constexpr bool BATCH = HESS && fp_batch_ok(NTC);
+    constexpr int NST = HESS ? fp_hess_stages(NTC) : fp_logit_stages(NTC);
+    constexpr int MEETN_FIT = (int)((size_t)NST * BUF * 8 / (3 * 2048));
     constexpr int MEETN = MEETN_FIT < NTRI ? MEETN_FIT : NTRI;
     static_assert(3 * MEETN >= NTRI, "the tiles meet in at most three passes");
-    static_assert((size_t)3 * (NT + 1) * G * 64 <= (size_t)FP_NST * BUF, "tail meeting fits the ring");
+    static_assert((size_t)3 * (NT + 1) * G * 64 <= (size_t)NST * BUF, "tail meeting fits the ring");
     static_assert(NARROW_NSEG == 5 && KC == 32, "piece schedule below: two k-steps of five segments per chunk");
     // (the logistic terms ride behind segments 1 and 3 of the first k-step and 0, 2 and 4 of the second: five VALU groups per chunk --
     // a group costs ~11 pipe cycles whatever its size -- with the LDS reads one segment ahead of their use)
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + rbeg), 0, nrows * 8, 0x00020000);
     // columns p .. 16 NTC - 1 are never written by the DMA (lanes masked): the ring is zeroed once
-    for (int e = tid; e < (HESS ? FP_NST : fp_logit_stages(NTC)) * BUF; e += THREADS) lds[e] = 0.0;
+    for (int e = tid; e < NST * BUF; e += THREADS) lds[e] = 0.0;
     __syncthreads();
 
     const bool col_in = 2 * lane < a.p;
@@ -316,14 +329,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         L.yv = base[YOFF + own_slot];
         if constexpr (WOUT) L.valid = chunk * KC + own_row < nrows;
     };
-    auto lp_dot = [&]() {                         // eta over the 8 lanes of the row (every lane ends with it), then the exponent split
-        double s0 = L.x[0][0] * bq[0][0], s1 = L.x[0][1] * bq[0][1];
-#pragma unroll
-        for (int q = 1; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
-        double s = s0 + s1;
-        s += dpp_xor_f64<1>(s);
-        s += dpp_xor_f64<2>(s);
-        s += dpp_xor_f64<8>(s);
+    auto lp_split = [&](double s) {               // the exponent split of exp(-|eta|)
         L.eta = s;
         double aabs;
         asm("v_min_f64 %0, |%1|, %2" : "=v"(aabs) : "v"(s), "s"(745.2));
@@ -333,6 +339,16 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         double r;
         asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "v"(L.kf), "s"(6.93147180369123816490e-01), "v"(aabs));
         L.rr = fp_fma_sc2(L.kf, 1.90821492927058770002e-10, r);
+    };
+    auto lp_dot = [&]() {                         // eta over the 8 lanes of the row (every lane ends with it), then the exponent split
+        double s0 = L.x[0][0] * bq[0][0], s1 = L.x[0][1] * bq[0][1];
+#pragma unroll
+        for (int q = 1; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
+        double s = s0 + s1;
+        s += dpp_xor_f64<1>(s);
+        s += dpp_xor_f64<2>(s);
+        s += dpp_xor_f64<8>(s);
+        lp_split(s);
     };
     auto lp_exp = [&]() {                         // e = exp(-|eta|): degree-13 polynomial, ldexp (logistic.h: exp_neg)
         const double r = L.rr;
@@ -354,15 +370,18 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         asm("v_cvt_i32_f64 %0, -%1" : "=v"(kneg) : "v"(L.kf));
         L.e = ldexp(q, kneg);
     };
-    auto lp_mu = [&](int buf) {                   // mu, w -> the stage's w slot (read back by this wave's MFMA part next chunk)
+    auto lp_mu_core = [&]() {
         const double inv = rcp_newton(1.0 + L.e);
         const double einv = L.e * inv;
         L.mu = L.eta >= 0.0 ? inv : einv;
         L.wgt = einv * inv;
         L.resid = L.yv - L.mu;
+    };
+    auto lp_mu = [&](int buf) {                   // mu, w -> the stage's w slot (read back by this wave's MFMA part next chunk)
+        lp_mu_core();
         if (HESS && ls == 0) lds[buf * BUF + WOFF + own_slot] = L.wgt;
     };
-    auto lp_log = [&](int chunk) {                // log1p(e) and the row's loglik term (logistic.h: logistic_terms)
+    auto lp_log_core = [&]() {                    // log1p(e) and the row's loglik term (logistic.h: logistic_terms)
         // t' = h (1 + e) with h = 1/2 above sqrt 2: num = t' - 1 = h e + (h - 1), den = t' + 1 = h e + (h + 1) -- the same values as
         // logistic.h's selects between fma(0.5, e, -0.5) / e and fma(0.5, e, 1.5) / 2 + e, from three one-dword selects
         const bool big = L.e > c_sqrt2m1;
@@ -388,6 +407,9 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         asm("v_max_f64 %0, %1, 0" : "=v"(pos) : "v"(L.eta));              // (fmax() puts a canonicalising v_max in front)
         const double softplus = pos + l1p;
         llacc += fma(L.yv, L.eta, -softplus);
+    };
+    auto lp_log = [&](int chunk) {
+        lp_log_core();
         if constexpr (WOUT) {
             if (ls == 0 && L.valid) a.w_out[rbeg + (int64_t)chunk * KC + own_row] = L.wgt;
         }
@@ -403,10 +425,68 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         lp_read(chunk, buf); lp_dot(); lp_exp(); lp_mu(buf); lp_log(chunk); lp_grad();
     };
 
+    // ---- BATCH: the same terms for the wave's own rows of TWO chunks at once.  The dot products keep the 8-lanes-per-row layout (one
+    // pass per chunk) and leave their eight partial sums per row in the wave's scratch corner; then lane L evaluates row (L & 15) --
+    // rows 0..7: the first chunk's, 8..15: the second's; four copies -- summing the partials in the butterfly's order (the same eta to
+    // the last bit), so the ~64 instructions of the transcendentals run once per 16 rows instead of once per 8.  w goes to the stages'
+    // w slots, the residuals to the scratch corner, from where the gradient passes (rows re-read from LDS: DS instructions cost the
+    // matrix pipe next to nothing) pick them up.  Everything stays inside the wave: no barrier, no flag.
+    double* const scr = lds + (BATCH ? NST * BUF + wave * FP_SCR : 0);
+    const int b_r = lane & 15, b_h = b_r >> 3, b_s = b_r & 7;
+    const int b_row = b_s < 4 ? 4 * wave + b_s : 16 + 4 * wave + (b_s - 4);
+    const int b_slot = 8 * wave + b_s;
+    double resid_g = 0.0;
+    auto bp_read = [&](int buf) {
+        const double* base = lds + buf * BUF;
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            const d2 v = *(const d2*)(base + xoff + 16 * q);
+            L.x[q][0] = v.x; L.x[q][1] = v.y;
+        }
+    };
+    auto bp_dot = [&](int h) {
+        double s0 = L.x[0][0] * bq[0][0], s1 = L.x[0][1] * bq[0][1];
+#pragma unroll
+        for (int q = 1; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
+        scr[(8 * h + lj) * 10 + ls] = s0 + s1;
+    };
+    auto bp_sum_read = [&](int chunk0, int buf0, int buf1) {
+        const d2* pr = (const d2*)(scr + b_r * 10);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const d2 v = pr[k]; L.ps[2 * k] = v.x; L.ps[2 * k + 1] = v.y; }
+        L.yv = lds[(b_h ? buf1 : buf0) * BUF + YOFF + b_slot];
+        if constexpr (WOUT) L.valid = (chunk0 + b_h) * KC + b_row < nrows;
+    };
+    auto bp_sum = [&]() {
+        lp_split(((L.ps[0] + L.ps[1]) + (L.ps[2] + L.ps[3])) + ((L.ps[4] + L.ps[5]) + (L.ps[6] + L.ps[7])));
+    };
+    auto bp_mu = [&](int buf0, int buf1) {
+        lp_mu_core();
+        if (lane < 16) {
+            lds[(b_h ? buf1 : buf0) * BUF + WOFF + b_slot] = L.wgt;
+            scr[160 + b_r] = L.resid;
+        }
+    };
+    auto bp_log = [&](int chunk0) {
+        lp_log_core();
+        if constexpr (WOUT) {
+            if (lane < 16 && L.valid) a.w_out[rbeg + (int64_t)(chunk0 + b_h) * KC + b_row] = L.wgt;
+        }
+    };
+    auto bp_gread = [&](int h, int buf) { bp_read(buf); resid_g = scr[160 + 8 * h + lj]; };
+    auto bp_grad = [&]() {
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            gacc[q][0] = fma(resid_g, L.x[q][0], gacc[q][0]);
+            gacc[q][1] = fma(resid_g, L.x[q][1], gacc[q][1]);
+        }
+    };
+
     if constexpr (HESS) narrow_acc_zero<fp_nreg(NT, G)>();
 
     // ---- prologue: chunks 0 .. 2 in flight (logit only: 0 .. D - 1); chunks 0 and 1 landed; the logistic terms of chunk 0
-    constexpr int D = HESS ? 3 : fp_logit_stages(NTC);
+    // (BATCH: chunks 0 .. 3 in flight, 0 and 1 landed, their logistic terms)
+    constexpr int D = BATCH ? 4 : HESS ? 3 : fp_logit_stages(NTC);
 #pragma unroll
     for (int ch = 0; ch < D; ++ch) {
 #pragma unroll
@@ -415,7 +495,13 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * DMA_PER_CHUNK) : "memory");
     if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");
-    logit_all(0, 0);
+    if constexpr (BATCH) {
+        bp_read(0); bp_dot(0); bp_read(1); bp_dot(1);
+        bp_sum_read(0, 0, 1); bp_sum(); lp_exp(); bp_mu(0, 1); bp_log(0);
+        bp_gread(0, 0); bp_grad(); bp_gread(1, 1); bp_grad();
+    } else {
+        logit_all(0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!HESS) asm volatile("s_barrier" ::: "memory");       // the loop's first DMA overwrites chunk 0, which every wave must have left
 
@@ -492,7 +578,68 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");
         cur = nxt;
     };
-    if constexpr (HESS) {
+    // BATCH: one trip = the MFMAs of chunks c and c + 1 (stages s0, s1), the logistic terms of chunks c + 2 and c + 3 (landed / landing
+    // in s2, s3), the DMA of chunks c + 4 (into the stage chunk c - 1 has left) and c + 5 (into chunk c's, once its MFMAs are out).
+    auto half = [&](auto hc, int c, int s0, int s1, int s2, int s3, int s4, const Frags& fr, Frags& fnext) {
+        constexpr int HALF = decltype(hc)::value;                       // 0: the MFMAs of chunk c (stage s0), 1: of chunk c + 1 (s1)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            double g[NT], btw[GA];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) g[t] = fr.f[kk][t] * fr.wv[kk];
+#pragma unroll
+            for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? fr.bt[kk][gi] * fr.wv[kk] : 0.0;
+            fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if (kk == 0) {
+                    // chunk c + 3 has landed when only the four row pieces of chunk c + 4 just issued are still out
+                    if constexpr (HALF == 0 && q == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : 2 * RQ) : "memory");
+                    if constexpr (!(FP_ABL & 4)) {
+                        if constexpr (q < 4) stage_rows(c + 4 + HALF, HALF == 0 ? s4 : s0, q); else stage_y(c + 4 + HALF, HALF == 0 ? s4 : s0);
+                    }
+                } else {
+                    // the next MFMA block's fragments (and the weights bp_mu has stored for them), three segments before they are needed
+                    if constexpr (q == 1) load_frags(HALF == 0 ? s1 : s2, fnext);
+                }
+                if constexpr (FP_ABL & 2) return;
+                if constexpr (HALF == 0) {
+                    if (kk == 0) {
+                        if constexpr (q == 0) bp_read(s2);
+                        else if constexpr (q == 1) bp_dot(0);
+                        else if constexpr (q == 2) bp_read(s3);
+                        else if constexpr (q == 3) bp_dot(1);
+                        else bp_sum_read(c + 2, s2, s3);
+                    } else {
+                        if constexpr (q == 0) bp_sum();
+                        else if constexpr (q == 2) lp_exp();
+                        else if constexpr (q == 4) bp_mu(s2, s3);
+                    }
+                } else {
+                    if (kk == 0) {
+                        if constexpr (q == 1) { if constexpr (!(FP_ABL & 1)) bp_log(c + 2); }
+                        else if constexpr (q == 3) bp_gread(0, s2);
+                        else if constexpr (q == 4) bp_grad();
+                    } else {
+                        if constexpr (q == 0) bp_gread(1, s3);
+                        else if constexpr (q == 1) bp_grad();
+                    }
+                }
+            });
+        }
+    };
+    if constexpr (HESS && BATCH) {
+        Frags fa, fb;
+        load_frags(0, fa);
+        int s0 = 0;
+        // an odd chunk count runs one chunk past the slab's end: zero rows through the DMA's bounds check, taken out of the logistic sums
+        for (int c = 0; c < nchunks; c += 2) {
+            const int s1 = s0 + 1 - (s0 >= 4 ? 5 : 0), s2 = s0 + 2 - (s0 >= 3 ? 5 : 0), s3 = s0 + 3 - (s0 >= 2 ? 5 : 0), s4 = s0 + 4 - (s0 >= 1 ? 5 : 0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : DMA_PER_CHUNK) : "memory");       // chunk c + 2 has landed (c + 3 may be in flight)
+            half(std::integral_constant<int, 0>{}, c, s0, s1, s2, s3, s4, fa, fb);
+            half(std::integral_constant<int, 1>{}, c, s0, s1, s2, s3, s4, fb, fa);
+            s0 = s2;
+        }
+    } else if constexpr (HESS) {
         Frags fa, fb;
         load_frags(0, fa);
         // an odd chunk count runs one chunk past the slab's end: zero rows through the DMA's bounds check, masked in the logistic sums
@@ -527,7 +674,14 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         }
     // loglik: one lane per row counts.  The zero rows evaluated past the slab's end -- chunks 0 .. nch_eval - 1 were evaluated -- each
     // added fma(0, 0, -softplus(0)) = -ln 2: taken out again (to the rounding of that one product).
-    {
+    if constexpr (BATCH) {
+        // lane L < 16 evaluated row b_row of the chunks b_h, b_h + 2, ... below nch_eval (even)
+        const int nch_eval = ((nchunks + 1) & ~1) + 2;
+        int first_bad = nrows > b_row ? (nrows - b_row + KC - 1) / KC : 0;
+        first_bad += (first_bad ^ b_h) & 1;                                                // ... of the lane's parity
+        const int nbad = nch_eval > first_bad ? (nch_eval - first_bad + 1) / 2 : 0;
+        llacc = lane < 16 ? fma((double)nbad, 6.931471805599453094e-01, llacc) : 0.0;
+    } else {
         const int nch_eval = (HESS ? ((nchunks + 1) & ~1) : nchunks) + 1;
         const int first_bad = nrows > own_row ? (nrows - own_row + KC - 1) / KC : 0;      // first chunk whose row `own_row` lies past the end
         const int nbad = nch_eval > first_bad ? nch_eval - first_bad : 0;
@@ -645,7 +799,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     a.gpart = (double*)((char*)ws + part);
     a.clk = (unsigned long long*)((char*)ws + part + gpb);
 #define DLSA_LAUNCH_FP2(WO, HS, NTV, GV) do { \
-        const size_t shm = (size_t)((HS) ? FP_NST : fp_logit_stages(NTV + (GV > 0 ? 1 : 0))) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
+        const size_t shm = (HS) ? fp_hess_lds(NTV + (GV > 0 ? 1 : 0)) : (size_t)fp_logit_stages(NTV + (GV > 0 ? 1 : 0)) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, HS, NTV, GV>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, HS, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
