@@ -33,6 +33,9 @@
 #ifndef DLSA_FUSED_BATCH
 #define DLSA_FUSED_BATCH 1          // 1: the transcendentals of a wave's own rows are evaluated once per TWO chunks, 16 rows x 4 copies instead of 8 rows x 8 copies (round 4); needs a fifth LDS stage
 #endif
+#ifndef FP_TIMELINE
+#define FP_TIMELINE 0               // profiling builds only (bench/fused_timeline.py): every workgroup leaves its s_memrealtime stamps in the free slots of its g partial
+#endif
 #ifndef FP_ABL
 #define FP_ABL 0                    // ABLATION builds only (wrong results; bench/build_variant.sh ... -DFP_ABL=n): 1 no log1p / loglik, 2 no logistic terms, 4 no DMA in the loop, 8 no MFMAs
 #endif
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     const bool probe = blockIdx.x == 0 && wave == 0;
     const unsigned long long t_begin = probe ? __builtin_readcyclecounter() : 0ull;
     const int slab = blockIdx.x;
+#if FP_TIMELINE
+    unsigned long long tl0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl2 = 0;
+#endif
     const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
     const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
     const int nrows = (int)(rend > rbeg ? rend - rbeg : 0);
@@ -270,6 +276,15 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             const int soff = (chunk * KC + wrow + rrow) * pitch_b;
             if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + wrow * LDP + rrow * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
         }
+    };
+    // one row piece (BATCH: one DMA instruction behind each MFMA segment -- two in a row cost the pipe four times what two apart do, bench/ubench_gap.hip)
+    auto stage_row1 = [&](int chunk, int buf, int ps) {
+        double* base = lds + buf * BUF;
+        int pitch_b = (int)a.ldx * 8, wrow = 4 * wave;
+        asm volatile("" : "+s"(pitch_b), "+s"(wrow));
+        const int rrow = 16 * (ps >> 2) + (ps & 3);
+        const int soff = (chunk * KC + wrow + rrow) * pitch_b;
+        if (col_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(base + wrow * LDP + rrow * LDP), 16, lane * 16, soff, 0, DLSA_STREAM_AUX);
     };
     // the chunk's labels.  PRIVATE: this wave's eight only, into its own corner of the y slot ([wave][8]: lane L fetches the two labels
     // 2 (L & 1) .. + 1 of k-step wave + 4 (L >> 1)).  Else every wave fetches all 32 (same bytes to the same place, the same count).
@@ -435,20 +450,28 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     const int b_r = lane & 15, b_h = b_r >> 3, b_s = b_r & 7;
     const int b_row = b_s < 4 ? 4 * wave + b_s : 16 + 4 * wave + (b_s - 4);
     const int b_slot = 8 * wave + b_s;
-    double resid_g = 0.0;
-    auto bp_read = [&](int buf) {
+    double resid_g[2] = {0.0, 0.0};
+    double xb[BATCH ? NTC : 1][2];            // the second chunk's row (the first chunk's sits in L.x): both stay in registers up to the gradient
+    auto bp_read = [&](auto hc, int buf) {
+        constexpr int h = decltype(hc)::value;
         const double* base = lds + buf * BUF;
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
             const d2 v = *(const d2*)(base + xoff + 16 * q);
-            L.x[q][0] = v.x; L.x[q][1] = v.y;
+            if constexpr (h == 0) { L.x[q][0] = v.x; L.x[q][1] = v.y; }
+            else { xb[BATCH ? q : 0][0] = v.x; xb[BATCH ? q : 0][1] = v.y; }
         }
     };
-    auto bp_dot = [&](int h) {
+    auto bp_dot = [&]() {                         // both chunks' partial sums -> the scratch corner
         double s0 = L.x[0][0] * bq[0][0], s1 = L.x[0][1] * bq[0][1];
+        double t0 = xb[0][0] * bq[0][0], t1 = xb[0][1] * bq[0][1];
 #pragma unroll
-        for (int q = 1; q < NTC; ++q) { s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1); }
-        scr[(8 * h + lj) * 10 + ls] = s0 + s1;
+        for (int q = 1; q < NTC; ++q) {
+            s0 = fma(L.x[q][0], bq[q][0], s0); s1 = fma(L.x[q][1], bq[q][1], s1);
+            t0 = fma(xb[BATCH ? q : 0][0], bq[q][0], t0); t1 = fma(xb[BATCH ? q : 0][1], bq[q][1], t1);
+        }
+        scr[lj * 10 + ls] = s0 + s1;
+        scr[(8 + lj) * 10 + ls] = t0 + t1;
     };
     auto bp_sum_read = [&](int chunk0, int buf0, int buf1) {
         const d2* pr = (const d2*)(scr + b_r * 10);
@@ -473,20 +496,25 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             if (lane < 16 && L.valid) a.w_out[rbeg + (int64_t)(chunk0 + b_h) * KC + b_row] = L.wgt;
         }
     };
-    auto bp_gread = [&](int h, int buf) { bp_read(buf); resid_g = scr[160 + 8 * h + lj]; };
+    auto bp_gread = [&]() { resid_g[0] = scr[160 + lj]; resid_g[1] = scr[168 + lj]; };
     auto bp_grad = [&]() {
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
-            gacc[q][0] = fma(resid_g, L.x[q][0], gacc[q][0]);
-            gacc[q][1] = fma(resid_g, L.x[q][1], gacc[q][1]);
+            gacc[q][0] = fma(resid_g[0], L.x[q][0], gacc[q][0]);
+            gacc[q][1] = fma(resid_g[0], L.x[q][1], gacc[q][1]);
+        }
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+            gacc[q][0] = fma(resid_g[1], xb[BATCH ? q : 0][0], gacc[q][0]);
+            gacc[q][1] = fma(resid_g[1], xb[BATCH ? q : 0][1], gacc[q][1]);
         }
     };
 
     if constexpr (HESS) narrow_acc_zero<fp_nreg(NT, G)>();
 
     // ---- prologue: chunks 0 .. 2 in flight (logit only: 0 .. D - 1); chunks 0 and 1 landed; the logistic terms of chunk 0
-    // (BATCH: chunks 0 .. 3 in flight, 0 and 1 landed, their logistic terms)
-    constexpr int D = BATCH ? 4 : HESS ? 3 : fp_logit_stages(NTC);
+    // (BATCH: chunks 0 .. 4 in flight -- all five stages --, 0 and 1 landed, their logistic terms)
+    constexpr int D = BATCH ? 5 : HESS ? 3 : fp_logit_stages(NTC);
 #pragma unroll
     for (int ch = 0; ch < D; ++ch) {
 #pragma unroll
@@ -496,15 +524,18 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * DMA_PER_CHUNK) : "memory");
     if constexpr (!PRIV) asm volatile("s_barrier" ::: "memory");
     if constexpr (BATCH) {
-        bp_read(0); bp_dot(0); bp_read(1); bp_dot(1);
+        bp_read(std::integral_constant<int, 0>{}, 0); bp_read(std::integral_constant<int, 1>{}, 1); bp_dot();
         bp_sum_read(0, 0, 1); bp_sum(); lp_exp(); bp_mu(0, 1); bp_log(0);
-        bp_gread(0, 0); bp_grad(); bp_gread(1, 1); bp_grad();
+        bp_gread(); bp_grad();
     } else {
         logit_all(0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!HESS) asm volatile("s_barrier" ::: "memory");       // the loop's first DMA overwrites chunk 0, which every wave must have left
 
+#if FP_TIMELINE
+    tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);
     int cur = 0;
@@ -579,7 +610,10 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         cur = nxt;
     };
     // BATCH: one trip = the MFMAs of chunks c and c + 1 (stages s0, s1), the logistic terms of chunks c + 2 and c + 3 (landed / landing
-    // in s2, s3), the DMA of chunks c + 4 (into the stage chunk c - 1 has left) and c + 5 (into chunk c's, once its MFMAs are out).
+    // in s2, s3), the DMA of chunks c + 5 and c + 6.  A stage is dead as soon as its chunk's fragments sit in registers (the wave's two
+    // k-steps ARE its rows of the chunk; their logistic terms were done a trip earlier): chunk c + 5 goes into chunk c's stage during
+    // the MFMAs of chunk c, chunk c + 6 into chunk c + 1's during the MFMAs of chunk c + 1 -- every row is requested more than a
+    // trip (> 3.5 us) before its first use (four chunks ahead left the odd chunk ~2 us: SQ_WAIT_ANY 6.7 % of the wave cycles).
     auto half = [&](auto hc, int c, int s0, int s1, int s2, int s3, int s4, const Frags& fr, Frags& fnext) {
         constexpr int HALF = decltype(hc)::value;                       // 0: the MFMAs of chunk c (stage s0), 1: of chunk c + 1 (s1)
 #pragma unroll
@@ -591,37 +625,32 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             for (int gi = 0; gi < GA; ++gi) btw[gi] = (G > 0) ? fr.bt[kk][gi] * fr.wv[kk] : 0.0;
             fp_kstep_spread<NT, G, 0>(fr.f[kk], g, btw, [&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if (kk == 0) {
-                    // chunk c + 3 has landed when only the four row pieces of chunk c + 4 just issued are still out
-                    if constexpr (HALF == 0 && q == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : 2 * RQ) : "memory");
-                    if constexpr (!(FP_ABL & 4)) {
-                        if constexpr (q < 4) stage_rows(c + 4 + HALF, HALF == 0 ? s4 : s0, q); else stage_y(c + 4 + HALF, HALF == 0 ? s4 : s0);
-                    }
-                } else {
-                    // the next MFMA block's fragments (and the weights bp_mu has stored for them), three segments before they are needed
-                    if constexpr (q == 1) load_frags(HALF == 0 ? s1 : s2, fnext);
+                // chunk c + 3 has landed when only chunk c + 4 and the two row pieces of chunk c + 5 just issued are still out
+                if (kk == 0) { if constexpr (HALF == 0 && q == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : DMA_PER_CHUNK + 2) : "memory"); }
+                if constexpr (!(FP_ABL & 4)) {      // the eight rows and the labels of chunk c + 5 (+ 1): one piece behind each of nine segments
+                    const int piece = 5 * kk + q;
+                    if (piece < 8) stage_row1(c + 5 + HALF, HALF == 0 ? s0 : s1, piece);
+                    else if (piece == 8) stage_y(c + 5 + HALF, HALF == 0 ? s0 : s1);
                 }
+                // the next MFMA block's fragments (and the weights bp_mu has stored for them), three segments before they are needed
+                if (kk == 1) { if constexpr (q == 1) load_frags(HALF == 0 ? s1 : s2, fnext); }
                 if constexpr (FP_ABL & 2) return;
                 if constexpr (HALF == 0) {
+                    // (few, large VALU groups: a group costs ~11 pipe cycles whatever its size; every LDS read one segment ahead of its use)
                     if (kk == 0) {
-                        if constexpr (q == 0) bp_read(s2);
-                        else if constexpr (q == 1) bp_dot(0);
-                        else if constexpr (q == 2) bp_read(s3);
-                        else if constexpr (q == 3) bp_dot(1);
-                        else bp_sum_read(c + 2, s2, s3);
+                        if constexpr (q == 0) bp_read(std::integral_constant<int, 0>{}, s2);
+                        else if constexpr (q == 2) bp_read(std::integral_constant<int, 1>{}, s3);
+                        else if constexpr (q == 3) bp_dot();
+                        else if constexpr (q == 4) bp_sum_read(c + 2, s2, s3);
                     } else {
-                        if constexpr (q == 0) bp_sum();
-                        else if constexpr (q == 2) lp_exp();
-                        else if constexpr (q == 4) bp_mu(s2, s3);
+                        if constexpr (q == 0) { bp_sum(); lp_exp(); }
+                        else if constexpr (q == 2) bp_mu(s2, s3);
+                        else if constexpr (q == 4) { if constexpr (!(FP_ABL & 1)) bp_log(c + 2); }
                     }
                 } else {
                     if (kk == 0) {
-                        if constexpr (q == 1) { if constexpr (!(FP_ABL & 1)) bp_log(c + 2); }
-                        else if constexpr (q == 3) bp_gread(0, s2);
-                        else if constexpr (q == 4) bp_grad();
-                    } else {
-                        if constexpr (q == 0) bp_gread(1, s3);
-                        else if constexpr (q == 1) bp_grad();
+                        if constexpr (q == 1) bp_gread();
+                        else if constexpr (q == 2) bp_grad();
                     }
                 }
             });
@@ -634,7 +663,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         // an odd chunk count runs one chunk past the slab's end: zero rows through the DMA's bounds check, taken out of the logistic sums
         for (int c = 0; c < nchunks; c += 2) {
             const int s1 = s0 + 1 - (s0 >= 4 ? 5 : 0), s2 = s0 + 2 - (s0 >= 3 ? 5 : 0), s3 = s0 + 3 - (s0 >= 2 ? 5 : 0), s4 = s0 + 4 - (s0 >= 1 ? 5 : 0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : DMA_PER_CHUNK) : "memory");       // chunk c + 2 has landed (c + 3 may be in flight)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FP_ABL & 4) ? 0 : 2 * DMA_PER_CHUNK) : "memory");       // chunk c + 2 has landed (c + 3, c + 4 may be in flight)
             half(std::integral_constant<int, 0>{}, c, s0, s1, s2, s3, s4, fa, fb);
             half(std::integral_constant<int, 1>{}, c, s0, s1, s2, s3, s4, fb, fa);
             s0 = s2;
@@ -650,6 +679,10 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#if FP_TIMELINE
+    tl2 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl2w = tl2;
+#endif
     __syncthreads();
 
     // ---- H: the four waves' triangles meet in LDS; wave 0 stores the slab's partial
@@ -701,6 +734,13 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     if (tid <= 16 * NTC)
         a.gpart[(int64_t)slab * GP + tid] = ((lds[tid] + lds[GP + tid]) + lds[2 * GP + tid]) + lds[3 * GP + tid];
     if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
+#if FP_TIMELINE
+    if (lane == 0) {       // slots 16 NTC + 1 .. + 7 of the workgroup's g partial are free: wave 0 leaves start / prologue end / loop end / end, waves 1..3 their loop ends
+        unsigned long long* tl = (unsigned long long*)(a.gpart + (int64_t)slab * GP + 16 * NTC + 1);
+        if (wave == 0) { tl[0] = tl0; tl[1] = tl1; tl[2] = tl2w; tl[3] = __builtin_amdgcn_s_memrealtime(); }
+        else tl[3 + wave] = tl2w;
+    }
+#endif
 }
 
 // g [p] and loglik: the slab partials in a fixed order
