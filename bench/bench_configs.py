@@ -124,8 +124,12 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
     rows_max = min(chunk_rows, n // K)
     Xc = engine.empty_rows(rows_max, p, dt, "cuda"); yc = torch.empty(rows_max, dtype=dt, device="cuda")
     H = torch.zeros((p, p), dtype=torch.float64, device="cuda")
-    t_syn, _ = timed(lambda: (engine.synth(20260101, 0, rows_max, p, kind=engine.SYNTH_GAUSSIAN, labels=False, dtype=dt, out=Xc),
-                              engine.synth_response(20260101, 0, Xc, out=yc)))
+    kind = os.environ.get("DLSA_C5_KIND", "gaussian32")       # "gaussian": the fp64-defined stream rounded to fp32 + a separate response pass (round 3)
+    if kind == "gaussian32":
+        t_syn, _ = timed(lambda: engine.synth_linear32(20260101, 0, rows_max, p, out=Xc, out_y=yc))
+    else:
+        t_syn, _ = timed(lambda: (engine.synth(20260101, 0, rows_max, p, kind=engine.SYNTH_GAUSSIAN, labels=False, dtype=dt, out=Xc),
+                                  engine.synth_response(20260101, 0, Xc, out=yc)))
     t_gram, _ = timed(lambda: engine.gram_acc64(Xc, None, out=H, accumulate=True))
     kern = engine.gram_last_kernel()[0]
     t_stats, _ = timed(lambda: engine.xtv_stats(Xc, yc, want_colsum=True))
@@ -133,7 +137,7 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
     torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
     t0 = time.perf_counter()
     overlap = os.environ.get("DLSA_C5_OVERLAP", "0") != "0"
-    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=chunk_rows, fit_intercept=True, dtype=dt, overlap=overlap)
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=chunk_rows, fit_intercept=True, dtype=dt, overlap=overlap, kind=kind)
     torch.cuda.synchronize(); t_map = time.perf_counter() - t0
     peak = torch.cuda.max_memory_allocated() - base
     t1 = time.perf_counter()
@@ -147,7 +151,7 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
             "gram_rows_per_s": rows_max / t_gram, "gram_TF_alg": rows_max * fl / t_gram / 1e12,
             "stats_GBps": rows_max * 4 * (p + 1) / t_stats / 1e9, "map_fit_s": t_map, "map_rows_per_s": n / t_map,
             "map_TF_alg_incl_generation": n * fl / t_map / 1e12, "reduce_lars_s": t_rest, "peak_device_bytes": peak,
-            "status_ok": all(v == 0 for v in mb.status), "generation_overlapped": overlap,
+            "status_ok": all(v == 0 for v in mb.status), "generation_overlapped": overlap, "stream_kind": kind,
             "theta_err_linf": float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth)))}
 
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "dlsa_synth_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dlsa_synth_response_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_dbl, c_vp, c_vp]),
     "dlsa_synth_response_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_dbl, c_vp, c_vp]),
+    "dlsa_synth_linear_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_dbl, c_vp, c_vp]),
     "dlsa_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "dlsa_gram_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "dlsa_gram_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),

@@ -515,7 +515,7 @@ static void choose_wide_slabs(int64_t n, int p, int cost, int& nslab, int64_t& r
         const double eff = (double)work / (double)(rounds * round_cost);
         const double score = eff * std::min(1.0, 0.88 + 0.01 * (double)rounds);
         if (score > best_score + 0.004) { best_score = score; best = ns; }       // prefer fewer, larger slabs
-        if (rounds >= 12 && eff >= 0.995) break;
+        if ((rounds >= 12 && eff >= 0.975) || rounds >= 20) break;               // (every slab costs a PP x PP partial: written, then read by the reduce)
     }
     rows_per_slab = ((n + best - 1) / best + WKC - 1) / WKC * WKC;
     if (rows_per_slab < WKC) rows_per_slab = WKC;

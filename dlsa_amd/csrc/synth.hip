@@ -4,6 +4,7 @@
 // pipeline and the uint32 -> double conversion are bit-identical to oracle/dlsa_oracle.py, so
 // the uniform variant gives the CPU oracle and every GPU shard exactly the same rows.
 #include "common.h"
+#include <algorithm>
 
 namespace dlsa {
 
@@ -111,6 +112,80 @@ __global__ void synth_response_kernel(unsigned long long seed, int64_t row0, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32-NATIVE linear rows (config 5's stream at its stated size): features AND response in one launch, every
+// value formed in fp32.  The fp64-defined generator above costs 41 ms per 2^22 x 2000 chunk -- Philox for two columns per call
+// and double-precision log / sqrt / sincos, all VALU time the matrix pipe cannot hide (the Gram of the same chunk takes 121 ms;
+// run side by side on two streams the two kernels take exactly the sum of their times, bench/overlap_probe.py) -- and the
+// response a second read of the chunk.  Definition (oracle/dlsa_oracle.py: synth_linear32):
+//   row i, column quad q = j / 4: Philox-4x32-10 counter (i_lo, i_hi, q, 3), key (seed, 0) -> four 24-bit uniforms
+//   u_k = (o_k >> 8) 2^-24;  columns 4q, 4q + 1 = r cos(2 pi u_1), r sin(2 pi u_1) with r = sqrt(-2 ln(1 - u_0)) sqrt(1/12);
+//   columns 4q + 2, 4q + 3 likewise from (u_2, u_3);
+//   y_i = sum_j x_ij beta_j + sigma sqrt(-2 ln(1 - v_0)) cos(2 pi v_1),  v from counter (i_lo, i_hi, 0, 4), key (seed + 1, 0).
+// The logarithm, root, sine and cosine are the hardware's fp32 instructions (v_log_f32, v_sqrt_f32, v_sin_f32, v_cos_f32): the
+// rows are a pure function of (seed, i) on this device, and agree with the oracle's numpy fp32 evaluation to ~1e-6 absolute.
+// One wave per row at a time (grid-stride): lane l forms the quads l, l + 64, ... (16-byte stores, 1 KB per wave instruction)
+// and keeps its share of x . beta; one wave reduction per row.
+__device__ __forceinline__ float u24(unsigned o) { return (float)(o >> 8) * 5.9604644775390625e-08f; }
+__device__ __forceinline__ void box_muller32(float u0, float u1, float scale, float& a, float& b) {
+    // -2 ln(1 - u0) = -2 ln2 log2(1 - u0);  v_sin / v_cos take their argument in revolutions
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u0)) * scale;
+    a = r * __builtin_amdgcn_cosf(u1);
+    b = r * __builtin_amdgcn_sinf(u1);
+}
+__global__ __launch_bounds__(256) void synth_linear32_kernel(unsigned long long seed, int64_t row0, int64_t n, int p, int ones_col,
+                                                             float* __restrict__ X, int64_t ldx, const float* __restrict__ beta,
+                                                             int p_true_ones, float sigma, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int nquad = (p + 3) / 4;
+    const bool vec = !ones_col && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);      // 16-byte stores when every quad is aligned
+    for (int64_t r = wave; r < n; r += nwaves) {
+        const unsigned long long gi = (unsigned long long)(row0 + r);
+        float* row = X + r * ldx + (ones_col ? 1 : 0);
+        float dot = 0.f;
+        for (int q = lane; q < nquad; q += 64) {
+            u4 c; c.x = (unsigned)gi; c.y = (unsigned)(gi >> 32); c.z = (unsigned)q; c.w = 3u;
+            const u4 o = philox4x32_10(c, (unsigned)seed, 0u);
+            float v[4];
+            box_muller32(u24(o.x), u24(o.y), 0.28867513459481287f, v[0], v[1]);
+            box_muller32(u24(o.z), u24(o.w), 0.28867513459481287f, v[2], v[3]);
+            const int j = 4 * q;
+            if (vec && j + 3 < p) *reinterpret_cast<float4*>(row + j) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (j + e < p) row[j + e] = v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < p) dot += beta ? v[e] * beta[(ones_col ? 1 : 0) + j + e] : (j + e < p_true_ones ? v[e] : 0.f);
+        }
+        if (ones_col && lane == 0) { X[r * ldx] = 1.f; if (beta) dot += beta[0]; }
+        for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+        if (y && lane == 0) {
+            u4 c; c.x = (unsigned)gi; c.y = (unsigned)(gi >> 32); c.z = 0u; c.w = 4u;
+            const u4 o = philox4x32_10(c, (unsigned)(seed + 1ull), 0u);
+            float z, unused;
+            box_muller32(u24(o.x), u24(o.y), 1.0f, z, unused);
+            y[r] = dot + sigma * z;
+        }
+    }
+}
+
+int synth_linear32_impl(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, float* X, int64_t ldx, const float* beta_true,
+                        double sigma, float* y, hipStream_t s) {
+    DLSA_REQUIRE(X, "synth_linear32: null X");
+    DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p + (ones_col ? 1 : 0) && sigma >= 0.0, "synth_linear32: bad shape n=%lld p=%d ldx=%lld",
+                 (long long)n, p, (long long)ldx);
+    if (n == 0) return DLSA_OK;
+    const int64_t blocks = std::min<int64_t>((n + 3) / 4, (int64_t)kNumCU * 32);       // 8 waves per SIMD, grid-stride over the rows
+    hipLaunchKernelGGL(synth_linear32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned long long)seed, row0, n, p, ones_col, X, ldx,
+                       beta_true, (int)(p * 0.4), (float)sigma, y);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
 template <typename T>
 int synth_response_impl(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const T* X, int64_t ldx,
                         const T* beta_true, double sigma, T* y, hipStream_t s) {
@@ -170,5 +245,9 @@ int dlsa_synth_response_f64(uint64_t seed, int64_t row0, int64_t n, int p, int o
 int dlsa_synth_response_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const float* X, int64_t ldx,
                             const float* beta_true, double sigma, float* y, void* stream) {
     return dlsa::synth_response_impl<float>(seed, row0, n, p, ones_col, X, ldx, beta_true, sigma, y, (hipStream_t)stream);
+}
+int dlsa_synth_linear_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, float* X, int64_t ldx, const float* beta_true,
+                          double sigma, float* y, void* stream) {
+    return dlsa::synth_linear32_impl(seed, row0, n, p, ones_col, X, ldx, beta_true, sigma, y, (hipStream_t)stream);
 }
 }

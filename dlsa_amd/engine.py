@@ -181,6 +181,28 @@ def synth_response(seed, row0, X, sigma=1.0, ones_col=False, beta_true=None, out
     return y
 
 
+def synth_linear32(seed, row0, n, p, sigma=1.0, ones_col=False, beta_true=None, out=None, out_y=None, response=True):
+    """fp32-native linear rows, features AND response in one launch (dlsa_synth_linear_f32: x ~ N(0, 1/12) from four 24-bit
+    uniforms per Philox call, y = x . beta* + sigma N(0,1), everything in fp32 with the device's transcendental instructions).
+    The chunk generator of the streaming map step at config 5's size: 4x cheaper than synth(kind=GAUSSIAN, float32) +
+    synth_response.  Returns (X [n, p (+1)], y [n] or None)."""
+    lib = _lib.load()
+    cols = p + (1 if ones_col else 0)
+    X = out if out is not None else empty_rows(n, cols, torch.float32, "cuda")
+    _require_gpu(X, beta_true, out_y)
+    _f64(X, "X", torch.float32); _f64(beta_true, "beta_true", torch.float32); _f64(out_y, "out_y", torch.float32)
+    if tuple(X.shape) != (n, cols) or (beta_true is not None and beta_true.numel() != cols):
+        raise ValueError("synth_linear32: X must be [n, p (+1)] and beta_true have p (+1) elements")
+    y = None
+    if response:
+        y = out_y if out_y is not None else torch.empty((n,), dtype=torch.float32, device=X.device)
+        if y.numel() != n:
+            raise ValueError("synth_linear32: y must have n elements")
+    check(lib.dlsa_synth_linear_f32(seed, row0, n, p, 1 if ones_col else 0, _ptr(X), _rowmajor(X), _ptr(beta_true), float(sigma),
+                                    _ptr(y), _stream()))
+    return X, y
+
+
 def design(num, codes, kind, src, level, shift, scale, dtype=torch.float64, out=None):
     """Dense design matrix from raw numeric columns + integer level codes (models.py:56-104,121-122).
     num [n,q] (dtype) or None, codes [n,f] int32 or None; kind/src/level int32 [p], shift/scale fp64 [p]

@@ -10,6 +10,7 @@ Fitting difference (deliberate, SURVEY.md finding 1): the reference stops sklear
 tol=1e-4, ~1e-3 away from the MLE; this engine returns the exact MLE (Newton/IRLS to a 1e-13
 step), which is what the reference computes when its tolerance is tightened.
 """
+import os
 import warnings
 
 import numpy as np
@@ -232,6 +233,8 @@ class _LinearBlock:
         self.rows = 0
 
     def add(self, Xc, yc):
+        # (the X'y pass on a second stream next to the Gram of the same chunk was measured in round 4: 2.139 vs 2.141 s for config 5's
+        # stream -- kernels on two streams do run side by side here, but take the sum of their times; bench/overlap_probe.py)
         first = self.rows == 0
         if Xc.dtype == torch.float32:
             engine.gram_acc64(Xc, None, out=self.HX, accumulate=not first)
@@ -315,15 +318,22 @@ def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=2026010
     pure function of (seed, i); y = X beta* + sigma N(0,1) by dlsa_synth_response_*), each chunk goes once through the Gram
     kernel (accumulating) and once through the X'y pass, and is overwritten by the next.  The K partitions are contiguous
     row ranges of the stream (the layout repartition(K, "partition_id") gives, logistic_dlsa.py:295); chunks never straddle
-    a partition.  Peak memory = one chunk buffer + K blocks.  overlap=True generates chunk i + 1 into a second buffer on a side
-    stream while chunk i is consumed; measured at config 5's size it buys 2 % (2.75 -> 2.69 s for 6.25e7 rows: the wide Gram
-    kernel holds every CU's registers and LDS, so the generator's workgroups wait for it either way) for twice the chunk
-    memory -- off by default.  Returns MappedBlocks (fp64 blocks)."""
+    a partition.  Peak memory = one chunk buffer + K blocks.  kind="gaussian32" (fp32 only) is the fp32-native stream: features and
+    response in ONE launch (engine.synth_linear32), 8.5 ms per 2^22 x 2000 chunk where "gaussian" + synth_response take 41 -- config 5
+    at its stated size 2.58 -> 2.11 s (97 -> 119 TF including generation).  overlap=True generates chunk i + 1 into a second buffer on
+    a side stream while chunk i is consumed: the kernels do run side by side, but generator and Gram together take the SUM of their
+    times (VALU work is not hidden under the fp32 matrix pipe on this chip, bench/overlap_probe.py: 120.1 + 41.2 -> 161.3 ms) for
+    twice the chunk memory -- off by default.  Returns MappedBlocks (fp64 blocks)."""
     K = int(partition_num)
     n, p, chunk_rows = int(n), int(p), int(chunk_rows)
     if K < 1 or n < 0 or chunk_rows < 1:
         raise ValueError("fit_linear_streaming: need partition_num >= 1, n >= 0, chunk_rows >= 1")
-    kind_id = {"uniform": engine.SYNTH_UNIFORM, "gaussian": engine.SYNTH_GAUSSIAN}[kind] if isinstance(kind, str) else int(kind)
+    # kind "gaussian32": the fp32-native stream (engine.synth_linear32: features and response in ONE launch, a quarter of the
+    # generator time of "gaussian" + synth_response at p = 2000) -- fp32 only
+    native32 = isinstance(kind, str) and kind == "gaussian32"
+    if native32 and dtype != torch.float32:
+        raise ValueError("fit_linear_streaming: kind='gaussian32' is the fp32-native stream (dtype=torch.float32)")
+    kind_id = 0 if native32 else ({"uniform": engine.SYNTH_UNIFORM, "gaussian": engine.SYNTH_GAUSSIAN}[kind] if isinstance(kind, str) else int(kind))
     pp = p + (1 if fit_intercept else 0)
     if names is None:
         names = ["x" + str(i) for i in range(p)]
@@ -350,8 +360,11 @@ def fit_linear_streaming(n, p, partition_num=1, chunk_rows=1 << 22, seed=2026010
         with torch.cuda.stream(side):
             if i >= nbuf:
                 side.wait_event(done[b])             # the kernels that read this buffer two chunks ago have finished
-            engine.synth(seed, row0 + r, m, p, kind=kind_id, labels=False, dtype=dtype, out=Xbuf[b][:m])
-            engine.synth_response(seed, row0 + r, Xbuf[b][:m], sigma=sigma, out=ybuf[b][:m])
+            if native32:
+                engine.synth_linear32(seed, row0 + r, m, p, sigma=sigma, out=Xbuf[b][:m], out_y=ybuf[b][:m])
+            else:
+                engine.synth(seed, row0 + r, m, p, kind=kind_id, labels=False, dtype=dtype, out=Xbuf[b][:m])
+                engine.synth_response(seed, row0 + r, Xbuf[b][:m], sigma=sigma, out=ybuf[b][:m])
             ready[b].record(side)
 
     blocks = [None] * K

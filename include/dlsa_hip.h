@@ -69,6 +69,15 @@ int dlsa_synth_response_f64(uint64_t seed, int64_t row0, int64_t n, int p, int o
                             const double* beta_true, double sigma, double* y, void* stream);
 int dlsa_synth_response_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, const float* X, int64_t ldx,
                             const float* beta_true, double sigma, float* y, void* stream);
+/* fp32-NATIVE linear rows, features and response in ONE launch (config 5's stream at its stated size: the chunk generator inside
+ * the streaming map step, dlsa_amd.fit_linear_streaming(kind="gaussian32")).  Same model as the two calls above -- x ~ N(0, 1/12),
+ * y = x . beta_true + sigma N(0,1), beta_true nullable = first int(0.4p) coefficients 1 -- on its own counter streams
+ * (quad q of row i: Philox counter (i_lo, i_hi, q, 3), key (seed, 0), four 24-bit uniforms -> two Box-Muller pairs; noise:
+ * counter (i_lo, i_hi, 0, 4), key (seed+1, 0)), every value formed in fp32 with the device's log2 / sqrt / sin / cos
+ * instructions: a row is a pure function of (seed, i); the oracle's numpy fp32 restatement agrees to ~1e-6 absolute.
+ * y nullable.  Replaces nothing in the reference (it has no linear simulator): bench / test data only. */
+int dlsa_synth_linear_f32(uint64_t seed, int64_t row0, int64_t n, int p, int ones_col, float* X, int64_t ldx,
+                          const float* beta_true, double sigma, float* y, void* stream);
 
 /* ---- K3: weighted tall-skinny Gram  H = X' diag(w) X  (dlsa/models.py:130) ------------
  * X: n x p, w: n (NULL = all ones, the linear-model X'X), H: p x p (ldh >= p), both

@@ -158,6 +158,67 @@ def test_linear_streaming_config5_width_bounded_memory(eng):
     assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.03
 
 
+@pytest.mark.parametrize("n,p,ones_col,row0", [(3000, 40, False, 0), (1111, 2000, False, 12345678901), (700, 37, False, 5), (900, 22, True, 64)])
+def test_synth_linear32_matches_oracle_restatement(eng, orc, n, p, ones_col, row0):
+    """the fp32-native linear stream (dlsa_synth_linear_f32): same Philox words as the oracle's numpy restatement, the transcendental
+    steps by the device's fp32 instructions -- agreement to a few fp32 ulps of the value scale, not bit for bit"""
+    seed = 424242
+    X, y = eng.synth_linear32(seed, row0, n, p, sigma=0.7, ones_col=ones_col)
+    Xo, yo = orc.synth_linear32(seed, row0, n, p, sigma=0.7)
+    Xg = X.cpu().numpy()
+    if ones_col:
+        assert np.all(Xg[:, 0] == 1.0)
+        Xg = Xg[:, 1:]
+    assert Xg.shape == Xo.shape and np.max(np.abs(Xg - Xo)) < 3e-6
+    # the response: the device sums its own fp32 features in fp32, lane by lane
+    yref = Xg.astype(np.float64) @ orc.true_beta(p) + (yo.astype(np.float64) - Xo.astype(np.float64) @ orc.true_beta(p))
+    assert np.max(np.abs(y.cpu().numpy() - yref)) < 2e-5 * max(1.0, np.sqrt(p))
+    # a row is a function of (seed, row index): two half calls give the same bits as one call
+    h = n // 2
+    Xa, ya = eng.synth_linear32(seed, row0, h, p, sigma=0.7, ones_col=ones_col)
+    Xb, yb = eng.synth_linear32(seed, row0 + h, n - h, p, sigma=0.7, ones_col=ones_col)
+    assert torch.equal(torch.cat([Xa, Xb]), X) and torch.equal(torch.cat([ya, yb]), y)
+
+
+def test_synth_linear32_moments_and_explicit_beta(eng):
+    n, p = 400000, 16
+    beta = torch.linspace(-1.0, 1.0, p, dtype=torch.float32, device="cuda")
+    X, y = eng.synth_linear32(9, 0, n, p, sigma=2.0, beta_true=beta)
+    Xd = X.double()
+    assert float(Xd.mean().abs()) < 2e-3 and abs(float(Xd.var()) - 1.0 / 12.0) < 2e-3
+    C = (Xd.T @ Xd / n - torch.eye(p, dtype=torch.float64, device="cuda") / 12.0).abs().max()
+    assert float(C) < 2e-3                                                           # columns (and the two Box-Muller outputs) uncorrelated
+    resid = y.double() - Xd @ beta.double()
+    assert abs(float(resid.mean())) < 0.02 and abs(float(resid.std()) - 2.0) < 0.02
+
+
+def test_linear_streaming_config5_stated_size(eng):
+    """BASELINE config 5 at its STATED per-GPU size: 6.25e7 x 2000 fp32 = 500 GB of rows generated on the device (fp32-native stream)
+    and streamed through one chunk buffer.  Properties: bounded memory, the generating coefficients recovered, and the same
+    stream summed with a different chunk size gives the same blocks to fp64 round-off of the fp32 partial Grams."""
+    import dlsa_amd
+    from conftest import _free_device_cache
+    _free_device_cache()
+    n, p, K = 62_500_000, 2000, 8
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    mb = dlsa_amd.fit_linear_streaming(n, p, partition_num=K, chunk_rows=1 << 22, fit_intercept=True, kind="gaussian32")
+    peak = torch.cuda.max_memory_allocated() - base
+    assert mb.status == [0] * K
+    assert peak < 40e9, "peak %.2f GB" % (peak / 1e9)
+    assert eng.gram_last_kernel()[0].startswith("gram_wide_f32_kernel")
+    out = dlsa_amd.dlsa_mapred(mb)
+    truth = np.concatenate([[0.0], np.ones(800), np.zeros(1200)])
+    assert float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth))) < 0.004
+    # one partition of the same stream (rows 0 .. n/K) with another chunking: same rows, other fp32 slab partials
+    n1 = n // K
+    a = dlsa_amd.fit_linear_streaming(n1, p, partition_num=1, chunk_rows=1 << 22, fit_intercept=True, kind="gaussian32")
+    b = dlsa_amd.fit_linear_streaming(n1, p, partition_num=1, chunk_rows=3_000_000, fit_intercept=True, kind="gaussian32")
+    Sa, Sb = a.Sig_inv[0].cpu().numpy(), b.Sig_inv[0].cpu().numpy()
+    assert rel_inf(Sa, Sb) < 5e-6 and rel_inf(Sa, mb.Sig_inv[0].cpu().numpy()) < 5e-6
+    assert rel_inf(a.coef[0].cpu().numpy(), b.coef[0].cpu().numpy()) < 1e-3         # coefficients of size <= 1 with sd ~ 1.2e-3 each
+
+
 def test_linear_edge_cases_empty_rows_and_partitions(eng):
     import dlsa_amd
     X = torch.randn((0, 12), dtype=torch.float64, device="cuda")
