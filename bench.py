@@ -20,6 +20,11 @@ value = total rows of all ranks / max-over-ranks time.
 The same JSON line carries `roofline` (Gram kernel vs the fp64 MFMA peak, HIP-event timed on the launch stream),
 `allreduce` (the collective, timed inside the steps and on its own), `cpu_baseline` (the numpy oracle of the hot
 path on the host cores, bounded sample; N=1 only) and `extra` (the HBM-bound logit pass, optionally the whole fit).
+
+Order of an N = 1 run: generate the shard -> W + K steps (`value`) -> the same launch until the GPU has been busy for
+--sustain-seconds (`sustained_block`) -> the CPU baseline in freshly spawned interpreters -> the K steps once more
+(`second_block`).  N > 1 starts with a PREFLIGHT per rank (devices, free HBM, communicator and one 8-byte all-reduce under
+60 s watchdogs: a one-line reason and a non-zero exit, never a hang); `--preflight` runs only that.
 """
 import argparse
 import hashlib
@@ -56,6 +61,12 @@ def parse(argv=None):
                          "TOTAL rows fixed at --rows-per-gpu, split evenly over the ranks (SURVEY 8(d) scaling report)")
     ap.add_argument("--e2e-partitions", type=int, default=25,
                     help="partitions per rank of the end-to-end fit (25 x 1e6 rows: logistic_dlsa.py:170 on config 3's shard)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="only the N-rank preflight (device count, free HBM for the shard, RCCL communicator + one 8-byte all-reduce, each\n"
+                         "under a 60 s watchdog): exit code 0 and one line per rank, or non-zero with the reason -- never hangs")
+    ap.add_argument("--sustain-seconds", type=float, default=12.0,
+                    help="after the K timed steps keep launching the same Gram pass until the GPU has been busy this long (N = 1): the\n"
+                         "driver's utilisation sampler sees the run, and the line carries the sustained ms_per_step")
     ap.add_argument("--cpu-rows-per-partition", type=int, default=0, help="0 = sized by oracle/cpu_baseline.py")
     ap.add_argument("--cpu-gram-rows", type=int, default=400_000)
     return ap.parse_args(argv)
@@ -72,10 +83,16 @@ def _free_port():
     return port
 
 
+def rank_threads(ncpu, nranks):
+    """Host threads a rank may use for OpenMP / torch intra-op work: the node's cores shared out over the ranks, at most 8 (the
+    library's own partition chains are <= 4 std::threads per rank that sleep in hipStreamSynchronize: 8 ranks x 4 on any node)."""
+    return max(1, min(8, int(ncpu) // max(1, int(nranks))))
+
+
 def launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it here
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", str(rank_threads(os.cpu_count() or 8, args.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
@@ -87,6 +104,8 @@ def launch(args):
             line = s
         else:
             print(ln, file=sys.stderr)
+    if args.preflight:                 # no JSON line: the ranks' own exit codes and one-line reasons are the result
+        return proc.returncode
     if proc.returncode != 0 or line is None:
         print("[bench] the %d-rank run failed (exit code %d, %s JSON line)" %
               (args.gpus, proc.returncode, "no" if line is None else "a"), file=sys.stderr)
@@ -136,6 +155,67 @@ def traffic_from_profile(p, R):
         return None, "unavailable: %r" % (e,)
 
 
+def _watchdog(seconds, what, rank):
+    """Run-once timer: if `what` has not finished in time the rank says so and leaves with a non-zero code (no hang)."""
+    import threading
+
+    def fire():
+        print("[bench] preflight FAILED on rank %d: %s did not finish within %.0f s" % (rank, what, seconds), file=sys.stderr, flush=True)
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def preflight(args, rank, world, local, timeout_s=60.0):
+    """What the first N-GPU run could trip over, checked up front with a one-line reason and a non-zero exit instead of a hang:
+    enough devices, enough free HBM for this rank's shard, the communicator (RCCL unless DLSA_BENCH_BACKEND=gloo) and ONE 8-byte
+    all-reduce.  Returns (torch.distributed or None, backend)."""
+    import datetime
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("[bench] preflight FAILED on rank %d: no GPU visible" % rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("DLSA_BENCH_BACKEND", "nccl")      # "gloo": lets ranks share one GPU in a dry run
+    if backend == "nccl" and ndev < world:
+        raise SystemExit("[bench] preflight FAILED on rank %d: %d ranks over RCCL need %d GPUs, this node shows %d "
+                         "(DLSA_BENCH_BACKEND=gloo lets ranks share a GPU for a dry run)" % (rank, world, world, ndev))
+    torch.cuda.set_device(local % max(1, ndev))
+    sharing = max(1, (world + ndev - 1) // max(1, ndev))
+    free, total = torch.cuda.mem_get_info()
+    need = args.rows_per_gpu * args.p * 8 * 1.08
+    if backend == "nccl" and need > free:
+        raise SystemExit("[bench] preflight FAILED on rank %d: the shard needs %.1f GB of HBM, device %d has %.1f GB free of %.1f "
+                         "(another process on the GPU?)" % (rank, need / 1e9, local, free / 1e9, total / 1e9))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        wd = _watchdog(timeout_s, "init_process_group(%s)" % backend, rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=timeout_s))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        wd.cancel()
+        wd = _watchdog(timeout_s, "the first all-reduce (8 bytes)", rank)
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one)
+        torch.cuda.synchronize()
+        wd.cancel()
+        if int(one.item()) != world:
+            raise SystemExit("[bench] preflight FAILED on rank %d: the 8-byte all-reduce returned %r, expected %d" % (rank, one.item(), world))
+    print("[bench] preflight ok: rank %d/%d device %d of %d, %.1f GB free, backend %s%s" % (
+        rank, world, local % max(1, ndev), ndev, free / 1e9, backend if world > 1 else "-", " (%d ranks per GPU)" % sharing if sharing > 1 else ""),
+        file=sys.stderr, flush=True)
+    if args.preflight and dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return dist, backend
+
+
 def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,40 +224,18 @@ def worker(args):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches the "
                          "ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
     p = args.p
-
-    # ---- CPU baseline first (rank 0, N=1 only): its worker processes are started before this process initialises
-    # the GPU, and it does not share the host with the GPU timing below
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # a REPORTED reference point: its failure (a worker, the pool's barrier, a missing gcc / liboracle_synth, host memory)
-        # must not cost the primary GPU line
-        try:
-            from oracle import cpu_baseline
-            cpu = cpu_baseline.run(p, args.seed, rows_per_partition=args.cpu_rows_per_partition or None,
-                                   gram_rows=args.cpu_gram_rows)
-        except BaseException as e:      # incl. SystemExit / BrokenBarrierError from the pool
-            if isinstance(e, KeyboardInterrupt):
-                raise
-            print("[bench] cpu_baseline failed: %r" % (e,), file=sys.stderr)
-            cpu = {"error": repr(e)}
+    cpu = None        # the CPU baseline runs AFTER the first GPU block (its pool uses spawned interpreters: safe once the GPU is up)
 
     import torch
+    torch.set_num_threads(rank_threads(os.cpu_count() or 8, world))
+    dist, backend = None, None
+    if world > 1 or args.preflight:
+        dist, backend = preflight(args, rank, world, local)
+        if args.preflight:
+            return 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local % max(1, ndev))
-    dist, backend = None, None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DLSA_BENCH_BACKEND", "nccl")      # "gloo": lets two ranks share one GPU in a dry run
-        if backend == "nccl":
-            if ndev < world:
-                raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (DLSA_BENCH_BACKEND=gloo "
-                                 "lets ranks share a GPU for a dry run)" % (world, world, ndev))
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
     from dlsa_amd import engine
 
     R = args.rows_per_gpu
@@ -258,6 +316,35 @@ def worker(args):
     clock_ghz = cycles / (last_ms * 1e-3) / 1e9 if cycles else None
     kern_ranks = per_rank(kern_ms)
     clock_ranks = per_rank(clock_ghz or 0.0)
+    if world > 1 and rank == 0 and kern_ranks["min"] > 0 and kern_ranks["max"] / kern_ranks["min"] > 1.05:
+        slow = max(range(world), key=lambda r: kern_ranks["per_rank"][r])
+        print("[bench] kernel time differs by %.1f %% over the ranks: rank %d is the slowest (%.2f ms, shader clock %.2f GHz; fastest %.2f ms)"
+              % ((kern_ranks["max"] / kern_ranks["min"] - 1) * 100, slow, kern_ranks["max"], clock_ranks["per_rank"][slow], kern_ranks["min"]),
+              file=sys.stderr, flush=True)
+
+    # ---- N = 1: the same launches again until the GPU has been busy for --sustain-seconds (the driver's utilisation sampler sees the
+    # run; the rate a long job holds), THEN the CPU baseline (fresh spawned interpreters, the GPU idle), then the K steps a second time
+    sustained = second_block = None
+    if world == 1 and args.sustain_seconds > 0:
+        nsus = int(max(0.0, args.sustain_seconds - elapsed) / max(1e-6, kern_ms * 1e-3))
+        if nsus > 0:
+            s_el, s_kern, _, _ = timed_steps(X, w, nsus, 0)
+            sustained = {"steps": nsus, "seconds": s_el, "ms_per_step": s_el / nsus * 1e3, "kernel_ms": s_kern, "value": R * nsus / s_el}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # a REPORTED reference point: its failure (a worker, the pool's barrier, a missing gcc / liboracle_synth, host memory)
+        # must not cost the primary GPU line
+        try:
+            from oracle import cpu_baseline
+            cpu = cpu_baseline.run(p, args.seed, rows_per_partition=args.cpu_rows_per_partition or None,
+                                   gram_rows=args.cpu_gram_rows)
+        except BaseException as e:      # incl. SystemExit / BrokenBarrierError from the pool
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            print("[bench] cpu_baseline failed: %r" % (e,), file=sys.stderr)
+            cpu = {"error": repr(e)}
+        b_el, b_kern, _, _ = timed_steps(X, w, args.steps, 1)
+        second_block = {"steps": args.steps, "ms_per_step": b_el / args.steps * 1e3, "kernel_ms": b_kern, "value": R * args.steps / b_el,
+                        "note": "the same K steps once more after the CPU baseline (GPU cold again): the line's `value` is the FIRST block"}
 
     # ---- strong scaling leg (N > 1): the SAME total rows as one GPU's shard, split evenly over the ranks
     strong = None
@@ -303,6 +390,8 @@ def worker(args):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": world if backend == "nccl" else 0,
+            "value_per_gpu": value / world,          # weak scaling: compare with the N = 1 line's value
+            "sustained_block": sustained, "second_block": second_block,
             "config": {"workload": "Logistic DLSA config 3 per-GPU row shard: synthetic Gaussian n=%d x p=%d fp64 "
                                    "per GPU (%.1f GB in HBM), weighted Gram X'WX pass%s" %
                                    (R, p, R * p * 8 / 1e9, " + 1 all-reduce of p^2+2p f64 (%s)" %

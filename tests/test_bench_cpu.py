@@ -117,3 +117,47 @@ def test_committed_traffic_profile_matches_the_tree():
     assert prof.get("gram_hip_sha16") == bench.gram_sources_sha16(), "stale profiles/pmc_latest.json"
     t, _ = bench.traffic_from_profile(500, 25_000_000)
     assert 0.99 * 25e6 * 4008 < t < 1.05 * 25e6 * 4008          # fabric traffic ~ the algorithmic bytes of the launch
+
+
+def test_rank_threads_never_oversubscribe_the_host():
+    """N ranks x (OpenMP / torch intra-op threads) stay within the node's cores; the launcher exports it."""
+    bench = _load_bench()
+    for ncpu in (8, 64, 128, 256):
+        for n in (1, 2, 4, 8):
+            t = bench.rank_threads(ncpu, n)
+            assert 1 <= t <= 8 and t * n <= max(ncpu, n)
+    assert bench.rank_threads(8, 8) == 1 and bench.rank_threads(256, 8) == 8 and bench.rank_threads(4, 8) == 1
+
+
+def test_launcher_exports_the_per_rank_thread_count(monkeypatch):
+    bench = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["env"] = env
+        return types.SimpleNamespace(returncode=0, stdout=json.dumps({"metric": "m", "n_gpus": 8}) + "\n")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 16)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    for v in ("WORLD_SIZE", "OMP_NUM_THREADS"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.main() == 0
+    assert seen["env"]["OMP_NUM_THREADS"] == "2"
+
+
+def test_bench_arguments_round4():
+    bench = _load_bench()
+    a = bench.parse([])
+    assert a.preflight is False and a.sustain_seconds == 12.0
+    assert bench.parse(["--preflight", "--gpus", "8"]).preflight is True
+
+
+def test_preflight_only_run_needs_no_json_line(monkeypatch):
+    bench = _load_bench()
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="[bench] preflight ok\n"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--preflight"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main() == 0
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=3, stdout=""))
+    assert bench.main() == 3
