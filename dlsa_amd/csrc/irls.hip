@@ -70,7 +70,7 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
                            const double* y, const double* beta, int64_t n, double* w_out, double* g, double* loglik,
                            void* ws, size_t ws_bytes, hipStream_t s);
 int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
-                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s);
+                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s, bool irls_weights);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
 
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
@@ -904,6 +904,9 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
                 DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Linv, c0.b.Linv, ppb, hipMemcpyDeviceToDevice, s0));
                 DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Hinv, c0.b.Hinv, ppb, hipMemcpyDeviceToDevice, s0));
                 DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.Hpool, c0.b.Hpool, ppb, hipMemcpyDeviceToDevice, s0));
+                // (the pooled factor's refresh solves against b.g before the chain's first pass has written it: a defined right-hand side,
+                // or the discarded solution's finiteness check would depend on what the workspace held)
+                DLSA_HIP_CHECK(hipMemcpyAsync(cs.b.g, c0.b.g, pb, hipMemcpyDeviceToDevice, s0));
                 cs.inv_valid_flag = c0.inv_valid_flag;
                 cs.have_warm = c0.have_warm;
                 cs.factor_rows = c0.factor_rows;
@@ -1138,7 +1141,7 @@ int dlsa_onehot_irls_fit_f64(const dlsa_onehot_plan* plan, const double* num, in
             return onehot_logit_pass_impl(plan, numk, ldn, codesk, ldc, yk, beta, nrows, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
         };
         d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
-            return onehot_gram_impl(plan, numk, ldn, codesk, ldc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s);
+            return onehot_gram_impl(plan, numk, ldn, codesk, ldc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s, true);
         };
         return d;
     };
@@ -1196,7 +1199,7 @@ int dlsa_onehot_irls_fit_ex_f64(const dlsa_onehot_plan* plan, const double* num,
             return onehot_logit_pass_impl(plan, numk, pn, codesk, pc, yk, beta, nrows, w, g, ll, b.ws_pass, b.ws_pass_bytes, s);
         };
         d.gram = [=](const double* w, int64_t nrows, double* H, const IrlsBuffers& b, hipStream_t s) {
-            return onehot_gram_impl(plan, numk, pn, codesk, pc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s);
+            return onehot_gram_impl(plan, numk, pn, codesk, pc, w, nrows, H, p, b.ws_pass, b.ws_pass_bytes, s, true);
         };
         return d;
     };

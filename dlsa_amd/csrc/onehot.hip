@@ -479,8 +479,12 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
     return DLSA_OK;
 }
 
+// irls_weights: w are the logistic weights mu (1 - mu) in (0, 1/4] of this library's own logit pass (the IRLS driver) -- the addends'
+// scale is known and the exact fixed-point sums (absolute resolution 2^-40) are the default.  A CALLER's weights (the public
+// dlsa_onehot_gram) may have any scale -- w ~ 1e-8 would keep five digits, w < 4.5e-13 none -- so they are summed in ordered
+// floating point (full fp64 relative accuracy at any scale, also bit-reproducible, slower).
 int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
-                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s) {
+                     const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s, bool irls_weights) {
     DLSA_REQUIRE(pl && H && ldh >= pl->desc.p && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot gram: null argument or ldh < p");
     OhDesc ds = pl->desc;
@@ -490,7 +494,7 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
 #endif
     // accumulation mode of the LDS tables: exact fixed-point (2, the default), ordered floating point (DLSA_OH_ORDERED=1),
     // unordered floating point (DLSA_OH_ORDERED=0)
-    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0 ? 1 : 0) : 2; }
+    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0 ? 1 : 0) : (irls_weights || !w ? 2 : 1); }
     const size_t ws_need = onehot_workspace_bytes_impl(pl, n);
     if (!ws || ws_bytes < ws_need || ((uintptr_t)ws & 255)) {
         set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", ws_need, ws_bytes);
@@ -643,7 +647,7 @@ int dlsa_onehot_logit_pass_f64(const dlsa_onehot_plan* pl, const double* num, in
 
 int dlsa_onehot_gram_f64(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
                          const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, void* stream) {
-    return dlsa::onehot_gram_impl(pl, num, ldn, codes, ldc, w, n, H, ldh, ws, ws_bytes, (hipStream_t)stream);
+    return dlsa::onehot_gram_impl(pl, num, ldn, codes, ldc, w, n, H, ldh, ws, ws_bytes, (hipStream_t)stream, false);
 }
 
 }  // extern "C"

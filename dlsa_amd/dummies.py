@@ -57,8 +57,12 @@ def select_dummy_factors(dummy_dict, keep_top, replace_with, pickle_file=None):
     dummy_info = {"factor_set": factor_set, "factor_selected": factor_selected, "factor_dropped": factor_dropped,
                   "factor_selected_names": factor_selected_names}
     if pickle_file:
-        with open(os.path.expanduser(pickle_file), "wb") as f:
+        # written next to its place and renamed: another rank (or job) that finds the file finds all of it
+        path = os.path.expanduser(pickle_file)
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
             pickle.dump(dummy_info, f)
+        os.replace(tmp, path)
         print("dummy_info saved in:\t" + pickle_file)
     return dummy_info
 

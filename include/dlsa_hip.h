@@ -269,7 +269,10 @@ int dlsa_design_f32(const float* num, int64_t ldn, int q, const int32_t* codes, 
  * nlevels[t] level codes each; level_col (concatenated over the factors) gives the output column of every level,
  * -1 for a level without a column (baseline / dropped).  All descriptor arrays are HOST arrays.  Plan creation
  * fails with DLSA_ERR_INVALID when a factor-pair table does not fit the per-workgroup LDS budget (use the dense
- * path then).  Accumulation uses LDS atomics: results are not bit-reproducible run to run (last-bit differences). */
+ * path then).  Accumulation: the Hessian inside dlsa_onehot_irls_fit_* (weights mu (1 - mu) <= 1/4 of the library's own logit pass)
+ * sums exact 64-bit fixed-point addends of absolute resolution 2^-40 in LDS -- order-independent, bit-reproducible; the public
+ * dlsa_onehot_gram_f64, whose caller may bring weights of ANY scale, sums in ordered floating point (full fp64 relative accuracy
+ * whatever the scale of w, also bit-reproducible, about 1.8x the time).  DLSA_OH_ORDERED=0 / 1 forces unordered / ordered adds. */
 typedef struct dlsa_onehot_plan dlsa_onehot_plan;
 int dlsa_onehot_plan_create(int p, int ndense, const int32_t* dense_kind, const int32_t* dense_src,
                             const double* dense_shift, const double* dense_scale, const int32_t* dense_col,

@@ -76,6 +76,8 @@ def main():
         n = len(pdf)
         if dummy_columns:
             path = os.path.expanduser(args.dummy_info) if args.dummy_info else ""
+            # every rank decides by itself: the table is a function of the input files, so a rank that finds rank 0's freshly written
+            # copy (os.replace: complete or absent) loads what it would have computed
             if path and os.path.exists(path):
                 with open(path, "rb") as f:
                     dummy_info = pickle.load(f)
@@ -93,8 +95,9 @@ def main():
             data_info = pd.read_csv(path)
         else:
             data_info = ingest.data_info_from_frame(pdf, numeric_cols)
-            if path and rank == 0:
-                data_info.to_csv(path, index=False)
+            if path and rank == 0:                     # (renamed into place: a rank that finds the table finds all of it)
+                data_info.to_csv(path + ".tmp.%d" % os.getpid(), index=False)
+                os.replace(path + ".tmp.%d" % os.getpid(), path)
         sh = ingest.shard_from_frame(pdf, Y_name, dummy_info, baseline, data_info, args.fit_intercept,
                                      sample_size_per_partition=args.sample_size_per_partition, world=world, rank=rank)
         del pdf

@@ -74,6 +74,19 @@ def test_reference_call_sequence_matches_golden(api, orc, name):
     by_aic, by_bic, _ = orc.dlsa(z["Sig_inv_sum"], z["beta_byOLS"], X.shape[0], fit_intercept=icpt)
     assert rel_inf(out["beta_byAIC"], by_aic) < 1e-8
     assert rel_inf(out["beta_byBIC"], by_bic) < 1e-8
+    if icpt:
+        # the beta_0 convention (the rpy2 line dlsa.py:97: beta0[idx] + b0[0]; the shipped Python crashes there, D2-D5): at the
+        # unshrunk END of the path the selected vector must be the WLS estimate itself, intercept included -- whatever the
+        # criterion picked -- and the reported intercept moves with the path by exactly -Sigma_00^-1 Sigma_0. (beta - beta_WLS)
+        # (lsa.py:98-104: the intercept is profiled out of the quadratic)
+        S, b = mr.iloc[:, 2:].to_numpy(), mr["beta_byOLS"].to_numpy()
+        path = api.lars_lsa(S, b, True, X.shape[0])
+        beta, beta0 = np.asarray(path["beta"]), np.asarray(path["beta0"])
+        assert rel_inf(beta[-1], b[1:]) < 1e-8 and abs(beta0[-1]) < 1e-8 * max(1.0, abs(b[0]))
+        prof = -(beta - b[1:][None, :]) @ S[0, 1:] / S[0, 0]
+        assert np.max(np.abs(beta0 - prof)) < 1e-8 * max(1.0, np.max(np.abs(prof)))
+        ib = int(np.argmin(np.asarray(path["BIC"])))
+        assert abs(float(out["beta_byBIC"].iloc[0]) - (beta0[ib] + b[0])) < 1e-10 * max(1.0, abs(b[0]))
 
 
 def test_tensor_fast_path_equals_frame_path(api, orc):

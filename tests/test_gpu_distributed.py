@@ -44,14 +44,16 @@ def _worker(rank, world, port, K, n, p, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,K", [(2, 6), (8, 16)])
+@pytest.mark.parametrize("world,K", [(2, 6), (8, 16), (8, 200)])
 def test_ranks_sharing_one_gpu_full_path(tmp_path, world, K):
     """2 ranks, and the 8 ranks of the driver's node (a dry run: gloo transport, all ranks on the one GPU of the test box,
     small rows): GPU g owns the partitions {k : k % G == g}, every rank fits its own, ONE all-reduce, every rank
-    solves + shrinks redundantly -- and every rank ends with the single-process oracle's result."""
+    solves + shrinks redundantly -- and every rank ends with the single-process oracle's result.  (8, 200) is config 3's
+    geometry on one node -- 200 partitions (logistic_dlsa.py:170 at n = 2e8), 25 per rank, at reduced rows: the one-shot mean
+    divides by the 200 partitions of the whole job (dlsa.py:51-52), not by a rank's 25."""
     import torch.multiprocessing as mp
     from oracle import dlsa_oracle as orc
-    n, p = 24000, 12
+    n, p = (24000, 12) if K < 100 else (80000, 10)
     mp.spawn(_worker, args=(world, _free_port(), K, n, p, str(tmp_path)), nprocs=world, join=True)
     X, y = orc.synth_logistic(314, 0, n, p)
     parts = orc.partition_rows(n, K)
@@ -63,6 +65,7 @@ def test_ranks_sharing_one_gpu_full_path(tmp_path, world, K):
         rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
         assert rel(z["ols"], ols) < 1e-10
         assert rel(z["oneshot"], oneshot) < 1e-10
+        assert rel(z["oneshot"] * K, np.sum([b[0] for b in blocks], axis=0)) < 1e-10          # the divisor is K, the job's partition count
         assert rel(z["S"], S) < 1e-10
         assert rel(z["bic"], by_bic) < 1e-8
 

@@ -172,6 +172,11 @@ def test_onehot_gram_exact_mode_agrees_with_float_modes_and_falls_back_on_overfl
     monkeypatch.delenv("DLSA_OH_ORDERED")
     assert torch.equal(Hb, Hb1) and bool(torch.isfinite(Hb).all())
     assert float((Hb - H1 * 1e6).abs().max()) < 1e-12 * float(Hb.abs().max())
+    # caller weights of a tiny scale keep their RELATIVE accuracy (the fixed-point mode is absolute, 2^-40: w ~ 1e-8 would
+    # keep five digits there, w < 4.5e-13 none -- the public entry sums a caller's weights in ordered floating point)
+    for sc in (1e-8, 1e-14):
+        Hs = engine.onehot_gram(plan, dn, dc, dev(w * sc))
+        assert float((Hs - H1 * sc).abs().max()) < 1e-12 * float(H1.abs().max()) * sc
     # a NaN weight must surface as NaN (through the fall-back), not vanish
     wn = w.copy(); wn[12345] = np.nan
     assert not bool(torch.isfinite(engine.onehot_gram(plan, dn, dc, dev(wn))).all())
