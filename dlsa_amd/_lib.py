@@ -17,8 +17,16 @@ c_vp = ctypes.c_void_p
 c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); every symbol include/dlsa_hip.h declares
+class IrlsOptionsC(ctypes.Structure):
+    """include/dlsa_hip.h: dlsa_irls_options (field for field)"""
+    _fields_ = [(n, c_int) for n in ("struct_bytes", "chains", "seeded", "subsample_div", "factor_div", "warm", "inherit", "pool", "secant",
+                                     "inverse", "predict", "fused", "fuse_last", "small", "qn_threads", "trace")] + [("freeze_at", c_dbl)]
+
+
 SIGNATURES = {
     "dlsa_version": (c_int, []),
+    "dlsa_irls_options_init": (None, [ctypes.POINTER(IrlsOptionsC)]),
+    "dlsa_irls_set_options": (c_int, [ctypes.POINTER(IrlsOptionsC)]),
     "dlsa_last_error": (c_int, [ctypes.c_char_p, c_int]),
     "dlsa_synth_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dlsa_synth_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),

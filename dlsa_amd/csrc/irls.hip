@@ -19,6 +19,7 @@
 // (models.py:114,130); Sig_invMcoef = Sig_inv . coef (models.py:131).  One D2H copy of 4 doubles
 // per iteration is the only host synchronisation.
 #include "common.h"
+#include "options.h"
 #include <math.h>
 #include <algorithm>
 #include <stdlib.h>
@@ -383,12 +384,12 @@ static int factor_ok(const IrlsBuffers& b, hipStream_t s, bool* ok) {
 }
 
 static bool inv_enabled(int p) {
-    const char* e = getenv("DLSA_IRLS_INVERSE");
+    const char* e = knob("DLSA_IRLS_INVERSE");
     return (e ? atoi(e) != 0 : true) && ((size_t)4 * p + 48) * sizeof(double) <= 64 * 1024;
 }
 
 static bool qn_enabled() {
-    const char* e = getenv("DLSA_IRLS_SECANT");
+    const char* e = knob("DLSA_IRLS_SECANT");
     return e ? atoi(e) != 0 : true;
 }
 
@@ -400,7 +401,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                       double freeze_at, double* H, const IrlsBuffers& b, hipStream_t s, int* status, int* iters,
                       int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
     double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY, dprev2 = INFINITY;
-    const char* env_pred = getenv("DLSA_IRLS_PREDICT");
+    const char* env_pred = knob("DLSA_IRLS_PREDICT");
     // prediction leaves Sig_inv / loglik evaluated up to 10 tol away from the returned coef (see below): only when that
     // is far below the 1e-10 parity tolerance, i.e. never for a loose caller-supplied tol
     const bool predict_on = (env_pred ? atoi(env_pred) != 0 : true) && tol <= 1e-10;
@@ -415,7 +416,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     const size_t qn_shm = ((size_t)p + 16) * sizeof(double);
     *status = DLSA_PART_NOT_CONVERGED;
     *fresh = false;
-    const char* env_fl = getenv("DLSA_IRLS_FUSE_LAST");
+    const char* env_fl = knob("DLSA_IRLS_FUSE_LAST");
     const bool can_fuse = d.pass && d.fusable && d.fusable(n);
     const bool fuse_last = can_fuse && (env_fl ? atoi(env_fl) != 0 : true);
     bool peek_next = false;
@@ -471,7 +472,8 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             // One element per thread up to 1024 columns.  Fewer waves make the kernel's ~20 block reductions cheaper, more waves its
             // mat-vec: 512 threads for p <= 512 (bench/qn_threads_ab.sh, average duration inside chained fits: p = 100 58 -> 45 us,
             // p = 260 82 -> 73, p = 500 335 -> 189; 256 threads: 51 / 94 / 357).  DLSA_QN_THREADS overrides.
-            static const int qn_threads_env = getenv("DLSA_QN_THREADS") ? atoi(getenv("DLSA_QN_THREADS")) : 0;
+            const char* qn_e = knob("DLSA_QN_THREADS");
+            const int qn_threads_env = qn_e ? atoi(qn_e) : 0;
             const int qn_default = p <= 512 ? 512 : 1024;
             const int qn_threads = qn_threads_env >= 64 && qn_threads_env <= 1024 && (p <= qn_threads_env || p > 1024) ? qn_threads_env : qn_default;
 #define DLSA_QN_STEP(EPT) hipLaunchKernelGGL(qn_step_kernel<EPT>, dim3(1), dim3(qn_threads), shm, s, (const double*)b.beta, \
@@ -532,7 +534,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
         ll = h[3];
         *loglik = ll;
-        if (getenv("DLSA_IRLS_TRACE")) fprintf(stderr, "[irls] n=%lld it=%d fresh=%d step=%.3e |beta|=%.3e ll=%.10e\n", (long long)n, it, (int)fresh_now, h[0], h[1], ll);
+        if (knob("DLSA_IRLS_TRACE")) fprintf(stderr, "[irls] n=%lld it=%d fresh=%d step=%.3e |beta|=%.3e ll=%.10e\n", (long long)n, it, (int)fresh_now, h[0], h[1], ll);
         if (h[2] == 1.0) { *status = DLSA_PART_NOT_SPD; return DLSA_OK; }
         if (h[2] == 2.0 || !isfinite(ll)) { *status = DLSA_PART_NAN; return DLSA_OK; }
         // safeguard: the previous step overshot (log-likelihood dropped) -> halve it, refresh H
@@ -623,7 +625,7 @@ struct IrlsChain {
 // depend on the overlap (every chain is deterministic; the MLE is unique), only on S, which is a function of the shapes.
 constexpr int IRLS_MAX_CHAINS = 8;          // (the default cap is 4: irls_chain_cap)
 static int irls_chain_cap(int64_t max_rows, double bytes_per_row) {
-    const char* e = getenv("DLSA_IRLS_CHAINS");
+    const char* e = knob("DLSA_IRLS_CHAINS");
     if (e) return std::min(IRLS_MAX_CHAINS, std::max(1, atoi(e)));
     // measured (bench/ab_chains.sh, same box, one chain -> four): 76 MB partitions (config 4 structured) 22.1 -> 14.5 ms, 0.8 GB (config 2,
     // K = 10) 14.6 -> 12.2, 2.1 GB (config 4 dense) 67.3 -> 59.9, 4 GB (config 3, K = 25) 287.5 -> 256.4 seeded (unseeded: 300, the
@@ -633,7 +635,7 @@ static int irls_chain_cap(int64_t max_rows, double bytes_per_row) {
 // Seeding (partition 0 alone, its state copied to every chain) saves S - 1 cold starts but serialises one partition: it pays when
 // a cold start is expensive -- not for the 128 MB raw partitions of a structured design (config 4: 14.5 unseeded, 15.9 seeded).
 static bool irls_chain_seed(int64_t max_rows, double bytes_per_row) {
-    const char* e = getenv("DLSA_IRLS_SEED");
+    const char* e = knob("DLSA_IRLS_SEED");
     if (e) return atoi(e) != 0;
     return (double)max_rows * bytes_per_row >= 2.56e8;
 }
@@ -675,8 +677,8 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
     S = std::max(S, 1);
     hipStream_t s0 = (hipStream_t)stream;
     // tuning knobs for experiments (defaults are the production policy)
-    const char* env_sub = getenv("DLSA_IRLS_SUBSAMPLE");
-    const char* env_frz = getenv("DLSA_IRLS_FREEZE");
+    const char* env_sub = knob("DLSA_IRLS_SUBSAMPLE");
+    const char* env_frz = knob("DLSA_IRLS_FREEZE");
     // 0/1 disables the warm start.  Wide designs (p >= 384) start from the smallest of 1/64, 1/32, 1/16 of the rows that still pins the
     // MLE (>= 200 p rows): at p = 500 the 1/16 subsample's own Newton run (Gram passes over 1.5e6 rows) costs more than its slightly
     // better start buys (bench/ab_subsample.sh, 2.5e7 x 500: 254-255 ms at 16, 241-242 at 64; p = 100: 11.3 ms at 16, 11.8-11.9 at 32-64)
@@ -697,21 +699,21 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
     };
     const double freeze_at = env_frz ? atof(env_frz) : 1.0;    // 0 disables the frozen Hessian
 
-    const char* env_warm = getenv("DLSA_IRLS_WARM");
+    const char* env_warm = knob("DLSA_IRLS_WARM");
     const bool warm_ok = env_warm ? atoi(env_warm) != 0 : true;   // 0 disables partition-to-partition warm starts
-    const char* env_inh = getenv("DLSA_IRLS_INHERIT");
+    const char* env_inh = knob("DLSA_IRLS_INHERIT");
     // Starting from an inherited Cholesky factor trades one Gram pass (~n p^2 flops) for a few more logit passes
     // (~n p bytes each): worth it once the Gram pass costs several logit passes, i.e. for p of a few hundred
     // (measured: 2.5e7 x 500 fit 0.41 -> 0.33 s; at p = 100 the extra iterations cost more than the Gram they save).
     const bool inherit_ok = env_inh ? atoi(env_inh) != 0 : (p >= 192);
-    const char* env_fd = getenv("DLSA_IRLS_FACTOR_DIV");
+    const char* env_fd = knob("DLSA_IRLS_FACTOR_DIV");
     const int fac_div = env_fd ? atoi(env_fd) : 4;              // rows / fac_div feed the stand-in Hessian (0/1: the subsample's)
     // Pooled preconditioner: the exact Hessians of the finished partitions (their Sig_inv, evaluated at their MLEs) are
     // summed, and after 1, 2, 4, 8, ... partitions the sum is factored and replaces the inherited factor.  Partitions of
     // one data set share the population Hessian, so the sum over m partitions misses the next partition's Hessian only by
     // its own sampling noise (~sqrt(p/n_k)) plus 1/sqrt(m) of it -- half the error of the stand-in from a quarter of the
     // first partition -- and the quasi-Newton iterations of every later partition get shorter for O(log K) factorizations.
-    const char* env_pool = getenv("DLSA_IRLS_POOL");
+    const char* env_pool = knob("DLSA_IRLS_POOL");
     const bool pool_ok = (env_pool ? atoi(env_pool) != 0 : true) && inherit_ok && K > 1;
 
     std::vector<IrlsChain> chains((size_t)S);
@@ -925,8 +927,10 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
             DLSA_HIP_CHECK(hipStreamWaitEvent(st[(size_t)c], fork, 0));
         }
         std::vector<std::thread> workers;
+        const dlsa_irls_options caller_opt = irls_options_snapshot();      // the chains' threads run under the caller's options
         for (int c = 1; c < S; ++c)
             workers.emplace_back([&, c]() {
+                irls_options_adopt(caller_opt);
                 IrlsChain& cs = chains[(size_t)c];
                 if (hipSetDevice(dev) != hipSuccess) { cs.rc = DLSA_ERR_HIP; cs.err = "hipSetDevice failed in a chain thread"; return; }
                 cs.rc = run_chain(c, st[(size_t)c]);

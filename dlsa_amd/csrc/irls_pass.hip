@@ -21,6 +21,7 @@
 // Outputs per slab: the H partial (summed by gram.hip's reduce kernel), g and loglik partials (summed in a fixed order by
 // irls_pass_finish_kernel): bit-reproducible run to run.
 #include "common.h"
+#include "options.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -781,7 +782,7 @@ static size_t fp_pp(int p) { return ((size_t)(p + 15) / 16 * 16 + 63) / 64 * 64;
 
 bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p) {
     if (p < FP_MIN_P || p > FP_MAX_P || (p & 1) || n < FP_MIN_ROWS) return false;
-    const char* e = getenv("DLSA_IRLS_FUSED");
+    const char* e = knob("DLSA_IRLS_FUSED");
     if (e && atoi(e) == 0) return false;          // A/B runs: the two-launch form
     int64_t rps;
     fp_slabs(n, rps);

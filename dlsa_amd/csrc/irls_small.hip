@@ -15,6 +15,7 @@
 // Width: p + intercept <= 64 columns (4 tiles per side, 10 accumulator tiles per wave); the implicit intercept is the LAST
 // column inside the kernel and the FIRST one in the outputs (models.py:136-142).
 #include "common.h"
+#include "options.h"
 #include <algorithm>
 #include <math.h>
 #include <vector>
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
 }
 
 bool irls_small_enabled() {
-    const char* e = getenv("DLSA_IRLS_SMALL");       // 0: always the host-driven path (valid results, A/B runs)
+    const char* e = knob("DLSA_IRLS_SMALL");       // 0: always the host-driven path (valid results, A/B runs)
     return e ? atoi(e) != 0 : true;
 }
 
@@ -285,7 +286,7 @@ bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     // the host-driven path fits such partitions on up to four concurrent chains (irls.hip, irls_fit_core): 0.55 ms per partition on one
     // chain, 0.23 on four (K = 20, p = 50, 10000 .. 60000 rows: 4.5 ms whatever the row count; this kernel 2.6 / 4.5 / 6.4 / 9.5 ms
     // at 10000 / 20000 / 30000 / 45000 rows -- bench/ab_small_vs_chains.sh)
-    const char* e = getenv("DLSA_IRLS_CHAINS");
+    const char* e = knob("DLSA_IRLS_CHAINS");
     const int cap = e ? std::min(8, std::max(1, atoi(e))) : 4;
     const int S = std::max(1, std::min(cap, (K - 1) / 2));
     static const double per_partition_ms[5] = {0.55, 0.55, 0.37, 0.29, 0.23};

@@ -4,7 +4,10 @@ PyTorch-ROCm is used for device memory and streams only: every function here han
 device pointers to libdlsa_hip.so through the C ABI of include/dlsa_hip.h and returns torch
 tensors that own the results.  There is no CPU path -- a CPU tensor raises.
 """
+import contextlib
 import ctypes
+import dataclasses
+from typing import Optional
 
 import numpy as np
 
@@ -409,6 +412,59 @@ def xtv(X, v):
     check(lib.dlsa_xtv_f64(_ptr(X), _rowmajor(X), _ptr(v.contiguous()), n, p, _ptr(g), _ptr(vv),
                            _ptr(ws), ws.numel(), _stream()))
     return g, vv
+
+
+@dataclasses.dataclass
+class IrlsOptions:
+    """Policy of the IRLS driver for the fits made inside `with engine.irls_options(opts):` (or passed as `options=` to
+    fit_logistic_partitions / fit_logistic_design / logistic_model): include/dlsa_hip.h dlsa_irls_options, field for field.  None =
+    automatic (the measured default for the shapes); every setting returns the same MLE and Hessian to the parity tolerance."""
+    chains: Optional[int] = None            # partition chains of one call (host threads + streams), 1..8
+    seeded: Optional[bool] = None           # partition 0 alone first, every chain seeded with its state
+    subsample_div: Optional[int] = None     # cold start on rows / d of a partition; 0 or 1: none
+    factor_div: Optional[int] = None
+    warm: Optional[bool] = None             # partition k + 1 starts from partition k's MLE
+    inherit: Optional[bool] = None
+    pool: Optional[bool] = None
+    secant: Optional[bool] = None
+    inverse: Optional[bool] = None
+    predict: Optional[bool] = None          # predicted convergence
+    fused: Optional[bool] = None            # fused Newton pass (one read of the rows per fresh Hessian)
+    fuse_last: Optional[bool] = None
+    small: Optional[bool] = None            # one-launch kernel for many small partitions
+    qn_threads: Optional[int] = None
+    trace: Optional[bool] = None
+    freeze_at: Optional[float] = None       # 0: never freeze the factor
+
+    def as_c(self):
+        lib = _lib.load()
+        c = _lib.IrlsOptionsC()
+        lib.dlsa_irls_options_init(ctypes.byref(c))
+        for f in dataclasses.fields(self):
+            v = getattr(self, f.name)
+            if v is not None:
+                setattr(c, f.name, float(v) if f.name == "freeze_at" else int(v))
+        return c
+
+
+@contextlib.contextmanager
+def irls_options(options=None, **fields):
+    """The calling thread's IRLS driver options for the fits (and workspace sizes) inside the block: an IrlsOptions, or its fields as
+    keyword arguments (`with engine.irls_options(chains=1, fused=False): ...`).  Cleared on exit."""
+    if options is None:
+        options = IrlsOptions(**fields) if fields else None
+    elif fields:
+        options = dataclasses.replace(options, **fields)
+    if options is None:
+        yield
+        return
+    lib = _lib.load()
+    c = options.as_c()
+    check(lib.dlsa_irls_set_options(ctypes.byref(c)))
+    try:
+        yield
+    finally:
+        lib.dlsa_irls_set_options(None)
 
 
 def irls_fit_ex(X, y, part_first, part_rows, row_step=1, fit_intercept=False, tol=1e-13, max_iter=100):

@@ -130,7 +130,7 @@ def logistic_model(sample_df, Y_name, fit_intercept=False, dummy_info=[], dummy_
 
 
 def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_intercept=False, names=None,
-                            tol=1e-13, max_iter=100):
+                            tol=1e-13, max_iter=100, options=None, **option_fields):
     """Tensor fast path of the map step for MANY partitions of one device-resident shard.
 
     X [n, p] fp64 row-major on the GPU, y [n].  Either `part_offsets` (K+1 ints: partition k is the
@@ -138,6 +138,8 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
     logistic_dlsa.py:295) or `partition_num` (systematic partition_id = i % K, models.py:33: partition k is
     the strided view X[k::K], nothing is gathered).  With fit_intercept the leading ones column of
     models.py:121-122 is implicit in the kernels (results have p + 1 columns, `intercept` first).
+    `options` (an engine.IrlsOptions) or its fields as keyword arguments -- chains=, seeded=, fused=, predict=, subsample_div=, ... --
+    set the IRLS driver's policy for this call (default: chosen from the shapes; same results to the parity tolerance either way).
     Returns MappedBlocks."""
     if not X.is_cuda:
         raise RuntimeError("fit_logistic_partitions runs on the GPU only (no CPU fallback)")
@@ -160,14 +162,15 @@ def fit_logistic_partitions(X, y, partition_num=None, part_offsets=None, fit_int
     else:
         offs = [int(v) for v in part_offsets]
         first, rows, step = offs[:-1], [offs[k + 1] - offs[k] for k in range(len(offs) - 1)], 1
-    r = engine.irls_fit_ex(engine.row_major(X), y.contiguous(), first, rows, row_step=step, fit_intercept=fit_intercept,
-                           tol=tol, max_iter=max_iter)
+    with engine.irls_options(options, **option_fields):
+        r = engine.irls_fit_ex(engine.row_major(X), y.contiguous(), first, rows, row_step=step, fit_intercept=fit_intercept,
+                               tol=tol, max_iter=max_iter)
     return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], names, r["status"], r["n_iter"], r["loglik"],
                         sample_size=n)
 
 
 def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=None, structured=True, tol=1e-13,
-                        max_iter=100):
+                        max_iter=100, options=None, **option_fields):
     """Tensor fast path of the map step for a design given by its RAW columns: num [n, q] fp64 (columns in
     spec.numeric_cols order) and codes [n, f] int32 level codes (DesignSpec.encode), both on the GPU.
     With structured=True and a qualifying design (<= 8 dense columns, <= 8 factors; pair tables larger than LDS are cut into bands) the fit runs on
@@ -189,13 +192,14 @@ def fit_logistic_design(num, codes, y, spec, partition_num=None, part_offsets=No
         offs = [int(v) for v in part_offsets]
         first, rows, step = offs[:-1], [offs[k + 1] - offs[k] for k in range(len(offs) - 1)], 1
     plan = spec.onehot_plan() if structured else None
-    if plan is not None:
-        r = engine.onehot_irls_fit_ex(plan, engine.row_major(num) if num is not None else None,
-                                      engine.row_major(codes) if codes is not None else None, y.contiguous(), first, rows,
-                                      row_step=step, tol=tol, max_iter=max_iter)
-    else:
-        X, _ = spec.build(num, codes)
-        r = engine.irls_fit_ex(X, y.contiguous(), first, rows, row_step=step, tol=tol, max_iter=max_iter)
+    with engine.irls_options(options, **option_fields):       # (the IRLS driver's policy for this call: see fit_logistic_partitions)
+        if plan is not None:
+            r = engine.onehot_irls_fit_ex(plan, engine.row_major(num) if num is not None else None,
+                                          engine.row_major(codes) if codes is not None else None, y.contiguous(), first, rows,
+                                          row_step=step, tol=tol, max_iter=max_iter)
+        else:
+            X, _ = spec.build(num, codes)
+            r = engine.irls_fit_ex(X, y.contiguous(), first, rows, row_step=step, tol=tol, max_iter=max_iter)
     return MappedBlocks(r["coef"], r["Sig_invMcoef"], r["Sig_inv"], spec.names, r["status"], r["n_iter"], r["loglik"],
                         sample_size=n)
 

@@ -138,6 +138,36 @@ int dlsa_irls_pass_f64(const double* X, int64_t ldx, const double* y, const doub
                        double* H, int64_t ldh, double* g, double* loglik, double* w_out,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-call options of the IRLS driver ---------------------------------------------------
+ * The driver of dlsa_irls_fit_* / dlsa_onehot_irls_fit_* chooses its measures (partition chains, subsample cold start, frozen /
+ * inherited / pooled factors, secant correction, fused passes, predicted exit, ...) from the shapes; every choice gives the same
+ * MLE and Hessian to the parity tolerance.  A caller that wants another policy sets it HERE, per host thread: the options stay in
+ * force for the calling thread's next fit and workspace-size calls until replaced or cleared (NULL).  Every int field: -1 =
+ * automatic (the measured default), 0 = off, 1 = on, unless said otherwise.  The DLSA_IRLS_* environment variables of the A/B
+ * scripts under bench/ are consulted only for fields left on automatic.  The reference has no counterpart (sklearn's solver
+ * arguments at dlsa/models.py:110-113 are the nearest). */
+typedef struct dlsa_irls_options {
+    int struct_bytes;    /* sizeof(dlsa_irls_options), set by dlsa_irls_options_init                                   */
+    int chains;          /* partition chains (host threads + streams of one call): 1..8; -1 = by the partitions' size  */
+    int seeded;          /* fit partition 0 alone and seed every chain with its state                                   */
+    int subsample_div;   /* cold start on rows / d of a partition: d >= 2; 0 or 1 = no subsample                        */
+    int factor_div;      /* rows / d feed the stand-in Hessian of an inherited start                                    */
+    int warm;            /* partition k + 1 starts from partition k's MLE                                               */
+    int inherit;         /* full-data iterations start from an inherited factor (default: p >= 192)                     */
+    int pool;            /* pooled preconditioner over the finished partitions                                          */
+    int secant;          /* quasi-Newton correction of reused factors                                                   */
+    int inverse;         /* explicit inverse of a reused factor                                                         */
+    int predict;         /* predicted convergence (skips the confirming pass when tol <= 1e-10)                         */
+    int fused;           /* fused Newton pass (one read of the rows per fresh Hessian) where the shape allows it        */
+    int fuse_last;       /* the iteration expected to end the run takes the fused pass for the result's Hessian         */
+    int small;           /* one-launch kernel for many small partitions                                                 */
+    int qn_threads;      /* workgroup size of the quasi-Newton step kernel (64..1024)                                   */
+    int trace;           /* print step norms to stderr                                                                  */
+    double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
+} dlsa_irls_options;
+void dlsa_irls_options_init(dlsa_irls_options* opt);            /* every field on automatic */
+int dlsa_irls_set_options(const dlsa_irls_options* opt);         /* NULL: back to automatic   */
+
 /* ---- a2-a6: per-partition exact-MLE fit + local quadratic approximation ---------------
  * Replaces logistic_model's numeric core (dlsa/models.py:110-131) for K partitions stored
  * contiguously: partition k = rows [part_offsets[k], part_offsets[k+1]) of X (host array of

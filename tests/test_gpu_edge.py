@@ -116,3 +116,39 @@ def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
     # and both are the oracle's MLE on the first partition
     c, _, s = orc.logistic_model_block(X[:60_000].cpu().numpy(), y[:60_000].cpu().numpy())
     assert rel_inf(base["coef"][0].cpu().numpy(), c) < 1e-10 and rel_inf(base["Sig_inv"][0].cpu().numpy(), s) < 1e-10
+    # the same switches through the C ABI's options struct (dlsa_irls_set_options, per thread): the path of the environment run,
+    # bit for bit -- and an option field wins over the environment variable of the same switch
+    off = eng.IrlsOptions(subsample_div=0, freeze_at=0.0, warm=False, inherit=False, secant=False, inverse=False, pool=False, predict=False)
+    with eng.irls_options(off):
+        opt = eng.irls_fit(X, y, offs)
+    assert opt["n_iter"] == plain["n_iter"] and torch.equal(opt["coef"], plain["coef"]) and torch.equal(opt["Sig_inv"], plain["Sig_inv"])
+    after = eng.irls_fit(X, y, offs)                       # the block's options are gone
+    assert after["n_iter"] == base["n_iter"] and torch.equal(after["coef"], base["coef"])
+    os.environ["DLSA_IRLS_SECANT"] = "0"
+    try:
+        with eng.irls_options(secant=True):
+            both = eng.irls_fit(X, y, offs)
+    finally:
+        os.environ.pop("DLSA_IRLS_SECANT", None)
+    assert both["n_iter"] == base["n_iter"] and torch.equal(both["coef"], base["coef"])
+
+
+def test_fit_logistic_partitions_takes_the_driver_policy_as_keyword_arguments(eng, orc):
+    """SURVEY 5 asked for keyword arguments + one small dataclass: chains / fused / predict ... on the operator-level entry."""
+    import dlsa_amd
+    n, p, K = 120_000, 64, 6
+    X, y = eng.synth(5, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    a = dlsa_amd.fit_logistic_partitions(X, y, partition_num=K)
+    b = dlsa_amd.fit_logistic_partitions(X, y, partition_num=K, chains=1, fused=False, predict=False, small=False)
+    c = dlsa_amd.fit_logistic_partitions(X, y, partition_num=K, options=eng.IrlsOptions(chains=3, seeded=True))
+    assert a.status == b.status == c.status == [0] * K
+    for other in (b, c):
+        assert rel_inf(other.coef.cpu().numpy(), a.coef.cpu().numpy()) < 1e-10
+        assert rel_inf(other.Sig_inv.cpu().numpy(), a.Sig_inv.cpu().numpy()) < 1e-10
+    with pytest.raises(TypeError):
+        dlsa_amd.fit_logistic_partitions(X, y, partition_num=K, chain=2)          # not a field of IrlsOptions
+    from dlsa_amd import _lib
+    with pytest.raises(RuntimeError):
+        with eng.irls_options(chains=9):
+            pass
+    assert "chains" in _lib.last_error()
