@@ -49,8 +49,8 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
 
 
 def airline_shaped(n, seed=7):
-    """Config 4 surrogate (dlsa_amd/surrogates.py): timings of the design kernel and of the structured passes."""
-    from dlsa_amd.surrogates import airline_shaped as make
+    """Config 4 surrogate (bench/surrogates.py): timings of the design kernel and of the structured passes."""
+    from surrogates import airline_shaped as make
     c = make(n, seed, dense=False)
     num, codes, spec, plan, y, beta, p = c["num"], c["codes"], c["spec"], c["plan"], c["y"], c["beta"], c["p"]
     Xbuf = torch.empty((n, p), dtype=torch.float64, device="cuda")

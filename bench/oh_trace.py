@@ -3,7 +3,8 @@ python bench/oh_trace.py [rows] [K]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dlsa_amd import engine, surrogates
+from dlsa_amd import engine
+import surrogates
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 14_000_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 d = surrogates.airline_shaped(n, dense=False)

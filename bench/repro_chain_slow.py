@@ -1,7 +1,8 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
-from dlsa_amd import engine, surrogates
+from dlsa_amd import engine
+import surrogates
 def oh(tag):
     n, K = 14_000_000, 14
     d = surrogates.airline_shaped(n, dense=False)

@@ -7,7 +7,7 @@ factor dropped, intercept first: p = 1 + 7 + 10 + 5 + 19 + 109 + 109 = 260 (SURV
 Everything is generated on the device; the dense matrix is only built on request (dlsa_design_f64)."""
 import torch
 
-from . import engine
+from dlsa_amd import engine
 
 AIRLINE_LEVELS = (11, 6, 20, 110, 110)
 AIRLINE_NUMERIC = 7

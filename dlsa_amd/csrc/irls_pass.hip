@@ -326,6 +326,12 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     // with a v_mov_b64 per evaluation)
     const double c_exp13 = fp_pin64<PIN>(1.6059043836821613e-10), c_log21 = fp_pin64<PIN>(1.0 / 21.0), c_sqrt2m1 = fp_pin64<PIN>(0.41421356237309503),
                  c_ln2 = fp_pin64<PIN>(6.931471805599453094e-01);
+    // (BATCH: the five stage offsets live in SGPRs too -- eight of the log polynomial's coefficients move to pinned VGPRs, of which
+    // these shapes have > 100 to spare, instead of spilling scalar registers)
+    constexpr bool VC = PIN && HESS && fp_batch_ok(NTC);
+    constexpr bool VC8 = VC && !(WOUT && fp_nreg(NT, G) > 200);       // (the widest shapes with w_out have eight VGPRs to spare, not sixteen)
+    const double c_l19 = fp_pin64<VC>(1.0 / 19.0), c_l17 = fp_pin64<VC>(1.0 / 17.0), c_l15 = fp_pin64<VC>(1.0 / 15.0), c_l13 = fp_pin64<VC>(1.0 / 13.0),
+                 c_l11 = fp_pin64<VC8>(1.0 / 11.0), c_l9 = fp_pin64<VC8>(1.0 / 9.0), c_l7 = fp_pin64<VC8>(1.0 / 7.0), c_l5 = fp_pin64<VC8>(1.0 / 5.0);
     const int k_half = fp_pin32<PIN>(0x3fe00000), k_one = fp_pin32<PIN>(0x3ff00000), k_mhalf = fp_pin32<PIN>((int)0xbfe00000), k_zero = fp_pin32<PIN>(0),
               k_1p5 = fp_pin32<PIN>(0x3ff80000), k_two = fp_pin32<PIN>(0x40000000);
 
@@ -408,14 +414,23 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         const double sv = num * rcp_newton(den);
         const double z = sv * sv;
         double q = c_log21;
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 19.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 17.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 15.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 13.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 11.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 9.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 7.0);
-        q = fp_fma_sc<PIN>(q, z, 1.0 / 5.0);
+        if constexpr (VC) {
+            q = fma(q, z, c_l19); q = fma(q, z, c_l17); q = fma(q, z, c_l15); q = fma(q, z, c_l13);
+            if constexpr (VC8) { q = fma(q, z, c_l11); q = fma(q, z, c_l9); q = fma(q, z, c_l7); q = fma(q, z, c_l5); }
+            else {
+                q = fp_fma_sc<PIN>(q, z, 1.0 / 11.0); q = fp_fma_sc<PIN>(q, z, 1.0 / 9.0);
+                q = fp_fma_sc<PIN>(q, z, 1.0 / 7.0); q = fp_fma_sc<PIN>(q, z, 1.0 / 5.0);
+            }
+        } else {
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 19.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 17.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 15.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 13.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 11.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 9.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 7.0);
+            q = fp_fma_sc<PIN>(q, z, 1.0 / 5.0);
+        }
         q = fp_fma_sc<PIN>(q, z, 1.0 / 3.0);
         q = fma(q, z, 1.0);
         const double l1p = fma(sv + sv, q, big ? c_ln2 : 0.0);

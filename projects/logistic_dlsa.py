@@ -143,8 +143,9 @@ def main():
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         n_local = int(offs[-1])
         kind = engine.SYNTH_GAUSSIAN if args.gaussian else engine.SYNTH_UNIFORM
-        # rows of partition k are the global rows k, k+K, k+2K, ...: generate the full stream once per rank in
-        # chunks and keep this rank's rows grouped by partition (device gather)
+        # rows of partition k are the global rows k, k+K, k+2K, ...: the stream is generated in chunks of a multiple of K rows, so inside
+        # a chunk partition k is the strided view Xc[k::K] -- one strided device copy per owned partition moves it behind the
+        # partition's earlier rows (no index arithmetic on the device: tensors for storage and copies only)
         Xl = torch.empty((n_local, p), dtype=torch.float64, device="cuda")
         yl = torch.empty((n_local,), dtype=torch.float64, device="cuda")
         fill = [int(o) for o in offs[:-1]]
@@ -152,12 +153,11 @@ def main():
         for r0 in range(0, n, chunk):
             m = min(chunk, n - r0)
             Xc, yc = engine.synth(args.seed, r0, m, p, kind=kind)
-            pid = (torch.arange(r0, r0 + m, device="cuda") % K)
             for j, k in enumerate(mine):
-                sel = (pid == k).nonzero().flatten()
-                Xl[fill[j]: fill[j] + sel.numel()] = Xc[sel]
-                yl[fill[j]: fill[j] + sel.numel()] = yc[sel]
-                fill[j] += sel.numel()
+                cnt = len(range(k, m, K))                                  # r0 is a multiple of K
+                Xl[fill[j]: fill[j] + cnt].copy_(Xc[k::K])
+                yl[fill[j]: fill[j] + cnt].copy_(yc[k::K])
+                fill[j] += cnt
         torch.cuda.synchronize()
         tictoc["repartition"].append(time.perf_counter())
         memsize_total = n * (p + 2) * 8
@@ -199,23 +199,18 @@ def main():
     time_mapred = tictoc["mapred"][1] - tictoc["mapred"][0]
     time_dlsa = tictoc["dlsa"][1] - tictoc["dlsa"][0]
     time_model_fit = tictoc["model_fit"][1] - tictoc["model_fit"][0]
-    out_time = pd.DataFrame({
-        "sample_size": n, "sample_size_per_partition": n / K, "n_par": p + int(args.fit_intercept),
-        "partition_num": K, "memsize_total": memsize_total,
-        "time_repartition": tictoc["repartition"][1] - tictoc["repartition"][0],
-        "time_mapred": time_mapred, "time_dlsa": time_dlsa, "time_model_fit": time_model_fit,
-        "time_model_eval": tictoc["model_eval"][1] - tictoc["model_eval"][0]}, index=[0])
+    from dlsa_amd import results
+    out_time = results.time_table(n, K, p + int(args.fit_intercept), memsize_total, tictoc["repartition"][1] - tictoc["repartition"][0],
+                                  time_mapred, time_dlsa, time_model_fit, tictoc["model_eval"][1] - tictoc["model_eval"][0])
     if args.coef_csv:
         # the table's MLE column (plot_coef.py:20-41 takes it from a separate global fit): every rank fits ITS rows as one
         # partition, the WLS combine of those fits is the global estimate up to O(1/n^2)
         g = dlsa_amd.dlsa_mapred(global_fit())
         if rank == 0:
-            from dlsa_amd import results
             results.write_coef_csv(args.coef_csv, out_par, list(Sig_inv_beta.columns[2:]), beta_byMLE=g["beta_byOLS"].to_numpy())
     if rank == 0:
         if args.save:
-            with open(os.path.expanduser(args.save), "wb") as f:
-                pickle.dump([Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time], f)
+            results.save_results(args.save, Sig_inv_beta, out_dlsa, out_par, out_model_eval, out_time)
             print("Model results are saved to:\t" + args.save)
         print("\nModel Summary:\n")
         print(out_time.to_string(index=False))

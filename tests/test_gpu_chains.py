@@ -69,7 +69,9 @@ def test_chained_fit_equals_single_chain_and_oracle(eng, orc, monkeypatch, layou
 
 
 def test_chained_structured_fit_and_an_empty_partition(eng, monkeypatch):
-    from dlsa_amd import surrogates
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
+    import surrogates                            # bench/surrogates.py: test / bench data, not product code
     n, K = 8 * 70000, 8
     d = surrogates.airline_shaped(n, dense=False)
     offs = [int(n * k / K) for k in range(K + 1)]

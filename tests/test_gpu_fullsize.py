@@ -80,7 +80,9 @@ def test_full_size_config4_structured_equals_dense(eng):
     """BASELINE config 4's per-GPU shard (113.9M / 8 = 1.4e7 rows, airline-shaped synthetic, p = 260): the structured
     one-hot passes on the raw row (76 B) must give the dense kernels' results on the matrix the design kernel builds
     (2080 B per row): Hessian, gradient, log-likelihood, and the 14-partition map step."""
-    from dlsa_amd.surrogates import airline_shaped
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
+    from surrogates import airline_shaped        # bench/surrogates.py: test / bench data, not product code
     n, K = 14_000_000, 14
     c = airline_shaped(n)
     X, num, codes, y, plan, p = c["X"], c["num"], c["codes"], c["y"], c["plan"], c["p"]
