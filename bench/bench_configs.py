@@ -13,6 +13,37 @@ import dlsa_amd      # noqa: E402
 from dlsa_amd import engine  # noqa: E402
 
 
+FP64_MFMA_PEAK_TF, FP32_MFMA_PEAK_TF, HBM_PEAK_GBS = 78.6, 157.3, 8000.0      # as bench.py / MI355X_MICROARCH.md
+
+
+def traffic_from_evidence(tag, p, n):
+    """HBM bytes of one launch over n rows from the committed counter passes of that kernel (profiles/r04_pmc_<tag>.json,
+    bench/pmc_evidence.py): per row of the evidence run, scaled; None when the evidence is of another width or of other sources."""
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import pmc_evidence as ev
+        doc = json.load(open(ev.evidence_path("r04", tag)))
+        if doc["p"] != p or doc["sources_sha16"] != ev.sources_sha16(ev.KERNELS[tag]["src"]):
+            return None
+        k = next(iter(doc["kernels"].values()))
+        return k["hbm_bytes"] / doc["rows"] * n
+    except Exception:
+        return None
+
+
+def roofline(kind, n, p, seconds, tag=None):
+    """{"bound", "achieved", "peak", "unit", "frac", "traffic"} of one launch: kind "gram64" / "gram32" (algorithmic flops of the
+    upper triangle), "fused" (the Gram's flops: the pass's logistic terms are not counted as useful work), "logit" (bytes)."""
+    if kind in ("gram64", "fused"):
+        ach, peak, unit, bound = n * (p * (p + 1) + p) / seconds / 1e12, FP64_MFMA_PEAK_TF, "TFLOP/s", "mfma"
+    elif kind == "gram32":
+        ach, peak, unit, bound = n * p * (p + 1) / seconds / 1e12, FP32_MFMA_PEAK_TF, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = n * 8 * (p + 2) / seconds / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+    return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "kernel": engine.gram_last_kernel()[0] if kind != "logit" else None,
+            "traffic": traffic_from_evidence(tag, p, n) if tag else None, "ms": seconds * 1e3}
+
+
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     ts = []
@@ -32,7 +63,14 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
     beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[: int(0.4 * p)] = 1.0
     w, _, _ = engine.logit_pass(X, y, beta)
     t_gram, H = timed(lambda: engine.gram(X, w))
+    kname = engine.gram_last_kernel()[0]
+    tag = "cyclic_p500" if "cyclic" in kname else "plan_p260" if "plan" in kname else "narrow_p100" if "narrow" in kname else None
+    rl = {"gram": roofline("gram64", n, p, t_gram, tag)}
     t_logit, _ = timed(lambda: engine.logit_pass(X, y, beta))
+    rl["logit"] = roofline("logit", n, p, t_logit, "logit_p500" if p == 500 else "logit_p50" if p == 50 else None)
+    if 49 <= p <= 120 and p % 2 == 0 and n >= 8192:
+        t_fused, _ = timed(lambda: engine.irls_pass(X, y, beta))
+        rl["fused"] = roofline("fused", n, p, t_fused, "fused_p100")
     def whole():
         mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs)
         out = dlsa_amd.dlsa_mapred(mb)
@@ -45,7 +83,9 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
             "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
             "gram_GBps_alg": n * 8 * (p + 1) / t_gram / 1e9,
             "logit_ms": t_logit * 1e3, "logit_GBps": n * 8 * (p + 2) / t_logit / 1e9,
-            "map_fit_s": t_fit, "map_reduce_lars_s": t_all, "irls_iters": mb.n_iter[:3], "status_ok": all(s == 0 for s in mb.status)}
+            "map_fit_s": t_fit, "map_reduce_lars_s": t_all, "irls_iters": mb.n_iter[:3], "status_ok": all(s == 0 for s in mb.status),
+            # the launch a fresh Hessian costs in this configuration's fit, and the other passes' own fractions
+            "roofline": rl.get("fused", rl["gram"]), "rooflines": rl}
 
 
 def airline_shaped(n, seed=7):
@@ -101,6 +141,7 @@ def linear_config(name, n, p, K):
                 asym = float((H - H.T).abs().max()); msg += " asym %.3e" % asym
             print(msg, file=sys.stderr, flush=True)
     t_gram, _ = timed(lambda: engine.gram(X, None))
+    rl = roofline("gram32", n, p, t_gram, "wide_f32_p2000")
     t_xty, _ = timed(lambda: engine.xtv(X, y))
     offs = [int(n * k / K) for k in range(K + 1)]
     t_all, mb = timed(lambda: dlsa_amd.fit_linear_partitions(X, y, part_offsets=offs), reps=2)
@@ -114,7 +155,8 @@ def linear_config(name, n, p, K):
     return {"config": name, "n": n, "p": p, "K": K, "dtype": "f32",
             "gram_ms": t_gram * 1e3, "gram_rows_per_s": n / t_gram, "gram_TF_alg": n * fl / t_gram / 1e12,
             "gram_GBps_alg": n * 4 * p / t_gram / 1e9, "xty_ms": t_xty * 1e3, "xty_GBps": n * 4 * (p + 1) / t_xty / 1e9,
-            "map_fit_s": t_all, "map_reduce_lars_s": t_whole, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max())}
+            "map_fit_s": t_all, "map_reduce_lars_s": t_whole, "theta_err_linf": float((torch.from_numpy(out["beta_byOLS"].to_numpy()).cuda() - beta.double()).abs().max()),
+            "roofline": rl}
 
 
 def linear_streaming_config(name, n, p, K, chunk_rows):
@@ -132,6 +174,7 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
                                   engine.synth_response(20260101, 0, Xc, out=yc)))
     t_gram, _ = timed(lambda: engine.gram_acc64(Xc, None, out=H, accumulate=True))
     kern = engine.gram_last_kernel()[0]
+    rl = roofline("gram32", rows_max, p, t_gram, "wide_f32_p2000")
     t_stats, _ = timed(lambda: engine.xtv_stats(Xc, yc, want_colsum=True))
     del Xc, yc, H
     torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
@@ -151,7 +194,7 @@ def linear_streaming_config(name, n, p, K, chunk_rows):
             "gram_rows_per_s": rows_max / t_gram, "gram_TF_alg": rows_max * fl / t_gram / 1e12,
             "stats_GBps": rows_max * 4 * (p + 1) / t_stats / 1e9, "map_fit_s": t_map, "map_rows_per_s": n / t_map,
             "map_TF_alg_incl_generation": n * fl / t_map / 1e12, "reduce_lars_s": t_rest, "peak_device_bytes": peak,
-            "status_ok": all(v == 0 for v in mb.status), "generation_overlapped": overlap, "stream_kind": kind,
+            "status_ok": all(v == 0 for v in mb.status), "generation_overlapped": overlap, "stream_kind": kind, "roofline": rl,
             "theta_err_linf": float(np.max(np.abs(out["beta_byOLS"].to_numpy() - truth)))}
 
 

@@ -20,11 +20,12 @@ c_u64 = ctypes.c_uint64
 class IrlsOptionsC(ctypes.Structure):
     """include/dlsa_hip.h: dlsa_irls_options (field for field)"""
     _fields_ = [(n, c_int) for n in ("struct_bytes", "chains", "seeded", "subsample_div", "factor_div", "warm", "inherit", "pool", "secant",
-                                     "inverse", "predict", "fused", "fuse_last", "small", "qn_threads", "trace")] + [("freeze_at", c_dbl)]
+                                     "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace")] + [("freeze_at", c_dbl)]
 
 
 SIGNATURES = {
     "dlsa_version": (c_int, []),
+    "dlsa_irls_last_fit_path": (c_int, []),
     "dlsa_irls_options_init": (None, [ctypes.POINTER(IrlsOptionsC)]),
     "dlsa_irls_set_options": (c_int, [ctypes.POINTER(IrlsOptionsC)]),
     "dlsa_last_error": (c_int, [ctypes.c_char_p, c_int]),

@@ -380,10 +380,21 @@ __device__ __forceinline__ void cs_sweeps(double (&a)[CS_NS], double& diag, doub
     }
 }
 
-__global__ __launch_bounds__(256) void spd_inverse_small_kernel(const double* __restrict__ A, int64_t lda, int p,
-                                                                const double* __restrict__ rhs, const double* __restrict__ ref,
-                                                                double* __restrict__ Hinv, double* __restrict__ xout,
-                                                                double* __restrict__ stats) {
+// Batched form (irls_batch.hip): workgroup b works on matrix b -- A + b sA, vectors + b sV, Hinv + b sH, stats + b sS -- and leaves at
+// once when active[b] == 0.  The single-matrix launch passes zero strides and no mask.
+struct CsBatch { int64_t sA, sV, sH, sS; const int* active; };
+__global__ __launch_bounds__(256) void spd_inverse_small_kernel(const double* __restrict__ A_, int64_t lda, int p,
+                                                                const double* __restrict__ rhs_, const double* __restrict__ ref_,
+                                                                double* __restrict__ Hinv_, double* __restrict__ xout_,
+                                                                double* __restrict__ stats_, CsBatch bt) {
+    const int bi = blockIdx.x;
+    if (bt.active && !bt.active[bi]) return;
+    const double* __restrict__ A = A_ + bi * bt.sA;
+    const double* __restrict__ rhs = rhs_ + bi * bt.sV;
+    const double* __restrict__ ref = ref_ ? ref_ + bi * bt.sV : nullptr;
+    double* __restrict__ Hinv = Hinv_ + bi * bt.sH;
+    double* __restrict__ xout = xout_ + bi * bt.sV;
+    double* __restrict__ stats = stats_ + bi * bt.sS;
     __shared__ __attribute__((aligned(16))) double rk[2][128];      // snapshot of the pivot row (= column, by symmetry), indexed by column
     __shared__ double dval[2];                                      // the pivot itself
     __shared__ double gv[128], xpart[2][128], red[52];
@@ -454,7 +465,16 @@ bool chol_small_ok(int p) {
 int launch_chol_small(const double* A, int64_t lda, int p, const double* rhs, const double* ref, double* Hinv, double* xout,
                       double* stats, hipStream_t s) {
     DLSA_REQUIRE(p > 0 && p <= CS_MAXP, "spd_inverse_small: p=%d", p);
-    hipLaunchKernelGGL(spd_inverse_small_kernel, dim3(1), dim3(256), 0, s, A, lda, p, rhs, ref, Hinv, xout, stats);
+    hipLaunchKernelGGL(spd_inverse_small_kernel, dim3(1), dim3(256), 0, s, A, lda, p, rhs, ref, Hinv, xout, stats, CsBatch{0, 0, 0, 0, nullptr});
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+// the same for `count` matrices in one launch: matrix b = A + b sA (row pitch lda), rhs / ref / xout + b sV, Hinv + b sH (p x p), stats + b sS
+int launch_chol_small_batched(int count, const double* A, int64_t lda, int64_t sA, int p, const double* rhs, const double* ref, int64_t sV,
+                              double* Hinv, int64_t sH, double* xout, double* stats, int64_t sS, const int* active, hipStream_t s) {
+    DLSA_REQUIRE(p > 0 && p <= CS_MAXP && count > 0, "spd_inverse_small (batched): p=%d count=%d", p, count);
+    hipLaunchKernelGGL(spd_inverse_small_kernel, dim3(count), dim3(256), 0, s, A, lda, p, rhs, ref, Hinv, xout, stats, CsBatch{sA, sV, sH, sS, active});
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

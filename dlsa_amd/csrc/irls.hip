@@ -73,6 +73,14 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
 int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
                      const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s, bool irls_weights);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
+// irls_batch.hip: the lock-step fit of all partitions of a call together
+bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step);
+int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int K, int p,
+                     double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+                     double* loglik_host, hipStream_t stream);
+// which driver the calling thread's last fit took: 0 = host-driven partition chains, 1 = the one-launch kernel for small partitions,
+// 2 = lock step (dlsa_irls_last_fit_path)
+static thread_local int g_last_fit_path = 0;
 
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
 
@@ -991,6 +999,8 @@ __global__ void gather_strided_kernel(const double* __restrict__ y, int64_t firs
 
 extern "C" {
 
+int dlsa_irls_last_fit_path(void) { return dlsa::g_last_fit_path; }
+
 size_t dlsa_irls_workspace_bytes(int64_t max_rows_per_partition, int p) {
     if (p <= 0 || p > 2048 || max_rows_per_partition < 0) return 0;
     // one slice per partition chain (irls_fit_core): small partitions are fitted on up to four streams at once
@@ -1010,9 +1020,17 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         std::vector<int64_t> rows((size_t)K);
         bool mono = true;
         for (int k = 0; k < K; ++k) { rows[(size_t)k] = part_offsets_host[k + 1] - part_offsets_host[k]; mono &= rows[(size_t)k] >= 0; }
-        if (mono && K <= 8192 && irls_small_eligible(rows.data(), K, p) && ws && ws_bytes >= irls_small_workspace_bytes(K) && !((uintptr_t)ws & 255))
+        if (mono && K <= 8192 && irls_small_eligible(rows.data(), K, p) && ws && ws_bytes >= irls_small_workspace_bytes(K) && !((uintptr_t)ws & 255)) {
+            g_last_fit_path = 1;
             return irls_small_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
                                   n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
+        }
+        if (mono && irls_batched_eligible(X, ldx, y, rows.data(), K, p, 0, 1)) {
+            g_last_fit_path = 2;
+            return irls_batched_fit(X, ldx, y, part_offsets_host, rows.data(), K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+                                    status_host, loglik_host, (hipStream_t)stream);
+        }
+        g_last_fit_path = 0;
     }
     auto make_data = [=](int, int64_t r0, char*, hipStream_t) {
         const double* Xk = X + r0 * ldx;
@@ -1068,9 +1086,17 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         set_error("irls_fit_ex: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    if (irls_small_eligible(part_rows_host, K, pe))
+    if (irls_small_eligible(part_rows_host, K, pe)) {
+        g_last_fit_path = 1;
         return irls_small_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv,
                               Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
+    }
+    if (irls_batched_eligible(X, ldx, y, part_rows_host, K, p, intercept, row_step)) {
+        g_last_fit_path = 2;
+        return irls_batched_fit(X, ldx, y, part_first_host, part_rows_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+                                status_host, loglik_host, (hipStream_t)stream);
+    }
+    g_last_fit_path = 0;
     const size_t ybytes = row_step > 1 ? align_up((size_t)std::max<int64_t>(max_rows, 1) * sizeof(double), 256) : 0;
     const int64_t pitch = ldx * row_step;                     // rows first, first + step, ...: a strided view, no copy of X
     auto make_data = [=](int k, int64_t, char* extra, hipStream_t st) {

@@ -1,0 +1,233 @@
+// LOCK-STEP map step for MANY partitions of a narrow fp64 design (dlsa/models.py:110-131 per partition; `partition_num` is a user
+// argument, models.py:32-33): the partitions of one call are fitted TOGETHER, one launch per stage of a Newton iteration over all
+// of them, instead of one after the other (irls.hip: a dozen launches + a host round trip per iteration and partition -- 0.28 ms per
+// partition on four chains whatever its size; 1000 partitions of 2e4 x 100 rows: 0.28 s for 20 ms worth of passes).
+//
+//   per iteration, four launches for ALL partitions:
+//     1. the fused Newton pass in its batched form (irls_pass.hip): a table of slabs, each the rows of ONE partition with that
+//        partition's own beta -> per-slab H partial, g, loglik;
+//     2. batch_unpack_kernel: per partition, the slabs' partials in a fixed order -> H (dense, both triangles, straight into the
+//        caller's Sig_inv block), g, loglik;
+//     3. spd_inverse_small_kernel, batched (chol.hip): delta = H^-1 g, |delta|, |beta|, the pivot flag, for every live partition;
+//     4. batch_update_kernel: the per-partition state machine of irls_small.hip / the oracle (log-likelihood safeguard with step
+//        halving, stopping rule |delta|_inf <= tol max(1, |beta|_inf), max_iter) -- a partition that ends writes coef, Sig_inv . coef
+//        and its status and leaves the active set; its slabs return at once in later passes.
+//   One 4-byte read-back per iteration (the number of live partitions).
+// Every partition starts from beta = 0 (no warm start from its neighbour: that is what lock step gives up); the MLE and the Hessian at
+// it are those of the host-driven path to the solver tolerance.  Shapes: what the fused pass and the one-launch inverse take (even
+// 50 <= p <= 112, aligned rows, no implicit intercept, contiguous partitions); chosen by a cost model against the chained path.
+// Scratch beyond the caller's workspace comes from the stream-ordered pool and is freed before the call returns.
+#include "common.h"
+#include "options.h"
+#include "irls_batch.h"
+#include <algorithm>
+#include <vector>
+
+namespace dlsa {
+
+// irls_pass.hip
+int irls_pass_batched_pp(int p);
+int irls_pass_batched_gp(int p);
+int irls_pass_batched_ll_at(int p);
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p);
+int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p,
+                             const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
+                             unsigned long long* clk, hipStream_t stream);
+// chol.hip
+bool chol_small_ok(int p);
+int launch_chol_small_batched(int count, const double* A, int64_t lda, int64_t sA, int p, const double* rhs, const double* ref, int64_t sV,
+                              double* Hinv, int64_t sH, double* xout, double* stats, int64_t sS, const int* active, hipStream_t s);
+
+constexpr int BATCH_SLAB_ROWS = 24576;          // a partition longer than this is cut into equal slabs (whole 32-row chunks)
+
+struct BatchState {            // per partition, device
+    double ll_prev;
+    int have_prev, halvings, iters, evals, last_pass, status;
+};
+
+// H, g, loglik of every live partition from its slabs' partials (fixed order over the slabs: bit-reproducible)
+__global__ __launch_bounds__(256) void batch_unpack_kernel(const double* __restrict__ partial, const double* __restrict__ gpart,
+                                                           const int* __restrict__ slab_begin, const int* __restrict__ active, int PP, int GP,
+                                                           int ll_at, int p, double* __restrict__ H, double* __restrict__ g,
+                                                           double* __restrict__ ll) {
+    const int k = blockIdx.x;
+    if (!active[k]) return;
+    const int s0 = slab_begin[k], s1 = slab_begin[k + 1];
+    double* __restrict__ Hk = H + (int64_t)k * p * p;
+    for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
+        const int i = e / p, j = e - i * p;
+        if (i > j) continue;
+        double s = 0.0;
+        for (int sl = s0; sl < s1; ++sl) s += partial[(int64_t)sl * PP * PP + (int64_t)i * PP + j];
+        Hk[i * p + j] = s;
+        Hk[j * p + i] = s;
+    }
+    for (int j = threadIdx.x; j <= p; j += blockDim.x) {
+        double s = 0.0;
+        for (int sl = s0; sl < s1; ++sl) s += gpart[(int64_t)sl * GP + (j < p ? j : ll_at)];
+        if (j < p) g[(int64_t)k * p + j] = s;
+        else ll[k] = s;
+    }
+}
+
+// the Newton state machine of one partition after a pass at its current beta (irls_small.hip's, lsa-free part of models.py:110-131)
+__global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, int max_iter, const double* __restrict__ H,
+                                                           const double* __restrict__ ll_in, const double* __restrict__ delta,
+                                                           const double* __restrict__ stats, double* __restrict__ beta,
+                                                           double* __restrict__ prev, double* __restrict__ stepv, BatchState* __restrict__ st,
+                                                           int* __restrict__ active, int* __restrict__ n_live, double* __restrict__ coef,
+                                                           double* __restrict__ smc, double* __restrict__ loglik, int* __restrict__ n_iter,
+                                                           int* __restrict__ status) {
+    const int k = blockIdx.x, j = threadIdx.x;
+    if (!active[k]) return;
+    BatchState s = st[k];
+    const double ll = ll_in[k];
+    double* bk = beta + (int64_t)k * p;
+    double* pk = prev + (int64_t)k * p;
+    double* sk = stepv + (int64_t)k * p;
+    const double* dk = delta + (int64_t)k * p;
+    int end = -1;                                  // >= 0: the partition's fit ends with this status
+    ++s.evals;
+    if (s.last_pass) end = DLSA_PART_NOT_CONVERGED;            // max_iter reached: H, loglik are those of the last iterate
+    else if (!isfinite(ll)) end = DLSA_PART_NAN;
+    else if (s.have_prev && ll < s.ll_prev - 1e-12 * fabs(s.ll_prev) && s.halvings < 30) {
+        // the previous step overshot: halve it and evaluate again (not a new iteration)
+        if (j < p) { const double h = 0.5 * sk[j]; sk[j] = h; bk[j] = pk[j] + h; }
+        ++s.halvings;
+        if (s.evals > 2 * max_iter + 64) end = DLSA_PART_NOT_CONVERGED;
+    } else {
+        const double dmax = stats[3 * k], bmax = stats[3 * k + 1], flag = stats[3 * k + 2];
+        ++s.iters;
+        if (flag == 1.0) end = DLSA_PART_NOT_SPD;
+        else if (flag == 2.0 || !isfinite(dmax)) end = DLSA_PART_NAN;
+        else if (dmax <= tol * fmax(1.0, bmax)) end = DLSA_PART_OK;
+        else {
+            if (j < p) { const double b = bk[j], d = dk[j]; pk[j] = b; sk[j] = d; bk[j] = b + d; }
+            s.ll_prev = ll; s.have_prev = 1; s.halvings = 0;
+            if (s.iters >= max_iter) s.last_pass = 1;
+        }
+    }
+    if (end >= 0) {
+        // outputs: coef, Sig_inv . coef (models.py:131); Sig_inv is the H the unpack kernel has just written in place
+        const double* Hk = H + (int64_t)k * p * p;
+        if (j < p) {
+            coef[(int64_t)k * p + j] = bk[j];
+            double acc = 0.0;
+            for (int c = 0; c < p; ++c) acc = fma(Hk[(int64_t)j * p + c], bk[c], acc);
+            smc[(int64_t)k * p + j] = acc;
+        }
+        if (j == 0) { loglik[k] = ll; n_iter[k] = s.iters; status[k] = end; }
+        s.status = end;
+    }
+    __syncthreads();                               // every thread has read active[k] / the old beta before they change
+    if (j == 0) {
+        st[k] = s;
+        if (end >= 0) active[k] = 0;
+        else atomicAdd(n_live, 1);
+    }
+}
+
+// Is the lock-step path the faster one?  Measured constants: a fused pass streams ~4.5e9 rows/s at p = 100 (scaled by the width), an
+// iteration of the four launches + the read-back ~0.15 ms; the chained path costs ~0.28 ms per partition on four chains + ~4.6 passes.
+bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept,
+                           int64_t row_step) {
+    const char* e = knob("DLSA_IRLS_BATCHED");
+    if (e && atoi(e) == 0) return false;
+    if (intercept || row_step != 1 || K < 2 || !irls_pass_batched_shape_ok(X, ldx, y, p) || !chol_small_ok(p)) return false;
+    int64_t total = 0, mn = INT64_MAX;
+    for (int k = 0; k < K; ++k) { total += rows_host[k]; mn = std::min(mn, rows_host[k]); }
+    if (mn < 1) return false;                      // empty partitions: the host-driven path writes the reference's zero block
+    if (e && atoi(e) != 0) return true;            // forced (A/B runs, tests)
+    const double pass_s = (double)total * (p / 100.0) * 2.3e-10;
+    const double t_batch = 8.0 * (pass_s + 0.15e-3), t_chain = K * 0.28e-3 + 4.6 * pass_s;
+    return K >= 8 && t_batch < t_chain;
+}
+
+int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int K, int p,
+                     double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+                     double* loglik_host, hipStream_t stream) {
+    const int PP = irls_pass_batched_pp(p), GP = irls_pass_batched_gp(p), ll_at = irls_pass_batched_ll_at(p);
+    // ---- the slab table: partition k in nsl equal slabs of whole chunks
+    std::vector<FusedSlab> slabs;
+    std::vector<int> slab_begin((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        const int64_t nk = rows_host[k];
+        const int nsl = (int)std::max<int64_t>(1, (nk + BATCH_SLAB_ROWS - 1) / BATCH_SLAB_ROWS);
+        const int64_t per = ((nk + nsl - 1) / nsl + 31) / 32 * 32;
+        slab_begin[(size_t)k] = (int)slabs.size();
+        for (int64_t r = 0; r < nk; r += per) {
+            FusedSlab sd;
+            sd.xoff = (first_host[k] + r) * ldx; sd.yoff = first_host[k] + r;
+            sd.nrows = (int)std::min<int64_t>(per, nk - r); sd.part = k;
+            DLSA_REQUIRE((double)(sd.nrows + 8 * 32) * (double)ldx * 8.0 < 2.0e9, "irls_fit (batched): a slab exceeds the 32-bit DMA offsets");
+            slabs.push_back(sd);
+        }
+    }
+    slab_begin[(size_t)K] = (int)slabs.size();
+    const int nslab = (int)slabs.size();
+
+    // ---- scratch: ONE block from the stream-ordered pool, freed before the call returns
+    const size_t pb = (size_t)K * p * sizeof(double);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_slabs = carve((size_t)nslab * sizeof(FusedSlab)), o_begin = carve(((size_t)K + 1) * sizeof(int)),
+                 o_active = carve((size_t)K * sizeof(int)), o_live = carve(256), o_iter = carve((size_t)K * sizeof(int)),
+                 o_status = carve((size_t)K * sizeof(int)), o_state = carve((size_t)K * sizeof(BatchState)),
+                 o_partial = carve((size_t)nslab * PP * PP * sizeof(double)), o_gpart = carve((size_t)nslab * GP * sizeof(double)),
+                 o_g = carve(pb), o_ll = carve((size_t)K * sizeof(double)), o_llout = carve((size_t)K * sizeof(double)), o_delta = carve(pb),
+                 o_stats = carve((size_t)K * 3 * sizeof(double)), o_beta = carve(pb), o_prev = carve(pb), o_step = carve(pb),
+                 o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256);
+    char* pool = nullptr;
+    DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, off, stream));
+    FusedSlab* d_slabs = (FusedSlab*)(pool + o_slabs);
+    int *d_begin = (int*)(pool + o_begin), *d_active = (int*)(pool + o_active), *d_live = (int*)(pool + o_live), *d_iter = (int*)(pool + o_iter),
+        *d_status = (int*)(pool + o_status);
+    BatchState* d_state = (BatchState*)(pool + o_state);
+    double *d_partial = (double*)(pool + o_partial), *d_gpart = (double*)(pool + o_gpart), *d_g = (double*)(pool + o_g), *d_ll = (double*)(pool + o_ll),
+           *d_llout = (double*)(pool + o_llout), *d_delta = (double*)(pool + o_delta), *d_stats = (double*)(pool + o_stats),
+           *d_beta = (double*)(pool + o_beta), *d_prev = (double*)(pool + o_prev), *d_step = (double*)(pool + o_step), *d_hinv = (double*)(pool + o_hinv);
+    unsigned long long* d_clk = (unsigned long long*)(pool + o_clk);
+    auto release = [&]() { (void)hipFreeAsync(pool, stream); };
+    int rc = DLSA_OK;
+    auto fail = [&](int code) { release(); return code; };
+#define DLSA_BATCH_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return fail(DLSA_ERR_HIP); } } while (0)
+    DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabs, slabs.data(), (size_t)nslab * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
+    DLSA_BATCH_CHECK(hipMemcpyAsync(d_begin, slab_begin.data(), ((size_t)K + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    {
+        std::vector<int> ones((size_t)K, 1);
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_active, ones.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
+        DLSA_BATCH_CHECK(hipStreamSynchronize(stream));        // (the host vectors above go out of scope / are reused)
+    }
+    DLSA_BATCH_CHECK(hipMemsetAsync(d_state, 0, (size_t)K * sizeof(BatchState), stream));
+    DLSA_BATCH_CHECK(hipMemsetAsync(d_beta, 0, pb, stream));
+    DLSA_BATCH_CHECK(hipMemsetAsync(d_prev, 0, pb, stream));
+    DLSA_BATCH_CHECK(hipMemsetAsync(d_step, 0, pb, stream));
+
+    const int cap = 2 * max_iter + 66;
+    int live = K;
+    for (int it = 0; it < cap && live > 0; ++it) {
+        rc = irls_pass_batched_launch(X, ldx, y, d_beta, p, p, d_slabs, nslab, d_active, d_partial, d_gpart, d_clk, stream);
+        if (rc) return fail(rc);
+        hipLaunchKernelGGL(batch_unpack_kernel, dim3(K), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
+                           (const int*)d_begin, (const int*)d_active, PP, GP, ll_at, p, Sig_inv, d_g, d_ll);
+        rc = launch_chol_small_batched(K, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
+        if (rc) return fail(rc);
+        DLSA_BATCH_CHECK(hipMemsetAsync(d_live, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, stream, p, tol, max_iter, (const double*)Sig_inv, (const double*)d_ll,
+                           (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
+                           Sig_invMcoef, d_llout, d_iter, d_status);
+        DLSA_BATCH_CHECK(hipGetLastError());
+        DLSA_BATCH_CHECK(hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream));
+        DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
+    }
+    if (live > 0) { set_error("irls_fit (batched): %d partitions still live after %d passes", live, cap); return fail(DLSA_ERR_INVALID); }
+    if (n_iter_host) DLSA_BATCH_CHECK(hipMemcpyAsync(n_iter_host, d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (status_host) DLSA_BATCH_CHECK(hipMemcpyAsync(status_host, d_status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (loglik_host) DLSA_BATCH_CHECK(hipMemcpyAsync(loglik_host, d_llout, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
+    release();
+    return DLSA_OK;
+#undef DLSA_BATCH_CHECK
+}
+
+}  // namespace dlsa

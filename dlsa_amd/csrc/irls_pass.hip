@@ -22,6 +22,7 @@
 // irls_pass_finish_kernel): bit-reproducible run to run.
 #include "common.h"
 #include "options.h"
+#include "irls_batch.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -106,7 +107,14 @@ constexpr int fp_logit_wgs(int ntc) { return ntc <= 5 ? 2 : 1; }
 constexpr int FP_MIN_P = 49, FP_MAX_P = 120;
 constexpr int64_t FP_MIN_ROWS = 8192;
 
+// BATCHED form (irls_batch.hip: the lock-step driver for many partitions): a workgroup's slab is described by a table entry (FusedSlab,
+// irls_batch.h) instead of slab * rows_per_slab -- rows of ONE partition, that partition's own beta, nothing to do when the partition
+// has converged.
+
 struct FusedArgs {
+    const FusedSlab* slabs;   // nullable: the batched form
+    const int* active;        // [partitions]: 0 = the partition's fit has ended (batched form)
+    int64_t beta_stride;      // beta of partition k = beta + k * beta_stride (batched form)
     const double* X;
     const double* y;
     const double* beta;
@@ -125,9 +133,14 @@ constexpr int fp_gp(int ntc) { return 16 * ntc + 8; }
 // BATCHED logistic terms (fused pass only): five stages + a scratch corner per wave (eight partial sums of 16 rows at a pitch of
 // ten doubles -- conflict-free 16-byte reads -- and the 16 residuals)
 constexpr int FP_NST_B = 5, FP_SCR = 192;
-constexpr bool fp_batch_ok(int ntc) { return DLSA_FUSED_BATCH && DLSA_FUSED_PRIVATE && (size_t)(FP_NST_B * fp_buf(ntc) + 4 * FP_SCR) * 8 <= (size_t)kLdsBytes; }
-constexpr int fp_hess_stages(int ntc) { return fp_batch_ok(ntc) ? FP_NST_B : FP_NST; }
-constexpr size_t fp_hess_lds(int ntc) { return (size_t)(fp_hess_stages(ntc) * fp_buf(ntc) + (fp_batch_ok(ntc) ? 4 * FP_SCR : 0)) * 8; }
+// ... for shapes whose five stages fit the LDS and whose accumulators leave the VGPRs the batched form needs (<= 190 accumulator registers:
+// up to 6 tiles + 1 tail group, p <= 100; the wider shapes' two fragment sets alone are 80-90 VGPRs and keep the per-chunk form)
+constexpr bool fp_batch_ok(int nt, int g) {
+    return DLSA_FUSED_BATCH && DLSA_FUSED_PRIVATE && fp_nreg(nt, g) <= 190 &&
+           (size_t)(FP_NST_B * fp_buf(nt + (g > 0 ? 1 : 0)) + 4 * FP_SCR) * 8 <= (size_t)kLdsBytes;
+}
+constexpr int fp_hess_stages(int nt, int g) { return fp_batch_ok(nt, g) ? FP_NST_B : FP_NST; }
+constexpr size_t fp_hess_lds(int nt, int g) { return (size_t)(fp_hess_stages(nt, g) * fp_buf(nt + (g > 0 ? 1 : 0)) + (fp_batch_ok(nt, g) ? 4 * FP_SCR : 0)) * 8; }
 
 template <int T, int TEND, typename F>
 __device__ __forceinline__ void fp_for_tiles(F&& fn) {
@@ -216,7 +229,8 @@ struct LogitState {
 
 // HESS = false: the same streaming skeleton without the Hessian -- the logit pass of narrow designs (w, g, loglik) fed by the
 // LDS-DMA ring instead of logit.hip's register loads
-template <bool WOUT, bool HESS, int NT, int G>
+// BF: the batched form (its own instantiations: the slab table's extra arguments cost the widest w_out shapes their last scalar registers)
+template <bool WOUT, bool HESS, int NT, int G, bool BF = false>
 __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 1)) void irls_pass_narrow_kernel(FusedArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -228,8 +242,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     constexpr bool PIN = fp_nreg(NT, G) <= 224;                        // registers to spare (all shapes but 7 tiles + 1 or 2 tail groups, 240 / 256 accumulators): pinned constants, scalar coefficients, early fragment loads
     constexpr int DMA_PER_CHUNK = KC / NWAVES + 1;                    // 8 row pieces + the y piece, per wave
     // BATCH: the logistic terms of the wave's own rows of TWO chunks in one evaluation (lane = row (lane & 15), four copies)
-    constexpr bool BATCH = HESS && fp_batch_ok(NTC);
-    constexpr int NST = HESS ? fp_hess_stages(NTC) : fp_logit_stages(NTC);
+    constexpr bool BATCH = HESS && fp_batch_ok(NT, G);
+    constexpr int NST = HESS ? fp_hess_stages(NT, G) : fp_logit_stages(NTC);
     constexpr int MEETN_FIT = (int)((size_t)NST * BUF * 8 / (3 * 2048));
     constexpr int MEETN = MEETN_FIT < NTRI ? MEETN_FIT : NTRI;
     static_assert(3 * MEETN >= NTRI, "the tiles meet in at most three passes");
@@ -246,14 +260,24 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 #if FP_TIMELINE
     unsigned long long tl0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl2 = 0;
 #endif
-    const int64_t rbeg = (int64_t)slab * a.rows_per_slab;
-    const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
-    const int nrows = (int)(rend > rbeg ? rend - rbeg : 0);
+    int64_t rbeg = BF ? 0 : (int64_t)slab * a.rows_per_slab, gxoff, gyoff;
+    int nrows;
+    const double* __restrict__ beta_in = a.beta;
+    if constexpr (BF) {                                                // batched form: the slab is a table entry
+        const FusedSlab sd = a.slabs[slab];
+        if (a.active && !a.active[sd.part]) return;                    // that partition's fit has ended: nobody reads this slab's partials
+        gxoff = sd.xoff; gyoff = sd.yoff; nrows = sd.nrows;
+        beta_in += (int64_t)sd.part * a.beta_stride;
+    } else {
+        const int64_t rend = min(rbeg + a.rows_per_slab, a.n);
+        nrows = (int)(rend > rbeg ? rend - rbeg : 0);
+        gxoff = rbeg * a.ldx; gyoff = rbeg;
+    }
     const int nchunks = (nrows + KC - 1) / KC;
 
     const unsigned xbytes = nrows > 0 ? (unsigned)(((int64_t)(nrows - 1) * a.ldx + a.p) * 8) : 0u;
-    __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + rbeg * a.ldx), 0, (int)xbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + rbeg), 0, nrows * 8, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + gxoff), 0, (int)xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + gyoff), 0, nrows * 8, 0x00020000);
     // columns p .. 16 NTC - 1 are never written by the DMA (lanes masked): the ring is zeroed once
     for (int e = tid; e < NST * BUF; e += THREADS) lds[e] = 0.0;
     __syncthreads();
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int col = 16 * q + 2 * ls + e;
-            bq[q][e] = col < a.p ? a.beta[col] : 0.0;
+            bq[q][e] = col < a.p ? beta_in[col] : 0.0;
             gacc[q][e] = 0.0;
         }
     // every lane of a row accumulates the row's loglik term (the eight copies are thinned out after the loop); rows past the slab's
@@ -328,8 +352,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
                  c_ln2 = fp_pin64<PIN>(6.931471805599453094e-01);
     // (BATCH: the five stage offsets live in SGPRs too -- eight of the log polynomial's coefficients move to pinned VGPRs, of which
     // these shapes have > 100 to spare, instead of spilling scalar registers)
-    constexpr bool VC = PIN && HESS && fp_batch_ok(NTC);
-    constexpr bool VC8 = VC && !(WOUT && fp_nreg(NT, G) > 200);       // (the widest shapes with w_out have eight VGPRs to spare, not sixteen)
+    constexpr bool VC = PIN && HESS && fp_batch_ok(NT, G);
+    constexpr bool VC8 = VC;
     const double c_l19 = fp_pin64<VC>(1.0 / 19.0), c_l17 = fp_pin64<VC>(1.0 / 17.0), c_l15 = fp_pin64<VC>(1.0 / 15.0), c_l13 = fp_pin64<VC>(1.0 / 13.0),
                  c_l11 = fp_pin64<VC8>(1.0 / 11.0), c_l9 = fp_pin64<VC8>(1.0 / 9.0), c_l7 = fp_pin64<VC8>(1.0 / 7.0), c_l5 = fp_pin64<VC8>(1.0 / 5.0);
     const int k_half = fp_pin32<PIN>(0x3fe00000), k_one = fp_pin32<PIN>(0x3ff00000), k_mhalf = fp_pin32<PIN>((int)0xbfe00000), k_zero = fp_pin32<PIN>(0),
@@ -840,6 +864,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
         return gram_impl_f64(X, ldx, w, n, p, H, ldh, 0, ws, ws_bytes, stream);
     }
     FusedArgs a;
+    a.slabs = nullptr; a.active = nullptr; a.beta_stride = 0;
     a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p; a.PP = (int)fp_pp(p);
     int nt, gt;
     fp_shape(p, nt, gt);
@@ -855,7 +880,7 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     a.gpart = (double*)((char*)ws + part);
     a.clk = (unsigned long long*)((char*)ws + part + gpb);
 #define DLSA_LAUNCH_FP2(WO, HS, NTV, GV) do { \
-        const size_t shm = (HS) ? fp_hess_lds(NTV + (GV > 0 ? 1 : 0)) : (size_t)fp_logit_stages(NTV + (GV > 0 ? 1 : 0)) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
+        const size_t shm = (HS) ? fp_hess_lds(NTV, GV) : (size_t)fp_logit_stages(NTV + (GV > 0 ? 1 : 0)) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, HS, NTV, GV>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, HS, NTV, GV>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
@@ -880,6 +905,49 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
     if (H) gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
     hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((p + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, p,
                        16 * ntc, g, loglik);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+// ---- the batched form (irls_batch.hip): ONE launch of the fused kernel over a table of slabs, each with its partition's own beta
+int irls_pass_batched_pp(int p) { return (int)fp_pp(p); }
+int irls_pass_batched_gp(int p) {
+    int nt, gt;
+    fp_shape(p, nt, gt);
+    return fp_gp(nt + (gt > 0 ? 1 : 0));
+}
+int irls_pass_batched_ll_at(int p) {
+    int nt, gt;
+    fp_shape(p, nt, gt);
+    return 16 * (nt + (gt > 0 ? 1 : 0));
+}
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p) {
+    return p >= FP_MIN_P && p <= FP_MAX_P && !(p & 1) && ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0;
+}
+int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p,
+                             const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
+                             unsigned long long* clk, hipStream_t stream) {
+    FusedArgs a;
+    a.slabs = d_slabs; a.active = d_active; a.beta_stride = beta_stride;
+    a.X = X; a.y = y; a.beta = beta; a.w_out = nullptr; a.ldx = ldx; a.n = 0; a.rows_per_slab = 0; a.p = p; a.PP = (int)fp_pp(p);
+    a.partial = partial; a.gpart = gpart; a.clk = clk;
+    int nt, gt;
+    fp_shape(p, nt, gt);
+#define DLSA_LAUNCH_FPB(NTV, GV) do { \
+        const size_t shm = fp_hess_lds(NTV, GV); \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_FPB_G(NTV) do { switch (gt) { \
+        case 0: DLSA_LAUNCH_FPB(NTV, 0); break; case 1: DLSA_LAUNCH_FPB(NTV, 1); break; \
+        case 2: DLSA_LAUNCH_FPB(NTV, 2); break; default: DLSA_LAUNCH_FPB(NTV, 3); break; } } while (0)
+    switch (nt) {
+        case 3: DLSA_LAUNCH_FPB_G(3); break; case 4: DLSA_LAUNCH_FPB_G(4); break;
+        case 5: DLSA_LAUNCH_FPB_G(5); break; case 6: DLSA_LAUNCH_FPB_G(6); break;
+        default: switch (gt) { case 0: DLSA_LAUNCH_FPB(7, 0); break; case 1: DLSA_LAUNCH_FPB(7, 1); break; default: DLSA_LAUNCH_FPB(7, 2); break; } break;
+    }
+#undef DLSA_LAUNCH_FPB_G
+#undef DLSA_LAUNCH_FPB
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

@@ -432,6 +432,7 @@ class IrlsOptions:
     fused: Optional[bool] = None            # fused Newton pass (one read of the rows per fresh Hessian)
     fuse_last: Optional[bool] = None
     small: Optional[bool] = None            # one-launch kernel for many small partitions
+    batched: Optional[bool] = None          # lock-step fit of all partitions together (narrow designs)
     qn_threads: Optional[int] = None
     trace: Optional[bool] = None
     freeze_at: Optional[float] = None       # 0: never freeze the factor
@@ -465,6 +466,15 @@ def irls_options(options=None, **fields):
         yield
     finally:
         lib.dlsa_irls_set_options(None)
+
+
+IRLS_PATH_CHAINS, IRLS_PATH_SMALL, IRLS_PATH_BATCHED = 0, 1, 2
+
+
+def irls_last_fit_path():
+    """Which driver this thread's last irls_fit / irls_fit_ex took (dlsa_irls_last_fit_path): IRLS_PATH_CHAINS (host-driven partition
+    chains), IRLS_PATH_SMALL (one launch, a workgroup per partition) or IRLS_PATH_BATCHED (lock step: all partitions together)."""
+    return int(_lib.load().dlsa_irls_last_fit_path())
 
 
 def irls_fit_ex(X, y, part_first, part_rows, row_step=1, fit_intercept=False, tol=1e-13, max_iter=100):

@@ -161,10 +161,14 @@ typedef struct dlsa_irls_options {
     int fused;           /* fused Newton pass (one read of the rows per fresh Hessian) where the shape allows it        */
     int fuse_last;       /* the iteration expected to end the run takes the fused pass for the result's Hessian         */
     int small;           /* one-launch kernel for many small partitions                                                 */
+    int batched;         /* lock-step fit of all partitions of a call together (narrow designs; -1 = by a cost model)  */
     int qn_threads;      /* workgroup size of the quasi-Newton step kernel (64..1024)                                   */
     int trace;           /* print step norms to stderr                                                                  */
     double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
 } dlsa_irls_options;
+/* which driver the calling thread's last dlsa_irls_fit_f64 / dlsa_irls_fit_ex_f64 took: 0 = host-driven partition chains, 1 = the
+ * one-launch kernel for many small partitions (p <= 64), 2 = lock step (all partitions of the call together, narrow designs) */
+int dlsa_irls_last_fit_path(void);
 void dlsa_irls_options_init(dlsa_irls_options* opt);            /* every field on automatic */
 int dlsa_irls_set_options(const dlsa_irls_options* opt);         /* NULL: back to automatic   */
 

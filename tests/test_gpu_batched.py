@@ -1,0 +1,89 @@
+"""GPU: the lock-step map step for many partitions of a narrow design (csrc/irls_batch.hip): all partitions of a call fitted together,
+one launch per stage of a Newton iteration -- against the host-driven chained path, the oracle (dlsa/models.py:110-131 restated)
+and itself."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available()
+    from dlsa_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import dlsa_oracle
+    return dlsa_oracle
+
+
+@pytest.mark.parametrize("p,sizes", [(64, [3000, 70000, 5000, 24577, 4100, 33000, 2500, 9000, 3100, 12000]),
+                                     (100, [20000] * 12 + [50001, 2000]),
+                                     (50, [2048, 4096, 100000, 3000, 7000, 2100, 2200, 2300])])
+def test_lock_step_fit_equals_chained_fit_and_oracle(eng, orc, p, sizes):
+    n, K = sum(sizes), len(sizes)
+    X, y = eng.synth(4242 + p, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    with eng.irls_options(batched=True, small=False):
+        b = eng.irls_fit(X, y, offs)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED
+        b2 = eng.irls_fit(X, y, offs)
+    with eng.irls_options(batched=False, small=False):
+        c = eng.irls_fit(X, y, offs)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS
+    assert b["status"] == c["status"] == [0] * K
+    for key in ("coef", "Sig_inv", "Sig_invMcoef"):
+        assert torch.equal(b[key], b2[key]), key                                   # bit-reproducible
+        assert rel_inf(b[key].cpu().numpy(), c[key].cpu().numpy()) < 1e-10, key
+    assert rel_inf(b["loglik"], c["loglik"]) < 1e-12
+    S = b["Sig_inv"].cpu().numpy()
+    assert np.array_equal(S, np.swapaxes(S, 1, 2))                                 # exactly symmetric
+    for k in (0, K - 1):                                                           # and the oracle's MLE / Hessian
+        Xk, yk = X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy()
+        co, smc, sig = orc.logistic_model_block(Xk, yk)
+        assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(S[k], sig) < 1e-10
+        assert rel_inf(b["Sig_invMcoef"][k].cpu().numpy(), smc) < 1e-10
+    # the operator-level entry takes the same route (contiguous partitions, no intercept)
+    import dlsa_amd
+    with eng.irls_options(batched=True, small=False):
+        mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs)
+    assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and rel_inf(mb.coef.cpu().numpy(), b["coef"].cpu().numpy()) == 0.0
+
+
+def test_lock_step_is_chosen_for_many_small_partitions_only(eng):
+    p = 64
+    X, y = eng.synth(7, 0, 64 * 3000, p, kind=eng.SYNTH_GAUSSIAN)
+    offs = [3000 * k for k in range(65)]
+    with eng.irls_options(small=False):
+        r = eng.irls_fit(X, y, offs)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and r["status"] == [0] * 64
+    r = eng.irls_fit(X, y, [0, 96000, 192000])                    # two large partitions: the chained path
+    assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS and r["status"] == [0, 0]
+    Xo, yo = eng.synth(8, 0, 40000, 63, kind=eng.SYNTH_GAUSSIAN)          # odd width: not the fused class
+    with eng.irls_options(batched=True, small=False):
+        eng.irls_fit(Xo, yo, [4000 * k for k in range(11)])
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS
+
+
+def test_lock_step_partitions_end_independently(eng, orc):
+    """a perfectly separated partition ends NOT_CONVERGED / not finite without holding up or disturbing the others"""
+    p, sizes = 50, [3000, 3000, 3000, 3000]
+    X, y = eng.synth(99, 0, sum(sizes), p, kind=eng.SYNTH_GAUSSIAN)
+    y = y.clone()
+    y[3000:6000] = (X[3000:6000, 0] > 0).double()                           # partition 1: separable by the first column
+    offs = [0, 3000, 6000, 9000, 12000]
+    with eng.irls_options(batched=True, small=False):
+        b = eng.irls_fit(X, y, offs, max_iter=25)
+    assert b["status"][1] != 0 and [b["status"][k] for k in (0, 2, 3)] == [0, 0, 0]
+    for k in (0, 2, 3):
+        co, _, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
+        assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
