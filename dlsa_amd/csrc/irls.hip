@@ -38,6 +38,9 @@ size_t gram_workspace_bytes_impl(int64_t n, int p, int elem_bytes);
 // feed the logistic terms -- one read of X per fresh Hessian instead of two)
 bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p);
 size_t irls_pass_workspace_bytes_impl(int64_t n, int p);
+bool irls_pass_fused_icpt_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p);
+int irls_pass_icpt_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
+                        double* g, double* loglik, double* w_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
                    double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
                    int* fused_out);
@@ -75,8 +78,8 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
 // irls_batch.hip: the lock-step fit of all partitions of a call together
 bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step);
-int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int K, int p,
-                     double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int64_t row_step, int K,
+                     int p, int intercept, double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
                      double* loglik_host, hipStream_t stream);
 // which driver the calling thread's last fit took: 0 = host-driven partition chains, 1 = the one-launch kernel for small partitions,
 // 2 = lock step (dlsa_irls_last_fit_path)
@@ -1027,7 +1030,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         }
         if (mono && irls_batched_eligible(X, ldx, y, rows.data(), K, p, 0, 1)) {
             g_last_fit_path = 2;
-            return irls_batched_fit(X, ldx, y, part_offsets_host, rows.data(), K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+            return irls_batched_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
                                     status_host, loglik_host, (hipStream_t)stream);
         }
         g_last_fit_path = 0;
@@ -1093,7 +1096,7 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
     }
     if (irls_batched_eligible(X, ldx, y, part_rows_host, K, p, intercept, row_step)) {
         g_last_fit_path = 2;
-        return irls_batched_fit(X, ldx, y, part_first_host, part_rows_host, K, p, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
+        return irls_batched_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
                                 status_host, loglik_host, (hipStream_t)stream);
     }
     g_last_fit_path = 0;
@@ -1117,11 +1120,20 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
             if (intercept) return gram_icpt_impl(Xk, pitch, w, nrows, p, H, pe, b.ws_pass, b.ws_pass_bytes, s);
             return gram_impl_f64(Xk, pitch, w, nrows, p, H, p, 0, b.ws_pass, b.ws_pass_bytes, s);
         };
-        if (!intercept) {        // (the implicit intercept's border needs its own streaming pass: those fits keep the two launches)
+        if (!intercept) {
             d.pass = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s) {
                 return irls_pass_impl(Xk, pitch, yk, beta, nrows, p, H, p, g, ll, w, nullptr, b.ws_pass, b.ws_pass_bytes, s, nullptr);
             };
             d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, pitch, yk, nrows, p); };
+        } else {                 // round 4: the fused kernel carries the implicit intercept as a ones column in its LDS stages
+            d.pass = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s) {
+                if (!irls_pass_fused_icpt_eligible(Xk, pitch, yk, nrows, p)) {
+                    int rc = logit_pass_impl(Xk, pitch, yk, beta, nrows, p, w, g, ll, b.ws_pass, b.ws_pass_bytes, s, 1);
+                    return rc ? rc : gram_icpt_impl(Xk, pitch, w, nrows, p, H, pe, b.ws_pass, b.ws_pass_bytes, s);
+                }
+                return irls_pass_icpt_impl(Xk, pitch, yk, beta, nrows, p, H, pe, g, ll, w, b.ws_pass, b.ws_pass_bytes, s);
+            };
+            d.fusable = [=](int64_t nrows) { return irls_pass_fused_icpt_eligible(Xk, pitch, yk, nrows, p); };
         }
         return d;
     };

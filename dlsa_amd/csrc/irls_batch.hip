@@ -29,8 +29,8 @@ namespace dlsa {
 int irls_pass_batched_pp(int p);
 int irls_pass_batched_gp(int p);
 int irls_pass_batched_ll_at(int p);
-bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p);
-int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p,
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept);
+int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
                              unsigned long long* clk, hipStream_t stream);
 // chol.hip
@@ -48,24 +48,26 @@ struct BatchState {            // per partition, device
 // H, g, loglik of every live partition from its slabs' partials (fixed order over the slabs: bit-reproducible)
 __global__ __launch_bounds__(256) void batch_unpack_kernel(const double* __restrict__ partial, const double* __restrict__ gpart,
                                                            const int* __restrict__ slab_begin, const int* __restrict__ active, int PP, int GP,
-                                                           int ll_at, int p, double* __restrict__ H, double* __restrict__ g,
+                                                           int ll_at, int p, int rot, double* __restrict__ H, double* __restrict__ g,
                                                            double* __restrict__ ll) {
+    // p = columns of the kernel's design; rot: its LAST column is the implicit intercept, which the outputs carry FIRST (models.py:136-142)
     const int k = blockIdx.x;
     if (!active[k]) return;
     const int s0 = slab_begin[k], s1 = slab_begin[k + 1];
     double* __restrict__ Hk = H + (int64_t)k * p * p;
+    auto om = [&](int c) { return rot ? (c == p - 1 ? 0 : c + 1) : c; };
     for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
         const int i = e / p, j = e - i * p;
         if (i > j) continue;
         double s = 0.0;
         for (int sl = s0; sl < s1; ++sl) s += partial[(int64_t)sl * PP * PP + (int64_t)i * PP + j];
-        Hk[i * p + j] = s;
-        Hk[j * p + i] = s;
+        Hk[om(i) * p + om(j)] = s;
+        Hk[om(j) * p + om(i)] = s;
     }
     for (int j = threadIdx.x; j <= p; j += blockDim.x) {
         double s = 0.0;
         for (int sl = s0; sl < s1; ++sl) s += gpart[(int64_t)sl * GP + (j < p ? j : ll_at)];
-        if (j < p) g[(int64_t)k * p + j] = s;
+        if (j < p) g[(int64_t)k * p + om(j)] = s;
         else ll[k] = s;
     }
 }
@@ -133,33 +135,55 @@ bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const 
                            int64_t row_step) {
     const char* e = knob("DLSA_IRLS_BATCHED");
     if (e && atoi(e) == 0) return false;
-    if (intercept || row_step != 1 || K < 2 || !irls_pass_batched_shape_ok(X, ldx, y, p) || !chol_small_ok(p)) return false;
+    const int pe = p + (intercept ? 1 : 0);
+    // strided partitions (partition_id = i % K, models.py:33: rows first, first + step, ...): the row pitch is ldx * step, and a slab of
+    // at least 2048 rows must stay inside the 32-bit DMA offsets
+    if (row_step < 1 || K < 2 || !irls_pass_batched_shape_ok(X, ldx * row_step, y, p, intercept) || !chol_small_ok(pe)) return false;
+    if ((double)(2048 + 8 * 32) * (double)ldx * (double)row_step * 8.0 >= 2.0e9) return false;
     int64_t total = 0, mn = INT64_MAX;
     for (int k = 0; k < K; ++k) { total += rows_host[k]; mn = std::min(mn, rows_host[k]); }
     if (mn < 1) return false;                      // empty partitions: the host-driven path writes the reference's zero block
     if (e && atoi(e) != 0) return true;            // forced (A/B runs, tests)
-    const double pass_s = (double)total * (p / 100.0) * 2.3e-10;
+    const double pass_s = (double)total * (pe / 100.0) * 2.3e-10;
     const double t_batch = 8.0 * (pass_s + 0.15e-3), t_chain = K * 0.28e-3 + 4.6 * pass_s;
     return K >= 8 && t_batch < t_chain;
 }
 
-int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int K, int p,
-                     double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
+// labels of strided partitions, slab by slab, into one contiguous buffer (the DMA's y pieces want consecutive labels)
+__global__ __launch_bounds__(256) void batch_gather_y_kernel(const double* __restrict__ y, const FusedSlab* __restrict__ slabs,
+                                                             const int64_t* __restrict__ ysrc, int64_t step, double* __restrict__ ybuf) {
+    const FusedSlab sd = slabs[blockIdx.x];
+    const int64_t src0 = ysrc[blockIdx.x];
+    for (int i = threadIdx.x; i < sd.nrows; i += blockDim.x) ybuf[sd.yoff + i] = y[src0 + (int64_t)i * step];
+}
+
+int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int64_t row_step, int K,
+                     int pdata, int intercept, double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
                      double* loglik_host, hipStream_t stream) {
+    const int p = pdata + (intercept ? 1 : 0);          // columns of beta / g / H (intercept first)
     const int PP = irls_pass_batched_pp(p), GP = irls_pass_batched_gp(p), ll_at = irls_pass_batched_ll_at(p);
-    // ---- the slab table: partition k in nsl equal slabs of whole chunks
+    // ---- the slab table: partition k in nsl equal slabs of whole chunks (rows first + r step: the kernel's row pitch is ldx * step)
+    const int64_t pitch = ldx * row_step;
+    const int64_t fit_rows = (int64_t)(1.9e9 / ((double)pitch * 8.0)) / 32 * 32 - 8 * 32;        // what the 32-bit DMA offsets hold
+    const int64_t slab_cap = std::max<int64_t>(2048, std::min<int64_t>(BATCH_SLAB_ROWS, fit_rows));
+    const bool gather_y = row_step > 1;
     std::vector<FusedSlab> slabs;
+    std::vector<int64_t> ysrc;                       // strided labels: index of the slab's first label in y
     std::vector<int> slab_begin((size_t)K + 1, 0);
+    int64_t ytotal = 0;
     for (int k = 0; k < K; ++k) {
         const int64_t nk = rows_host[k];
-        const int nsl = (int)std::max<int64_t>(1, (nk + BATCH_SLAB_ROWS - 1) / BATCH_SLAB_ROWS);
+        const int nsl = (int)std::max<int64_t>(1, (nk + slab_cap - 1) / slab_cap);
         const int64_t per = ((nk + nsl - 1) / nsl + 31) / 32 * 32;
         slab_begin[(size_t)k] = (int)slabs.size();
         for (int64_t r = 0; r < nk; r += per) {
             FusedSlab sd;
-            sd.xoff = (first_host[k] + r) * ldx; sd.yoff = first_host[k] + r;
+            sd.xoff = (first_host[k] + r * row_step) * ldx;
             sd.nrows = (int)std::min<int64_t>(per, nk - r); sd.part = k;
-            DLSA_REQUIRE((double)(sd.nrows + 8 * 32) * (double)ldx * 8.0 < 2.0e9, "irls_fit (batched): a slab exceeds the 32-bit DMA offsets");
+            sd.yoff = gather_y ? ytotal : first_host[k] + r;
+            ysrc.push_back(first_host[k] + r * row_step);
+            ytotal += (sd.nrows + 1) / 2 * 2;       // (even: the y pieces are 16-byte DMA loads from 8-byte aligned labels)
+            DLSA_REQUIRE((double)(sd.nrows + 8 * 32) * (double)pitch * 8.0 < 2.0e9, "irls_fit (batched): a slab exceeds the 32-bit DMA offsets");
             slabs.push_back(sd);
         }
     }
@@ -176,7 +200,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
                  o_partial = carve((size_t)nslab * PP * PP * sizeof(double)), o_gpart = carve((size_t)nslab * GP * sizeof(double)),
                  o_g = carve(pb), o_ll = carve((size_t)K * sizeof(double)), o_llout = carve((size_t)K * sizeof(double)), o_delta = carve(pb),
                  o_stats = carve((size_t)K * 3 * sizeof(double)), o_beta = carve(pb), o_prev = carve(pb), o_step = carve(pb),
-                 o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256);
+                 o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256),
+                 o_ysrc = carve(gather_y ? (size_t)nslab * sizeof(int64_t) : 0), o_ybuf = carve(gather_y ? (size_t)(ytotal + 64) * sizeof(double) : 0);
     char* pool = nullptr;
     DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, off, stream));
     FusedSlab* d_slabs = (FusedSlab*)(pool + o_slabs);
@@ -187,12 +212,19 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
            *d_llout = (double*)(pool + o_llout), *d_delta = (double*)(pool + o_delta), *d_stats = (double*)(pool + o_stats),
            *d_beta = (double*)(pool + o_beta), *d_prev = (double*)(pool + o_prev), *d_step = (double*)(pool + o_step), *d_hinv = (double*)(pool + o_hinv);
     unsigned long long* d_clk = (unsigned long long*)(pool + o_clk);
+    int64_t* d_ysrc = (int64_t*)(pool + o_ysrc);
+    double* d_ybuf = (double*)(pool + o_ybuf);
+    const double* ylab = gather_y ? d_ybuf : y;
     auto release = [&]() { (void)hipFreeAsync(pool, stream); };
     int rc = DLSA_OK;
     auto fail = [&](int code) { release(); return code; };
 #define DLSA_BATCH_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return fail(DLSA_ERR_HIP); } } while (0)
     DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabs, slabs.data(), (size_t)nslab * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
     DLSA_BATCH_CHECK(hipMemcpyAsync(d_begin, slab_begin.data(), ((size_t)K + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (gather_y) {
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_ysrc, ysrc.data(), (size_t)nslab * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(batch_gather_y_kernel, dim3(nslab), dim3(256), 0, stream, y, (const FusedSlab*)d_slabs, (const int64_t*)d_ysrc, row_step, d_ybuf);
+    }
     {
         std::vector<int> ones((size_t)K, 1);
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_active, ones.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -206,10 +238,10 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     const int cap = 2 * max_iter + 66;
     int live = K;
     for (int it = 0; it < cap && live > 0; ++it) {
-        rc = irls_pass_batched_launch(X, ldx, y, d_beta, p, p, d_slabs, nslab, d_active, d_partial, d_gpart, d_clk, stream);
+        rc = irls_pass_batched_launch(X, pitch, ylab, d_beta, p, pdata, intercept, d_slabs, nslab, d_active, d_partial, d_gpart, d_clk, stream);
         if (rc) return fail(rc);
         hipLaunchKernelGGL(batch_unpack_kernel, dim3(K), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
-                           (const int*)d_begin, (const int*)d_active, PP, GP, ll_at, p, Sig_inv, d_g, d_ll);
+                           (const int*)d_begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, Sig_inv, d_g, d_ll);
         rc = launch_chol_small_batched(K, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
         if (rc) return fail(rc);
         DLSA_BATCH_CHECK(hipMemsetAsync(d_live, 0, sizeof(int), stream));

@@ -224,13 +224,18 @@ struct LogitState {
     double x[NTC][2];         // the lane's columns of its row
     double yv, eta, e, inv, mu, wgt, sv, num, den, q, kf, rr, resid;
     double ps[8];             // batched form: the eight partial sums of the lane's row
+    double vmask;             // ICPT: 1.0 for a row of the slab, 0.0 past its end (a factor costs no scalar register pair to keep)
     bool big, valid;
 };
 
 // HESS = false: the same streaming skeleton without the Hessian -- the logit pass of narrow designs (w, g, loglik) fed by the
 // LDS-DMA ring instead of logit.hip's register loads
-// BF: the batched form (its own instantiations: the slab table's extra arguments cost the widest w_out shapes their last scalar registers)
-template <bool WOUT, bool HESS, int NT, int G, bool BF = false>
+// BF: the batched form (its own instantiations: the slab table's extra arguments cost the widest w_out shapes their last scalar registers).
+// ICPT: the design is [X | 1] -- the implicit intercept of models.py:121-122 as the LAST column inside the kernel (NT, G are the shape of
+// p + 1 columns): the DMA never writes column p of a stage (its lanes end at the even p), so that column is set to 1.0 ONCE; rows past
+// the slab's end (zeros through the descriptor's bounds check, but a one in that column) are masked out of w, the residual and the
+// log-likelihood by the row's validity instead.  The host side rotates the intercept to the FRONT of g and H (models.py:136-142).
+template <bool WOUT, bool HESS, int NT, int G, bool BF = false, bool ICPT = false>
 __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 1)) void irls_pass_narrow_kernel(FusedArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         gxoff = rbeg * a.ldx; gyoff = rbeg;
     }
     const int nchunks = (nrows + KC - 1) / KC;
+    double* const wout_base = WOUT ? a.w_out + rbeg : nullptr;        // (one pointer instead of a pointer and a row offset kept through the loop)
 
     const unsigned xbytes = nrows > 0 ? (unsigned)(((int64_t)(nrows - 1) * a.ldx + a.p) * 8) : 0u;
     __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + gxoff), 0, (int)xbytes, 0x00020000);
@@ -281,6 +287,10 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     // columns p .. 16 NTC - 1 are never written by the DMA (lanes masked): the ring is zeroed once
     for (int e = tid; e < NST * BUF; e += THREADS) lds[e] = 0.0;
     __syncthreads();
+    if constexpr (ICPT) {
+        for (int e = tid; e < NST * KC; e += THREADS) lds[(e / KC) * BUF + (e % KC) * LDP + a.p] = 1.0;
+        __syncthreads();
+    }
 
     const bool col_in = 2 * lane < a.p;
     constexpr int RQ = KC / NWAVES / 4;                               // rows per wave and DMA part (two)
@@ -335,7 +345,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int col = 16 * q + 2 * ls + e;
-            bq[q][e] = col < a.p ? beta_in[col] : 0.0;
+            if constexpr (ICPT) bq[q][e] = col < a.p ? beta_in[col + 1] : (col == a.p ? beta_in[0] : 0.0);      // beta arrives intercept FIRST
+            else bq[q][e] = col < a.p ? beta_in[col] : 0.0;
             gacc[q][e] = 0.0;
         }
     // every lane of a row accumulates the row's loglik term (the eight copies are thinned out after the loop); rows past the slab's
@@ -373,7 +384,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
             L.x[q][0] = v.x; L.x[q][1] = v.y;
         }
         L.yv = base[YOFF + own_slot];
-        if constexpr (WOUT) L.valid = chunk * KC + own_row < nrows;
+        if constexpr (WOUT || ICPT) L.valid = chunk * KC + own_row < nrows;
+        if constexpr (ICPT) L.vmask = __hiloint2double(L.valid ? 0x3ff00000 : 0, 0);
     };
     auto lp_split = [&](double s) {               // the exponent split of exp(-|eta|)
         L.eta = s;
@@ -422,6 +434,10 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         L.mu = L.eta >= 0.0 ? inv : einv;
         L.wgt = einv * inv;
         L.resid = L.yv - L.mu;
+        if constexpr (ICPT) {                     // a row past the slab's end is all zeros but for the ones column: it must weigh nothing
+            L.wgt *= L.vmask;
+            L.resid *= L.vmask;
+        }
     };
     auto lp_mu = [&](int buf) {                   // mu, w -> the stage's w slot (read back by this wave's MFMA part next chunk)
         lp_mu_core();
@@ -461,12 +477,13 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         double pos;
         asm("v_max_f64 %0, %1, 0" : "=v"(pos) : "v"(L.eta));              // (fmax() puts a canonicalising v_max in front)
         const double softplus = pos + l1p;
-        llacc += fma(L.yv, L.eta, -softplus);
+        if constexpr (ICPT) llacc = fma(fma(L.yv, L.eta, -softplus), L.vmask, llacc);
+        else llacc += fma(L.yv, L.eta, -softplus);
     };
     auto lp_log = [&](int chunk) {
         lp_log_core();
         if constexpr (WOUT) {
-            if (ls == 0 && L.valid) a.w_out[rbeg + (int64_t)chunk * KC + own_row] = L.wgt;
+            if (ls == 0 && L.valid) wout_base[(int64_t)chunk * KC + own_row] = L.wgt;
         }
     };
     auto lp_grad = [&]() {
@@ -518,7 +535,8 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const d2 v = pr[k]; L.ps[2 * k] = v.x; L.ps[2 * k + 1] = v.y; }
         L.yv = lds[(b_h ? buf1 : buf0) * BUF + YOFF + b_slot];
-        if constexpr (WOUT) L.valid = (chunk0 + b_h) * KC + b_row < nrows;
+        if constexpr (WOUT || ICPT) L.valid = (chunk0 + b_h) * KC + b_row < nrows;
+        if constexpr (ICPT) L.vmask = __hiloint2double(L.valid ? 0x3ff00000 : 0, 0);
     };
     auto bp_sum = [&]() {
         lp_split(((L.ps[0] + L.ps[1]) + (L.ps[2] + L.ps[3])) + ((L.ps[4] + L.ps[5]) + (L.ps[6] + L.ps[7])));
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
     auto bp_log = [&](int chunk0) {
         lp_log_core();
         if constexpr (WOUT) {
-            if (lane < 16 && L.valid) a.w_out[rbeg + (int64_t)(chunk0 + b_h) * KC + b_row] = L.wgt;
+            if (lane < 16 && L.valid) wout_base[(int64_t)(chunk0 + b_h) * KC + b_row] = L.wgt;
         }
     };
     auto bp_gread = [&]() { resid_g[0] = scr[160 + lj]; resid_g[1] = scr[168 + lj]; };
@@ -747,7 +765,9 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
         }
     // loglik: one lane per row counts.  The zero rows evaluated past the slab's end -- chunks 0 .. nch_eval - 1 were evaluated -- each
     // added fma(0, 0, -softplus(0)) = -ln 2: taken out again (to the rounding of that one product).
-    if constexpr (BATCH) {
+    if constexpr (ICPT) {
+        llacc = (BATCH ? lane < 16 : ls == 0) ? llacc : 0.0;          // (invalid rows added nothing: nothing to take out)
+    } else if constexpr (BATCH) {
         // lane L < 16 evaluated row b_row of the chunks b_h, b_h + 2, ... below nch_eval (even)
         const int nch_eval = ((nchunks + 1) & ~1) + 2;
         int first_bad = nrows > b_row ? (nrows - b_row + KC - 1) / KC : 0;
@@ -784,8 +804,9 @@ __global__ __launch_bounds__(256, (!HESS ? fp_logit_wgs(NT + (G > 0 ? 1 : 0)) : 
 }
 
 // g [p] and loglik: the slab partials in a fixed order
+// (rot: the kernel's LAST column -- the implicit intercept -- is entry 0 of g, the others move up by one: models.py:136-142)
 __global__ __launch_bounds__(256) void irls_pass_finish_kernel(const double* __restrict__ gpart, int nslab, int GP, int p, int ll_at,
-                                                               double* __restrict__ g, double* __restrict__ loglik) {
+                                                               double* __restrict__ g, double* __restrict__ loglik, int rot) {
     __shared__ double red[16][17];
     const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
@@ -801,7 +822,7 @@ __global__ __launch_bounds__(256) void irls_pass_finish_kernel(const double* __r
 #pragma unroll
         for (int k = 1; k < 16; ++k) t += red[k][cl];
         if (is_ll) { if (loglik) *loglik = t; }
-        else if (g) g[col] = t;
+        else if (g) g[rot ? (col == p - 1 ? 0 : col + 1) : col] = t;
     }
 }
 
@@ -904,7 +925,90 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
                      nt > 6 ? (gt > 2 ? 2 : gt) : gt);
     if (H) gram_reduce_launch<double>((const double*)ws, nslab, a.PP, p, H, ldh, 0, stream);
     hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((p + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, p,
-                       16 * ntc, g, loglik);
+                       16 * ntc, g, loglik, 0);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+// ---- the fused pass for a design with the IMPLICIT intercept (dlsa_irls_fit_ex_f64 with intercept != 0; models.py:121-122): p data
+// columns, p + 1 = pe columns of beta / g / H with the intercept FIRST.  Kernel instantiations <true, true, NT, G, false, true>.
+bool irls_pass_fused_icpt_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p) {
+    const int pe = p + 1;
+    if (pe < FP_MIN_P || pe > FP_MAX_P || (p & 1) || n < FP_MIN_ROWS) return false;
+    const char* e = knob("DLSA_IRLS_FUSED");
+    if (e && atoi(e) == 0) return false;
+    int nt, gt;
+    fp_shape(pe, nt, gt);
+    if (nt == 6 && gt == 3) return false;         // (p + 1 = 105 .. 108 with w_out: five VGPRs short; those fits keep the two launches)
+    int64_t rps;
+    fp_slabs(n, rps);
+    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0 && (double)(rps + 8 * FP_KC) * (double)ldx * 8.0 < 2.0e9;
+}
+
+// slab partials (kernel column order: intercept LAST) -> H with the intercept first, both triangles; fixed order over the slabs
+__global__ __launch_bounds__(256) void fused_reduce_icpt_kernel(const double* __restrict__ partial, int nslab, int PP, int pe,
+                                                                double* __restrict__ H, int64_t ldh) {
+    __shared__ double part[16][17];
+    const int jl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jl, i = blockIdx.y;
+    if (blockIdx.x * 16 + 15 < i) return;
+    const bool live = j < pe && j >= i;
+    double s0 = 0.0;
+    if (live)
+        for (int k = kg; k < nslab; k += 16) s0 += partial[(int64_t)k * PP * PP + (int64_t)i * PP + j];
+    part[kg][jl] = s0;
+    __syncthreads();
+    if (kg == 0 && live) {
+        double s = part[0][jl];
+#pragma unroll
+        for (int g2 = 1; g2 < 16; ++g2) s += part[g2][jl];
+        const int io = i == pe - 1 ? 0 : i + 1, jo = j == pe - 1 ? 0 : j + 1;
+        H[(int64_t)io * ldh + jo] = s;
+        H[(int64_t)jo * ldh + io] = s;
+    }
+}
+
+int irls_pass_icpt_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
+                        double* g, double* loglik, double* w_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+    const int pe = p + 1;
+    DLSA_REQUIRE(X && y && beta && H && w_out && ldh >= pe, "irls_pass (intercept): null argument or ldh < p + 1");
+    FusedArgs a;
+    a.slabs = nullptr; a.active = nullptr; a.beta_stride = 0;
+    a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p; a.PP = (int)fp_pp(pe);
+    int nt, gt;
+    fp_shape(pe, nt, gt);
+    const int ntc = nt + (gt > 0 ? 1 : 0), GP = fp_gp(ntc);
+    const int nslab = fp_slabs(n, a.rows_per_slab, 1);
+    const size_t part = align_up((size_t)nslab * a.PP * a.PP * 8, 256), gpb = align_up((size_t)nslab * GP * 8, 256);
+    const size_t need = part + gpb + kGramProbeBytes;
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+        set_error("irls_pass (intercept): workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+        return DLSA_ERR_WORKSPACE;
+    }
+    a.partial = (double*)ws;
+    a.gpart = (double*)((char*)ws + part);
+    a.clk = (unsigned long long*)((char*)ws + part + gpb);
+#define DLSA_LAUNCH_FPI(NTV, GV) do { \
+        const size_t shm = fp_hess_lds(NTV, GV); \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<true, true, NTV, GV, false, true>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<true, true, NTV, GV, false, true>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_FPI_G(NTV) do { switch (gt) { \
+        case 0: DLSA_LAUNCH_FPI(NTV, 0); break; case 1: DLSA_LAUNCH_FPI(NTV, 1); break; \
+        case 2: DLSA_LAUNCH_FPI(NTV, 2); break; default: DLSA_LAUNCH_FPI(NTV, 3); break; } } while (0)
+    switch (nt) {
+        case 3: DLSA_LAUNCH_FPI_G(3); break; case 4: DLSA_LAUNCH_FPI_G(4); break;
+        case 5: DLSA_LAUNCH_FPI_G(5); break;
+        case 6: switch (gt) { case 0: DLSA_LAUNCH_FPI(6, 0); break; case 1: DLSA_LAUNCH_FPI(6, 1); break; default: DLSA_LAUNCH_FPI(6, 2); break; } break;
+        default: switch (gt) { case 0: DLSA_LAUNCH_FPI(7, 0); break; case 1: DLSA_LAUNCH_FPI(7, 1); break; default: DLSA_LAUNCH_FPI(7, 2); break; } break;
+    }
+#undef DLSA_LAUNCH_FPI_G
+#undef DLSA_LAUNCH_FPI
+    DLSA_HIP_CHECK(hipGetLastError());
+    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<true,true,%d,%d,icpt>", nt > 6 ? 7 : nt, nt > 6 ? (gt > 2 ? 2 : gt) : gt);
+    hipLaunchKernelGGL(fused_reduce_icpt_kernel, dim3((pe + 15) / 16, pe), dim3(256), 0, stream, (const double*)ws, nslab, a.PP, pe, H, ldh);
+    hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((pe + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, pe,
+                       16 * ntc, g, loglik, 1);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
@@ -921,23 +1025,32 @@ int irls_pass_batched_ll_at(int p) {
     fp_shape(p, nt, gt);
     return 16 * (nt + (gt > 0 ? 1 : 0));
 }
-bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p) {
-    return p >= FP_MIN_P && p <= FP_MAX_P && !(p & 1) && ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0;
+// (p = data columns; with the implicit intercept the kernel's shape is that of p + 1 columns, the PP / GP / ll_at queries take p + 1)
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept) {
+    const int pe = p + (intercept ? 1 : 0);
+    return pe >= FP_MIN_P && pe <= FP_MAX_P && !(p & 1) && ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0;
 }
-int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p,
+int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
                              unsigned long long* clk, hipStream_t stream) {
+    const int pe = p + (intercept ? 1 : 0);
     FusedArgs a;
     a.slabs = d_slabs; a.active = d_active; a.beta_stride = beta_stride;
-    a.X = X; a.y = y; a.beta = beta; a.w_out = nullptr; a.ldx = ldx; a.n = 0; a.rows_per_slab = 0; a.p = p; a.PP = (int)fp_pp(p);
+    a.X = X; a.y = y; a.beta = beta; a.w_out = nullptr; a.ldx = ldx; a.n = 0; a.rows_per_slab = 0; a.p = p; a.PP = (int)fp_pp(pe);
     a.partial = partial; a.gpart = gpart; a.clk = clk;
     int nt, gt;
-    fp_shape(p, nt, gt);
+    fp_shape(pe, nt, gt);
 #define DLSA_LAUNCH_FPB(NTV, GV) do { \
         const size_t shm = fp_hess_lds(NTV, GV); \
-        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true>), \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+        if (intercept) { \
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true, true>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+            hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true, true>), dim3(nslab), dim3(256), shm, stream, a); \
+        } else { \
+            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+            hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true>), dim3(nslab), dim3(256), shm, stream, a); \
+        } } while (0)
 #define DLSA_LAUNCH_FPB_G(NTV) do { switch (gt) { \
         case 0: DLSA_LAUNCH_FPB(NTV, 0); break; case 1: DLSA_LAUNCH_FPB(NTV, 1); break; \
         case 2: DLSA_LAUNCH_FPB(NTV, 2); break; default: DLSA_LAUNCH_FPB(NTV, 3); break; } } while (0)

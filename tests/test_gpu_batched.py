@@ -87,3 +87,27 @@ def test_lock_step_partitions_end_independently(eng, orc):
     for k in (0, 2, 3):
         co, _, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
         assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
+
+
+@pytest.mark.parametrize("p,K,n,icpt,strided", [(100, 12, 150001, True, False), (100, 10, 100000, True, True), (64, 16, 96000, False, True),
+                                                  (50, 7, 70007, True, True), (110, 6, 60000, True, False)])
+def test_lock_step_with_intercept_and_strided_partitions(eng, orc, p, K, n, icpt, strided):
+    """the reference-faithful call: partition_id = i % K (models.py:33: the strided views X[k::K]) and fit_intercept (logistic_dlsa.py:79)
+    -- the fused kernel carries the intercept as a ones column in its LDS stages, the slabs walk the rows with pitch ldx K"""
+    import dlsa_amd
+    X, y = eng.synth(3100 + p + K, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    kw = dict(partition_num=K) if strided else dict(part_offsets=[int(n * k / K) for k in range(K + 1)])
+    b = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, batched=True, small=False, **kw)
+    assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED
+    c = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, batched=False, small=False, **kw)
+    assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS
+    assert b.status == c.status == [0] * K and b.names == c.names
+    for key in ("coef", "Sig_inv", "Sig_invMcoef"):
+        assert rel_inf(getattr(b, key).cpu().numpy(), getattr(c, key).cpu().numpy()) < 1e-10, key
+    k = K - 1
+    rows = np.arange(k, n, K) if strided else np.arange(int(n * k / K), n)
+    co, smc, sig = orc.logistic_model_block(X.cpu().numpy()[rows], y.cpu().numpy()[rows], icpt)
+    assert rel_inf(b.coef[k].cpu().numpy(), co) < 1e-10 and rel_inf(b.Sig_inv[k].cpu().numpy(), sig) < 1e-10
+    assert rel_inf(b.Sig_invMcoef[k].cpu().numpy(), smc) < 1e-10
+    out = dlsa_amd.dlsa_mapred(b)                                   # and the reduce takes the blocks as they are
+    assert list(out.columns[:2]) == ["beta_byOLS", "beta_byONESHOT"] and out.shape == (p + int(icpt), 2 + p + int(icpt))

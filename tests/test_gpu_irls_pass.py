@@ -138,3 +138,29 @@ def test_ring_logit_pass_short_rows_two_workgroups_per_cu(eng, orc, p, n):
     assert abs(float(ll) - llo) < 1e-12 * abs(llo)
     w2, g2, ll2 = eng.logit_pass(Xd, yd, bd)
     assert torch.equal(w, w2) and torch.equal(g, g2) and torch.equal(ll, ll2)
+
+
+@pytest.mark.parametrize("p,n", [(100, 40011), (50, 9001), (64, 20000), (118, 33333), (98, 16385)])
+def test_fits_with_the_implicit_intercept_take_the_fused_pass(eng, orc, p, n):
+    """Round 4: the fused kernel carries the intercept of models.py:121-122 as a ones column in its LDS stages (the reference's driver
+    always fits one, logistic_dlsa.py:79), rows past a slab's end masked by their validity.  A fit with fit_intercept must give the
+    two-launch path's and the oracle's MLE / Hessian, intercept first (models.py:136-142), for ragged row counts too."""
+    X, y = orc.synth_logistic(500 + p, 0, n, p, orc.SYNTH_GAUSSIAN)
+    Xd, yd = dev(X), dev(y)
+    first, rows = [0, n // 3], [n // 3, n - n // 3]
+    with eng.irls_options(batched=False, small=False):
+        f = eng.irls_fit_ex(Xd, yd, first, rows, fit_intercept=True)
+    kern = eng.gram_last_kernel()[0]
+    assert "icpt" in kern or rows[1] < 8192, kern
+    with eng.irls_options(batched=False, small=False, fused=False):
+        u = eng.irls_fit_ex(Xd, yd, first, rows, fit_intercept=True)
+    assert f["status"] == u["status"] == [0, 0]
+    for key in ("coef", "Sig_inv", "Sig_invMcoef"):
+        assert rel_inf(f[key].cpu().numpy(), u[key].cpu().numpy()) < 1e-10, key
+    k = 1
+    co, smc, sig = orc.logistic_model_block(X[first[k]:first[k] + rows[k]], y[first[k]:first[k] + rows[k]], True)
+    assert rel_inf(f["coef"][k].cpu().numpy(), co) < 1e-10
+    assert rel_inf(f["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
+    assert rel_inf(f["Sig_invMcoef"][k].cpu().numpy(), smc) < 1e-10
+    S = f["Sig_inv"][k].cpu().numpy()
+    assert np.array_equal(S, S.T) and abs(S[0, 0] - float(np.sum(orc.logit_pass(np.hstack([np.ones((rows[k], 1)), X[first[k]:]]), y[first[k]:], co)[0]))) < 1e-9 * S[0, 0]

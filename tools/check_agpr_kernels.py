@@ -175,7 +175,7 @@ def expected_agprs(name):
         nt, g = int(m.group(1)), int(m.group(2))
         nreg = 8 * (nt * (nt + 1) // 2) + 2 * (nt + 1) * g          # gram_narrow.hip: narrow_nreg
         return nreg, (256 if nreg <= 184 else 512)                 # narrow_wgs_per_cu: two workgroups of 4 waves per CU
-    m = re.search(r"irls_pass_narrow_kernelILb[01]ELb1ELi(\d+)ELi(\d+)ELb[01]EE", name)
+    m = re.search(r"irls_pass_narrow_kernelILb[01]ELb1ELi(\d+)ELi(\d+)ELb[01]ELb[01]EE", name)
     if m:                                                          # irls_pass.hip: one wave per SIMD
         nt, g = int(m.group(1)), int(m.group(2))
         return 8 * (nt * (nt + 1) // 2) + 2 * (nt + 1) * g, 512
