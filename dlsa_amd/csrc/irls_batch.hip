@@ -79,7 +79,9 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
                                                            double* __restrict__ prev, double* __restrict__ stepv, BatchState* __restrict__ st,
                                                            int* __restrict__ active, int* __restrict__ n_live, double* __restrict__ coef,
                                                            double* __restrict__ smc, double* __restrict__ loglik, int* __restrict__ n_iter,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, int phase_a) {
+    // phase_a: the cold start on the partitions' leading rows -- a partition that ends there writes no outputs (a failed one goes back
+    // to beta = 0): batch_restart_kernel then opens the full-row phase from the subsample MLEs
     const int k = blockIdx.x, j = threadIdx.x;
     if (!active[k]) return;
     BatchState s = st[k];
@@ -109,7 +111,10 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
             if (s.iters >= max_iter) s.last_pass = 1;
         }
     }
-    if (end >= 0) {
+    if (end >= 0 && phase_a) {
+        if (end != DLSA_PART_OK && j < p) bk[j] = 0.0;
+        s.status = end;
+    } else if (end >= 0) {
         // outputs: coef, Sig_inv . coef (models.py:131); Sig_inv is the H the unpack kernel has just written in place
         const double* Hk = H + (int64_t)k * p * p;
         if (j < p) {
@@ -127,6 +132,16 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
         if (end >= 0) active[k] = 0;
         else atomicAdd(n_live, 1);
     }
+}
+
+// between the subsample phase and the full-row phase: everybody is live again, the safeguard's memory is cleared (another objective)
+__global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __restrict__ active) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    BatchState s = st[k];
+    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0;
+    st[k] = s;
+    active[k] = 1;
 }
 
 // Is the lock-step path the faster one?  Measured constants: a fused pass streams ~4.5e9 rows/s at p = 100 (scaled by the width), an
@@ -189,6 +204,37 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     }
     slab_begin[(size_t)K] = (int)slabs.size();
     const int nslab = (int)slabs.size();
+    // ---- cold start: the first Newton iterations from beta = 0 run on the leading 1 / 8 of every partition's rows (they only have to
+    // get near the MLE: 4-5 passes at an eighth of the cost), then the full-row iterations start from there (3-4 passes instead of 7).
+    // Only when every partition's eighth still pins its MLE (>= 40 rows per coefficient, >= 2048 rows).
+    std::vector<FusedSlab> slabsA;
+    std::vector<int> beginA((size_t)K + 1, 0);
+    bool phase_a = true;
+    {
+        const char* e = knob("DLSA_IRLS_SUBSAMPLE");
+        int64_t mn = INT64_MAX;
+        for (int k = 0; k < K; ++k) mn = std::min(mn, rows_host[k]);
+        const int64_t need_rows = std::max<int64_t>(2048, 40 * (int64_t)p);
+        const int div = e ? atoi(e) : (mn / 8 / 32 * 32 >= need_rows ? 8 : 4);       // an eighth where that is enough rows, else a quarter
+        if (div < 2) phase_a = false;
+        for (int k = 0; k < K && phase_a; ++k) {
+            const int64_t nA = rows_host[k] / div / 32 * 32;
+            if (nA < std::max<int64_t>(2048, 40 * (int64_t)p)) { phase_a = false; break; }
+            const FusedSlab& f0 = slabs[(size_t)slab_begin[(size_t)k]];       // (the labels of a partition's leading rows lead its gathered labels)
+            const int nsl = (int)std::max<int64_t>(1, (nA + slab_cap - 1) / slab_cap);
+            const int64_t per = ((nA + nsl - 1) / nsl + 31) / 32 * 32;
+            beginA[(size_t)k] = (int)slabsA.size();
+            for (int64_t r = 0; r < nA; r += per) {
+                FusedSlab sd;
+                sd.xoff = f0.xoff + r * pitch; sd.yoff = f0.yoff + r;
+                sd.nrows = (int)std::min<int64_t>(per, nA - r); sd.part = k;
+                slabsA.push_back(sd);
+            }
+        }
+        beginA[(size_t)K] = (int)slabsA.size();
+        if (!phase_a) slabsA.clear();
+    }
+    const int nslabA = (int)slabsA.size();
 
     // ---- scratch: ONE block from the stream-ordered pool, freed before the call returns
     const size_t pb = (size_t)K * p * sizeof(double);
@@ -201,7 +247,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
                  o_g = carve(pb), o_ll = carve((size_t)K * sizeof(double)), o_llout = carve((size_t)K * sizeof(double)), o_delta = carve(pb),
                  o_stats = carve((size_t)K * 3 * sizeof(double)), o_beta = carve(pb), o_prev = carve(pb), o_step = carve(pb),
                  o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256),
-                 o_ysrc = carve(gather_y ? (size_t)nslab * sizeof(int64_t) : 0), o_ybuf = carve(gather_y ? (size_t)(ytotal + 64) * sizeof(double) : 0);
+                 o_ysrc = carve(gather_y ? (size_t)nslab * sizeof(int64_t) : 0), o_ybuf = carve(gather_y ? (size_t)(ytotal + 64) * sizeof(double) : 0),
+                 o_slabsA = carve((size_t)nslabA * sizeof(FusedSlab)), o_beginA = carve(((size_t)K + 1) * sizeof(int));
     char* pool = nullptr;
     DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, off, stream));
     FusedSlab* d_slabs = (FusedSlab*)(pool + o_slabs);
@@ -215,6 +262,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     int64_t* d_ysrc = (int64_t*)(pool + o_ysrc);
     double* d_ybuf = (double*)(pool + o_ybuf);
     const double* ylab = gather_y ? d_ybuf : y;
+    FusedSlab* d_slabsA = (FusedSlab*)(pool + o_slabsA);
+    int* d_beginA = (int*)(pool + o_beginA);
     auto release = [&]() { (void)hipFreeAsync(pool, stream); };
     int rc = DLSA_OK;
     auto fail = [&](int code) { release(); return code; };
@@ -224,6 +273,10 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     if (gather_y) {
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_ysrc, ysrc.data(), (size_t)nslab * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(batch_gather_y_kernel, dim3(nslab), dim3(256), 0, stream, y, (const FusedSlab*)d_slabs, (const int64_t*)d_ysrc, row_step, d_ybuf);
+    }
+    if (phase_a) {
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabsA, slabsA.data(), (size_t)nslabA * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_beginA, beginA.data(), ((size_t)K + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     }
     {
         std::vector<int> ones((size_t)K, 1);
@@ -237,21 +290,36 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
 
     const int cap = 2 * max_iter + 66;
     int live = K;
-    for (int it = 0; it < cap && live > 0; ++it) {
-        rc = irls_pass_batched_launch(X, pitch, ylab, d_beta, p, pdata, intercept, d_slabs, nslab, d_active, d_partial, d_gpart, d_clk, stream);
+    // one phase: passes over the given slab table until no partition is live
+    auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a) -> int {
+        live = K;
+        for (int it = 0; it < cap && live > 0; ++it) {
+            int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream);
+            if (r) return r;
+            hipLaunchKernelGGL(batch_unpack_kernel, dim3(K), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
+                               begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, Sig_inv, d_g, d_ll);
+            r = launch_chol_small_batched(K, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
+            if (r) return r;
+            if (hipMemsetAsync(d_live, 0, sizeof(int), stream) != hipSuccess) return DLSA_ERR_HIP;
+            hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, stream, p, ptol, max_iter, (const double*)Sig_inv, (const double*)d_ll,
+                               (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
+                               Sig_invMcoef, d_llout, d_iter, d_status, in_a);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) {
+                set_error("irls_fit (batched): a launch or the read-back of the live count failed");
+                return DLSA_ERR_HIP;
+            }
+        }
+        return DLSA_OK;
+    };
+    if (phase_a) {
+        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 1e-4), 1);
         if (rc) return fail(rc);
-        hipLaunchKernelGGL(batch_unpack_kernel, dim3(K), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
-                           (const int*)d_begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, Sig_inv, d_g, d_ll);
-        rc = launch_chol_small_batched(K, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
-        if (rc) return fail(rc);
-        DLSA_BATCH_CHECK(hipMemsetAsync(d_live, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, stream, p, tol, max_iter, (const double*)Sig_inv, (const double*)d_ll,
-                           (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
-                           Sig_invMcoef, d_llout, d_iter, d_status);
-        DLSA_BATCH_CHECK(hipGetLastError());
-        DLSA_BATCH_CHECK(hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream));
-        DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
+        // (a partition still live after the cap restarts like a failed one would: from where it is)
+        hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
     }
+    rc = run_phase(d_slabs, nslab, d_begin, tol, 0);
+    if (rc) return fail(rc);
     if (live > 0) { set_error("irls_fit (batched): %d partitions still live after %d passes", live, cap); return fail(DLSA_ERR_INVALID); }
     if (n_iter_host) DLSA_BATCH_CHECK(hipMemcpyAsync(n_iter_host, d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (status_host) DLSA_BATCH_CHECK(hipMemcpyAsync(status_host, d_status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
