@@ -161,3 +161,21 @@ def test_preflight_only_run_needs_no_json_line(monkeypatch):
     assert bench.main() == 0
     monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=3, stdout=""))
     assert bench.main() == 3
+
+
+def test_committed_kernel_evidence_matches_the_tree():
+    """profiles/r04_pmc_<kernel>.json (bench/pmc_evidence.py) carry the hash of the sources they were taken from: a kernel whose
+    sources changed since needs its counters taken again (python3 bench/pmc_evidence.py r04 <tag> on the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, "bench"))
+    import pmc_evidence as ev
+    stale = []
+    for tag, k in ev.KERNELS.items():
+        path = ev.evidence_path("r04", tag)
+        assert os.path.exists(path), "missing " + path
+        doc = json.load(open(path))
+        if doc["sources_sha16"] != ev.sources_sha16(k["src"]):
+            stale.append(tag)
+        assert doc["kernels"], tag
+        kk = next(iter(doc["kernels"].values()))
+        assert kk.get("duration_ms_under_pmc", 0) > 0 and "GRBM_GUI_ACTIVE" in kk and "FETCH_SIZE" in kk, tag
+    assert not stale, "stale evidence for: " + ", ".join(stale)

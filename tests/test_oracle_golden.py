@@ -164,3 +164,21 @@ def test_synth_rows_are_pure_functions_of_index():
     assert X.min() >= -0.5 and X.max() < 0.5
     G = orc.synth_features(7, 0, 20000, 4, orc.SYNTH_GAUSSIAN)
     assert abs(G.std() - (1 / 12) ** 0.5) < 0.01 and abs(G.mean()) < 0.01
+
+
+def test_oracle_fp32_linear_stream_is_a_function_of_seed_and_row():
+    """oracle.synth_linear32 (the restatement of csrc/synth.hip's fp32-native linear stream): rows depend on (seed, row index) only,
+    the features have the stated moments, the response is X beta* + sigma N(0, 1)."""
+    from oracle import dlsa_oracle as orc
+    X, y = orc.synth_linear32(11, 1000, 6000, 10, sigma=0.5)
+    Xa, ya = orc.synth_linear32(11, 1000, 2500, 10, sigma=0.5)
+    Xb, yb = orc.synth_linear32(11, 3500, 3500, 10, sigma=0.5)
+    assert X.dtype == np.float32 and y.dtype == np.float32
+    assert np.array_equal(np.vstack([Xa, Xb]), X) and np.array_equal(np.concatenate([ya, yb]), y)
+    assert not np.array_equal(orc.synth_linear32(12, 1000, 100, 10)[0], X[:100])
+    Xl, yl = orc.synth_linear32(5, 0, 200000, 6, sigma=2.0)
+    assert abs(float(Xl.mean())) < 3e-3 and abs(float(Xl.var()) - 1.0 / 12.0) < 2e-3
+    C = np.corrcoef(Xl.astype(np.float64), rowvar=False)
+    assert np.max(np.abs(C - np.eye(6))) < 0.01
+    r = yl.astype(np.float64) - Xl.astype(np.float64) @ orc.true_beta(6)
+    assert abs(r.mean()) < 0.02 and abs(r.std() - 2.0) < 0.02
