@@ -13,9 +13,11 @@ worst = dict(score=0.0, H=0.0, smc=0.0, ll=0.0)
 paths = {}
 for c in range(cases):
     p = int(rng.choice([rng.integers(2, 30), rng.integers(30, 70), 2 * rng.integers(25, 61), rng.integers(60, 130), rng.integers(130, 320)]))
-    K = int(rng.choice([1, 1, 2, 3, 7]))
+    K = int(rng.choice([1, 1, 2, 3, 7, 12, 40]))          # (>= 8 partitions of a fused-class width: the lock-step driver's territory)
     per = int(rng.choice([rng.integers(40 * p, 80 * p), rng.integers(200 * p, 400 * p), rng.integers(8192, 40000), rng.integers(100000, 400000)]))
     per = max(per, 40 * p)
+    if K >= 12:
+        per = min(per, 60000)
     n = per * K + int(rng.integers(0, 5))
     if n * p > 3e8:
         n = int(3e8 // p); per = n // K
@@ -26,6 +28,11 @@ for c in range(cases):
     print_case = lambda: print("CASE %d: n=%d p=%d K=%d strided=%s icpt=%s kind=%d" % (c, n, p, K, strided, icpt, kind), flush=True)
     if os.environ.get("FIT_FUZZ_VERBOSE"):
         print_case()
+    # the driver is the library's choice, or forced: lock step where it applies / the chained path
+    force = rng.choice(["auto", "auto", "lock", "chains"])
+    opt = {} if force == "auto" else (dict(batched=True, small=False) if force == "lock" else dict(batched=False))
+    ctx = engine.irls_options(**opt)
+    ctx.__enter__()
     if strided:
         first, rows = list(range(K)), [(n - k + K - 1) // K for k in range(K)]
         r = engine.irls_fit_ex(X, y, first, rows, row_step=K, fit_intercept=icpt)
@@ -38,8 +45,11 @@ for c in range(cases):
         offs = [int(n * k / K) for k in range(K + 1)]
         r = engine.irls_fit(X, y, offs)
         parts = [(X[offs[k]:offs[k + 1]], y[offs[k]:offs[k + 1]]) for k in range(K)]
+    ctx.__exit__(None, None, None)
     key = ("strided" if strided else "ranges") + ("+icpt" if icpt else "")
     paths[key] = paths.get(key, 0) + 1
+    drv = ("chains", "small", "lock step")[engine.irls_last_fit_path()]
+    paths["driver: " + drv] = paths.get("driver: " + drv, 0) + 1
     assert r["status"] == [0] * K, ("status", c, n, p, K, key, r["status"], r["n_iter"])
     for k, (Xk, yk) in enumerate(parts):
         A = torch.cat([torch.ones((Xk.shape[0], 1), dtype=torch.float64, device="cuda"), Xk], 1) if (icpt) else Xk.contiguous()
