@@ -135,6 +135,10 @@ struct LogitArgs {
     // X'(y - mu) resp. X'v.  For xtv, a null y stands for the all-ones vector.
     const double* beta0;
     double* s0part;
+    // BORDER form: the intercept's border of the Hessian [1 | X]' W [1 | X] (models.py:121-130) from the weights this pass computes
+    // anyway -- hpart [nblocks][NC*128] = X'w per block, swpart [nblocks] = sum w -- so that the Gram that follows needs no pass of its own
+    double* hpart = nullptr;
+    double* swpart = nullptr;
 };
 
 // g += sum_i resid(row i) * x_i : the residual of row i sits in lane lane_of_row(i) and is broadcast through SGPRs
@@ -151,22 +155,25 @@ __device__ __forceinline__ void rank1_update(double resid, const double2 (&x)[RB
     }
 }
 
-template <int NC, int RB, bool VEC>
+template <int NC, int RB, bool VEC, bool BORDER = false>
 __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     __shared__ double red[NC * 128 + 2];
+    __shared__ double redh[BORDER ? NC * 128 + 1 : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const double b0 = a.beta0 ? *a.beta0 : 0.0;
     double s0 = 0.0;
 
-    double2 b[NC], g[NC];
+    double2 b[NC], g[NC], h[BORDER ? NC : 1];
+    double sw = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int col = c * 128 + 2 * lane;
         b[c].x = col < a.p ? a.beta[col] : 0.0;
         b[c].y = col + 1 < a.p ? a.beta[col + 1] : 0.0;
         g[c].x = 0.0; g[c].y = 0.0;
+        if constexpr (BORDER) { h[c].x = 0.0; h[c].y = 0.0; }
     }
     double ll = 0.0;
     const int myrow = row_of_lane<RB>(lane);
@@ -230,6 +237,11 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
             s0 += resid;
         }
         rank1_update<RB, NC, 0>(resid, x, g);
+        if constexpr (BORDER) {                 // X'w and sum w of the same rows (a clamped row past n weighs nothing)
+            const double wv = valid ? wgt : 0.0;
+            if (rep) sw += wv;
+            rank1_update<RB, NC, 0>(wv, x, h);
+        }
     };
 
     int64_t bt = (int64_t)blockIdx.x * LOGIT_WAVES + wave;
@@ -262,6 +274,8 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
 
     // block reduction of g and loglik: waves add into LDS one after another (fixed order)
     for (int m = 32; m >= 1; m >>= 1) { ll += __shfl_xor(ll, m, 64); s0 += __shfl_xor(s0, m, 64); }
+    if constexpr (BORDER)
+        for (int m = 32; m >= 1; m >>= 1) sw += __shfl_xor(sw, m, 64);
     for (int wv = 0; wv < LOGIT_WAVES; ++wv) {
         if (wave == wv) {
 #pragma unroll
@@ -269,7 +283,13 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
                 double* dst = red + c * 128 + 2 * lane;
                 if (wv == 0) { dst[0] = g[c].x; dst[1] = g[c].y; }
                 else { dst[0] += g[c].x; dst[1] += g[c].y; }
+                if constexpr (BORDER) {
+                    double* dh = redh + c * 128 + 2 * lane;
+                    if (wv == 0) { dh[0] = h[c].x; dh[1] = h[c].y; }
+                    else { dh[0] += h[c].x; dh[1] += h[c].y; }
+                }
             }
+            if constexpr (BORDER) { if (lane == 0) { if (wv == 0) redh[NC * 128] = sw; else redh[NC * 128] += sw; } }
             if (lane == 0) {
                 if (wv == 0) { red[NC * 128] = ll; red[NC * 128 + 1] = s0; }
                 else { red[NC * 128] += ll; red[NC * 128 + 1] += s0; }
@@ -280,6 +300,11 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     double* gp = a.gpart + (int64_t)blockIdx.x * (NC * 128);
     for (int col = tid; col < NC * 128; col += LOGIT_THREADS) gp[col] = red[col];
     if (tid == 0) { a.llpart[blockIdx.x] = red[NC * 128]; if (a.s0part) a.s0part[blockIdx.x] = red[NC * 128 + 1]; }
+    if constexpr (BORDER) {
+        double* hp = a.hpart + (int64_t)blockIdx.x * (NC * 128);
+        for (int col = tid; col < NC * 128; col += LOGIT_THREADS) hp[col] = redh[col];
+        if (tid == 0) a.swpart[blockIdx.x] = redh[NC * 128];
+    }
 }
 
 // g[col] = sum_b gpart[b][col], loglik = sum_b llpart[b].  One workgroup per 16 columns (32 workgroups at p = 500:
@@ -363,6 +388,10 @@ static int logit_blocks(int64_t n, int rb) {
 
 template <int NC, int RB>
 static void launch_logit(const LogitArgs& a, bool vec, int blocks, hipStream_t s) {
+    if (a.hpart) {          // BORDER form (vector loads only: logit_border_ok)
+        hipLaunchKernelGGL((logit_kernel<NC, RB, true, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+        return;
+    }
     if (vec) hipLaunchKernelGGL((logit_kernel<NC, RB, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
     else hipLaunchKernelGGL((logit_kernel<NC, RB, false>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
 }
@@ -370,8 +399,9 @@ static void launch_logit(const LogitArgs& a, bool vec, int blocks, hipStream_t s
 size_t logit_workspace_bytes_impl(int64_t n, int p) {
     (void)n;
     const int nc = logit_nc(p);
-    return align_up((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double), 256) +
-           2 * align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
+    // (twice the g partials and three scalar partials: the BORDER form's X'w / sum w share the arena)
+    return 2 * align_up((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double), 256) +
+           3 * align_up((size_t)LOGIT_MAX_BLOCKS * sizeof(double), 256);
 }
 
 // irls_pass.hip: the streaming skeleton of the fused Newton pass (rows through an LDS-DMA ring) without the Hessian
@@ -380,9 +410,27 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
                    double* g, double* loglik, double* w_out, double* w_scratch, void* ws, size_t ws_bytes, hipStream_t stream,
                    int* fused_out);
 
+static int logit_pass_run(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
+                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border);
+
 // intercept != 0: beta and g have p + 1 entries, [intercept | the p columns of X]; X itself has p columns.
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
                     double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept) {
+    return logit_pass_run(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, stream, intercept, nullptr);
+}
+
+// The logit pass of a fit with the implicit intercept that ALSO leaves border[0] = sum w, border[1 .. p] = X'w (the first row of
+// [1 | X]' W [1 | X], models.py:121-130) from the weights it computes: the Gram pass that follows then needs no border pass of its
+// own (config 3's reference-faithful call: one 100 GB read less per fresh Hessian).  Vector-load shapes only (logit_border_ok).
+bool logit_border_ok(const double* X, int64_t ldx, int p) { return (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0); }
+int logit_pass_border_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
+                           double* w_out, double* g, double* loglik, double* border, void* ws, size_t ws_bytes, hipStream_t stream) {
+    DLSA_REQUIRE(border && logit_border_ok(X, ldx, p), "logit_pass (border): needs a border buffer and 16-byte aligned rows of even length");
+    return logit_pass_run(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, stream, 1, border);
+}
+
+static int logit_pass_run(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
+                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border) {
     DLSA_REQUIRE(X && y && beta, "logit_pass: null X, y or beta");
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p, "logit_pass: bad shape n=%lld p=%d ldx=%lld", (long long)n, p, (long long)ldx);
     DLSA_REQUIRE(p <= 2048, "logit_pass: p=%d > 2048 not supported", p);
@@ -405,6 +453,8 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     a.llpart = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
     a.s0part = (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double));
     a.beta0 = intercept ? beta : nullptr;
+    a.hpart = border ? (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double)) : nullptr;
+    a.swpart = border ? (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double)) : nullptr;
     const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {
@@ -418,6 +468,10 @@ int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double*
     if (g || loglik) {
         logit_finish_launch((const double*)a.gpart, (const double*)a.llpart, blocks, nc * 128, p, (g && intercept) ? g + 1 : g,
                             loglik, stream, (g && intercept) ? (const double*)a.s0part : nullptr, (g && intercept) ? g : nullptr);
+        DLSA_HIP_CHECK(hipGetLastError());
+    }
+    if (border) {           // the same fixed-order sums for X'w (-> border[1 ..]) and sum w (-> border[0], through the kernel's loglik slot)
+        logit_finish_launch((const double*)a.hpart, (const double*)a.swpart, blocks, nc * 128, p, border + 1, border, stream, nullptr, nullptr);
         DLSA_HIP_CHECK(hipGetLastError());
     }
     return DLSA_OK;
