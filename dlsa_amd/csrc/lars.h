@@ -1,0 +1,36 @@
+// Arguments and workspace of the LARS path kernels (lars.hip: R^{-1} form, one workgroup or a grid; lars_q.hip: carried
+// Cholesky rows, one workgroup).  Reference: lars_lsa, dlsa/lsa.py:90-212.
+#pragma once
+#include "common.h"
+
+namespace dlsa {
+
+struct LarsArgs {
+    const double* Sigma0;   // p x p
+    const double* b0;       // p
+    int64_t lds0;
+    int p, intercept, type, max_steps;
+    double n, eps;
+    // workspace
+    double* S;        // m x ld scaled Sigma (ld = m rounded up to even; the pad column is zero)
+    double* Rinv;     // m x ld upper triangular inverse factor (active order), rows
+    double* RinvT;    // m x ld its transpose, rows
+    double* vec;      // 12 vectors of length m (see kernel)
+    int* ivec;        // 4 int vectors of length m
+    // outputs
+    double* beta_path; double* beta0; double* aic; double* bic;
+    int* n_steps;     // device scalar
+    // multi-workgroup kernel only
+    double* rbuf;     // m: r = R^{-T} x of the current append, gathered from the row owners
+    double* wbuf;     // m: equiangular weights, gathered from the row owners
+    double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
+    unsigned* bar;    // grid barrier: [0] arrival counter, [1] abort word (both zero at launch)
+    long long bar_timeout;   // ticks of the 100 MHz wall clock a workgroup waits at a grid barrier before it aborts the launch
+};
+
+// lars_q.hip: the path kernel for narrow problems (m = p - intercept <= LARS_Q_MAX_M)
+constexpr int LARS_Q_MAX_M = 400;
+bool lars_q_eligible(int p, int intercept);
+int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s);
+
+}  // namespace dlsa

@@ -21,6 +21,7 @@
 //     set before it is unchanged) instead of Givens-downdating R (lsa.py:35-80); the factor of the remaining ordered
 //     set is unique.
 #include "common.h"
+#include "lars.h"
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -37,28 +38,6 @@ std::atomic<long long> g_lars_barrier_timeout_ticks{200000000ll};   // 2 s of th
 std::atomic<int> g_lars_grid_aborts{0};
 #endif
 
-struct LarsArgs {
-    const double* Sigma0;   // p x p
-    const double* b0;       // p
-    int64_t lds0;
-    int p, intercept, type, max_steps;
-    double n, eps;
-    // workspace
-    double* S;        // m x ld scaled Sigma (ld = m rounded up to even; the pad column is zero)
-    double* Rinv;     // m x ld upper triangular inverse factor (active order), rows
-    double* RinvT;    // m x ld its transpose, rows
-    double* vec;      // 12 vectors of length m (see kernel)
-    int* ivec;        // 4 int vectors of length m
-    // outputs
-    double* beta_path; double* beta0; double* aic; double* bic;
-    int* n_steps;     // device scalar
-    // multi-workgroup kernel only
-    double* rbuf;     // m: r = R^{-T} x of the current append, gathered from the row owners
-    double* wbuf;     // m: equiangular weights, gathered from the row owners
-    double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
-    unsigned* bar;    // grid barrier: [0] arrival counter, [1] abort word (both zero at launch)
-    long long bar_timeout;   // ticks of the 100 MHz wall clock a workgroup waits at a grid barrier before it aborts the launch
-};
 
 // The kernels are compiled TWICE (Makefile: lars.hip and lars_t512 from the same source): workgroups of 1024 threads for wide
 // paths, of 512 for p <= 768 -- every phase of a step ends in a workgroup barrier or a block reduction, and those cost by the
@@ -1031,6 +1010,16 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     // gives the launch up: 2 s
     a.bar_timeout = g_lars_barrier_timeout_ticks.load();
     int steps = 0, wgs_used = 1;
+    if (lars_q_eligible(p, intercept)) {
+        // narrow problems: one workgroup on the carried Cholesky rows (lars_q.hip); every entry of its matrices is written before
+        // it is read, so nothing is cleared
+        const int rc = lars_q_run(a, p, intercept, s);
+        if (rc) return rc;
+        DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        if (n_steps_host) *n_steps_host = steps;
+        return DLSA_OK;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
         DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));

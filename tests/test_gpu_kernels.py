@@ -442,11 +442,12 @@ def test_lars_lasso_drops_wide_matches_oracle(eng, orc, p, rho, seed, intercept)
     assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
 
 
-def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc):
+def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc, monkeypatch):
     """The grid kernel's hand-rolled barrier is bounded: a workgroup that waits longer than the timeout aborts the
     launch, every workgroup leaves, and the host reruns the path on the single-workgroup kernel.  With a timeout of one tick every
     wait is 'too long', so the rerun is what produces the result here -- same path as the oracle's; nothing hangs."""
     from dlsa_amd import _lib
+    monkeypatch.setenv("DLSA_LARS_Q", "0")         # (p = 300 would otherwise run on lars_q.hip's single workgroup)
     lib = _lib.load()
     S, b, n = _correlated_lsa_problem(300, 0.9, 3)
     ro = orc.lars_lsa(S, b, False, n, type="lasso")
@@ -469,6 +470,28 @@ def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypa
     """The multi-workgroup path kernel (cooperative launch, grid barriers) and the single-workgroup one walk the
     same path: reference goldens incl. drops, wide lasso paths with drops, the intercept."""
     monkeypatch.setenv("DLSA_LARS_WGS", str(wgs))
+    monkeypatch.setenv("DLSA_LARS_Q", "0")         # lars.hip's kernels (the default for these widths is lars_q.hip, tested below)
+    _lars_reference_cases(eng, orc)
+
+
+@pytest.mark.parametrize("threads,lds", [(256, 1), (512, 1), (512, 0), (1024, 0)])
+def test_lars_q_kernel_variants_match_golden_and_oracle(eng, orc, monkeypatch, threads, lds):
+    """lars_q.hip (carried Cholesky rows, the default up to m = 400) in its four builds -- Q and RT in LDS or in global memory,
+    256 / 512 / 1024 threads -- on the reference goldens incl. drops, wide lasso paths with drops, the intercept; and the width
+    where it hands over to lars.hip."""
+    monkeypatch.setenv("DLSA_LARS_Q_THREADS", str(threads))
+    monkeypatch.setenv("DLSA_LARS_Q_LDS", str(lds))
+    _lars_reference_cases(eng, orc)
+    S, b, n = _correlated_lsa_problem(400, 0.9, 17)
+    r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
+    monkeypatch.setenv("DLSA_LARS_Q", "0")
+    r0 = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
+    assert r["beta"].shape == r0["beta"].shape
+    assert rel_inf(r["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
+    assert rel_inf(r["BIC"].cpu().numpy(), r0["BIC"].cpu().numpy()) < 1e-7
+
+
+def _lars_reference_cases(eng, orc):
     for name in F3:
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
         typ = "lasso" if name.endswith("lasso") else "lar"
