@@ -3,6 +3,8 @@ Prints min / median wall time of lars_path (host call incl. the step-count read-
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from dlsa_amd import _lib
+if os.environ.get("DLSA_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["DLSA_LIB"])
 from dlsa_amd import engine
 
 for p in [int(v) for v in sys.argv[1:]] or [50, 100, 260]:

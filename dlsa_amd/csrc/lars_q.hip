@@ -87,6 +87,30 @@ struct QBlock {
     }
 };
 
+// The cross-wave half of a block reduction: v[q] is already the same in every lane of a wave (reduced there, or a ballot count);
+// OPS[q] = 0 sum, 1 min, 2 max.  One barrier, alternating buffers as QBlock::reduce2.
+template <int T, int N>
+__device__ __forceinline__ void cross_wave(double (&v)[N], const int (&ops)[N], double* red, int& phase) {
+    constexpr int WAVES = T / 64;
+    static_assert(N <= 4, "a buffer holds four values per wave");
+    double* r = red + (phase & 1) * 4 * WAVES;
+    ++phase;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) r[q * WAVES + (threadIdx.x >> 6)] = v[q];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double s = r[q * WAVES];
+        for (int k = 1; k < WAVES; ++k) {
+            const double u = r[q * WAVES + k];
+            s = ops[q] == 0 ? s + u : (ops[q] == 1 ? fmin(s, u) : fmax(s, u));
+        }
+        v[q] = s;
+    }
+}
+
 // 1 / sqrt(d) to about an ulp: v_rsq_f64 and two Newton steps (sqrt + division are ~45 dependent instructions, and every wave
 // of the workgroup evaluates the step's scalars itself)
 __device__ __forceinline__ double rsqrt_newton(double d) {
@@ -97,24 +121,43 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return fma(0.5 * y, e, y);
 }
 
-// A thread's place in the fused pass, fixed for the whole path: column pair jx of [Q (NQ pairs) | RT (NRmax pairs)], row group g
-// of G (G = 1 or even: the packed RT's row offsets then advance by a second-order recurrence, no multiplication per row).
-// i0 = the first row the thread reads (RT's column pair (c2, c2 + 1) exists from row c2 on).
+// A thread's place in the fused pass, fixed for the whole path: threads [0, NQ * GQ) take the NQ column pairs of Q in GQ row
+// groups, the next NR * GR threads the NR column pairs of RT in GR row groups (GR = 1 or even: the packed RT's row offsets then
+// advance by a second-order recurrence, no multiplication per row).  RT's rows are half as long on average, so GQ > GR fills the
+// workgroup better than one G for both.  i0 = the first row the thread reads (RT's column pair (c2, c2 + 1) exists from row c2
+// on), `stride` = the distance between the row groups' partial sums of one column pair in `part` (indexed by thread).
 struct QLayout {
-    int JT2, G, g, jx, c2, i0;
+    int G, g, c2, i0, stride;
     bool isq, live;
 };
-__device__ __forceinline__ QLayout q_layout(int T, int tid, int m) {
+__device__ __forceinline__ QLayout q_layout(int T, int tid, int m, bool lds) {
     QLayout L;
-    const int NQ = ((m + 1) & ~1) >> 1;
-    L.JT2 = NQ + ((m + 2) >> 1);
-    L.G = max(1, T / L.JT2);
-    if (L.G > 1) L.G &= ~1;
-    L.g = tid / L.JT2;
-    L.jx = tid - L.g * L.JT2;
+    const int NQ = ((m + 1) & ~1) >> 1, NR = (m + 2) >> 1;
+    int GQ = 1, GR = 1;
+    if (lds) {
+        // the split that minimises the longest walk: n / GQ rows for a Q thread, about n / (2 GR) for an RT thread
+        float best = 1e30f;
+        for (int gr = 1; gr <= 16; gr = gr == 1 ? 2 : gr + 2) {
+            const int gq = (T - NR * gr) / NQ;
+            if (gq < 1) break;
+            const float cost = fmaxf(1.0f / (float)gq, 0.55f / (float)gr);
+            if (cost < best) { best = cost; GQ = gq; GR = gr; }
+        }
+    } else {
+        // Q and RT in global memory: the pass is bound by what one CU streams from L2 (~75 GB/s in 16-byte loads); more loading
+        // threads only lengthen the slowest walk (p = 260, GQ = 2 / GR = 1: 2.35 ms; one G for both: 2.13 ms)
+        GQ = GR = max(1, T / (NQ + NR));
+    }
+    const int nq_threads = NQ * GQ;
+    L.isq = tid < nq_threads;
+    const int u = L.isq ? tid : tid - nq_threads;
+    const int width = L.isq ? NQ : NR;
+    L.G = L.isq ? GQ : GR;
+    L.stride = width;
+    L.g = u / width;
+    const int jx = u - L.g * width;
     L.live = L.g < L.G;
-    L.isq = L.jx < NQ;
-    L.c2 = L.isq ? 2 * L.jx : 2 * (L.jx - NQ);
+    L.c2 = 2 * jx;
     L.i0 = L.g;
     if (!L.isq && L.c2 > L.g) L.i0 = L.g + (L.c2 - L.g + L.G - 1) / L.G * L.G;
     return L;
@@ -131,7 +174,12 @@ __device__ __forceinline__ void fused_mv(const QLayout& L, const double* __restr
     const bool mine = L.live && (L.isq || L.c2 < ncolR);
     if (mine) {
         double2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
-        constexpr int NB = T >= 1024 ? 4 : 8;      // row loads in flight per thread (128 registers per thread at 1024 threads)
+        // row loads in flight per thread: L2 needs ~64 KB in flight to stream at a CU's rate, and beyond m = 255 a column pair
+        // has one thread (G = 1); 128 registers per thread bound the 1024-thread build
+#ifndef DLSA_LARS_Q_NB_GLOBAL
+#define DLSA_LARS_Q_NB_GLOBAL 8
+#endif
+        constexpr int NB = T >= 1024 ? 4 : (LDSQ ? 8 : DLSA_LARS_Q_NB_GLOBAL);
         const int G = L.G;
         int i = L.i0;
         const double* __restrict__ xp = x + i * xs;
@@ -166,20 +214,35 @@ __device__ __forceinline__ void fused_mv(const QLayout& L, const double* __restr
                 a3.x = fma(xv[k + 3], q[k + 3].x, a3.x); a3.y = fma(xv[k + 3], q[k + 3].y, a3.y);
             }
         }
-        while (i < n) {
-            const double2 q = *reinterpret_cast<const double2*>(rp);
-            const double x0 = *xp;
-            next();
-            a0.x = fma(x0, q.x, a0.x); a0.y = fma(x0, q.y, a0.y);
+        if (i < n) {      // the last, partial batch: the same independent loads under a row mask (singly they would each cost a round trip)
+            double2 q[NB];
+            double xv[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                q[k] = double2{0.0, 0.0};
+                xv[k] = 0.0;
+                if (i < n) {
+                    q[k] = *reinterpret_cast<const double2*>(rp);
+                    xv[k] = *xp;
+                    next();
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k += 4) {
+                a0.x = fma(xv[k], q[k].x, a0.x); a0.y = fma(xv[k], q[k].y, a0.y);
+                a1.x = fma(xv[k + 1], q[k + 1].x, a1.x); a1.y = fma(xv[k + 1], q[k + 1].y, a1.y);
+                a2.x = fma(xv[k + 2], q[k + 2].x, a2.x); a2.y = fma(xv[k + 2], q[k + 2].y, a2.y);
+                a3.x = fma(xv[k + 3], q[k + 3].x, a3.x); a3.y = fma(xv[k + 3], q[k + 3].y, a3.y);
+            }
         }
-        part[L.g * L.JT2 + L.jx] = double2{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
+        part[threadIdx.x] = double2{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
     }
     QTICK(4);
     lds_barrier();
     QTICK(5);
     if (mine && L.g == 0) {
-        double2 t = part[L.jx];
-        for (int q = 1; q < L.G; ++q) { const double2 u = part[q * L.JT2 + L.jx]; t.x += u.x; t.y += u.y; }
+        double2 t = part[threadIdx.x];
+        for (int q = 1; q < L.G; ++q) { const double2 u = part[threadIdx.x + q * L.stride]; t.x += u.x; t.y += u.y; }
         if (L.isq) eq(L.c2, t); else er(L.c2, t);
     }
     QTICK(6);
@@ -235,7 +298,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         RT = a.Rinv;
     }
     auto rt_off = [&](int l) { return LDSQ ? rt_off_packed(l) : l * ld; };
-    const QLayout L = q_layout(T, tid, m);
+    const QLayout L = q_layout(T, tid, m, LDSQ);
     double* __restrict__ S = a.S;
 
     QPROF_DECL;
@@ -422,7 +485,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         // lasso modification (lsa.py:164-173)
         const double A = rsqrt_newton(tsq);
         double gamhat = Cmax * (tsq * A);              // Cmax / A
-        double mins[2] = {INFINITY, INFINITY}, dummy[1] = {0.0};
+        double mins[2] = {INFINITY, INFINITY};
         const double uj = A * v[jv];
         const double wj = A * gi1[min(r_pos, ld - 1)];
         if (r_state == 0) {
@@ -435,14 +498,20 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
             if (z > eps) mins[1] = fmin(mins[1], z);
         }
         QTICK(9);
-        B::reduce2(mins, WaveOpMin(), dummy, WaveOpMax(), red, red_phase);
+        {
+            mins[0] = wave_allreduce_min(mins[0]);
+            if (a.type == 1) mins[1] = wave_allreduce_min(mins[1]);      // (uniform: the lasso's crossing distance)
+            const int ops[2] = {1, 1};
+            cross_wave<T>(mins, ops, red, red_phase);
+        }
         QTICK(10);
         gamhat = fmin(mins[0], gamhat);
         had_drops = uni(a.type == 1 && mins[1] < gamhat);
         if (had_drops) gamhat = mins[1];
         // ---- move (lsa.py:175-177), drops (lsa.py:179-186), the path point: un-scaled beta (lsa.py:194-201), RSS, dof, AIC/BIC
         // (:190-210) and Cmax of the next step (lsa.py:128-129): every thread on its own variable
-        double rec[3] = {0.0, 0.0, 0.0}, cm[1] = {0.0};      // RSS, dof, a12 . beta
+        double rec[4] = {0.0, 0.0, 0.0, 0.0};      // RSS, dof, a12 . beta, max |Cvec| over the variables that are not active
+        bool nonzero = false;
         if (own) {
             if (r_state == 1) {
                 bool dropped = false;
@@ -456,15 +525,22 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
             const double ub = r_absb * r_beta;
             a.beta_path[(int64_t)k * m + tid] = ub;
             rec[0] = (r_bsgn - r_beta) * r_cvec;
-            if (fabs(ub) > eps) rec[1] = 1.0;
+            nonzero = fabs(ub) > eps;
             if (a.intercept) rec[2] = r_a12 * ub;
-            if (r_state != 1) cm[0] = fabs(r_cvec);
+            if (r_state != 1) rec[3] = fabs(r_cvec);
         }
         QTICK(11);
-        B::reduce2(rec, WaveOpSum(), cm, WaveOpMax(), red, red_phase);
+        {
+            rec[0] = wave_allreduce_sum(rec[0]);
+            rec[1] = (double)__popcll(__ballot(nonzero));                  // dof: a count, no butterfly
+            if (a.intercept) rec[2] = wave_allreduce_sum(rec[2]);          // (uniform)
+            rec[3] = wave_allreduce_max(rec[3]);
+            const int ops[4] = {0, 0, 0, 2};
+            cross_wave<T>(rec, ops, red, red_phase);
+        }
         QTICK(12);
-        Cmax = cm[0];
-        if (tid == 0) {
+        Cmax = rec[3];
+        if (tid == T - 64) {      // (a wave that owns no variable: off the path of the waves that do)
             a.aic[k] = rec[0] + 2.0 * rec[1];
             a.bic[k] = rec[0] + logn * rec[1];
             a.beta0[k] = a.intercept ? beta0c - rec[2] / a11 : 0.0;
