@@ -491,6 +491,20 @@ def test_lars_q_kernel_variants_match_golden_and_oracle(eng, orc, monkeypatch, t
     assert rel_inf(r["BIC"].cpu().numpy(), r0["BIC"].cpu().numpy()) < 1e-7
 
 
+@pytest.mark.parametrize("p,intercept", [(1, False), (2, False), (2, True), (3, True)])
+def test_lars_tiny_problems_match_oracle(eng, orc, p, intercept):
+    """One and two penalised variables (m = p - intercept = 1, 2): the shortest paths the kernels' layouts must survive."""
+    S, b, n = _correlated_lsa_problem(p, 0.5, 70 + p)
+    for typ in ("lar", "lasso"):
+        ro = orc.lars_lsa(S, b, intercept, n, type=typ)
+        r = eng.lars_path(dev(S), dev(b), intercept, float(n), type=typ)
+        assert r["beta"].shape == ro["beta"].shape
+        assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-8
+        assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-8
+        if intercept:
+            assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-8
+
+
 def _lars_reference_cases(eng, orc):
     for name in F3:
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
