@@ -58,7 +58,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
     typedef double acc_t __attribute__((ext_vector_type(4)));
     __shared__ double Hs[SM_MAXP * SM_LD];      // the Hessian (full, symmetric)
     __shared__ double Ls[SM_MAXP * SM_LD];      // its Cholesky factor (lower)
-    __shared__ double gs[SM_MAXP], beta[SM_MAXP], prev[SM_MAXP], stepv[SM_MAXP], bs[SM_MAXP];
+    __shared__ double gs[SM_MAXP], beta[SM_MAXP], prev[SM_MAXP], stepv[SM_MAXP];
     __shared__ double sc[4];                    // [0] loglik  [1] loop state  [2] status
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x;
@@ -197,40 +197,54 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 };
-                for (int c = 0; c < pe; ++c) if (j < pe && c <= j) Ls[j * SM_LD + c] = Hs[j * SM_LD + c];
-                wave_sync();
+                // Cholesky by columns, left-looking: lane j forms s_j = H[j][c] - sum_{k<c} L[j][k] L[c][k] with independent,
+                // pipelined LDS reads (its own row, pitch 65: conflict-free; row c: a broadcast) and four accumulators; the pivot
+                // s_c reaches every lane through v_readlane.  (Until round 4 this was the right-looking form: per column every
+                // lane ran a serial read-modify-write loop over its row in LDS -- p^2 / 2 dependent round trips, a fifth of the
+                // time an iteration of a 5 000 x 50 partition took.)
+                const int jj = min(j, pe - 1);
+                const double* __restrict__ rj = Ls + jj * SM_LD;
+                auto bcast = [&](double v, int src) {      // lane src's value to every lane (src uniform)
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+                };
                 bool ok = true;
+                double dg = 1.0;                            // L[j][j]
                 for (int c = 0; c < pe; ++c) {
-                    const double d = Ls[c * SM_LD + c];
-                    if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
-                    const double s = sqrt(d);
-                    if (j >= c && j < pe) Ls[j * SM_LD + c] = (j == c) ? s : Ls[j * SM_LD + c] / s;
-                    wave_sync();                            // column c is scaled: the trailing update reads other lanes' entries of it
-                    if (j > c && j < pe) {
-                        const double ljc = Ls[j * SM_LD + c];
-                        for (int m = c + 1; m <= j; ++m) Ls[j * SM_LD + m] -= ljc * Ls[m * SM_LD + c];
+                    const double* __restrict__ rc = Ls + c * SM_LD;
+                    double s0 = Hs[jj * SM_LD + c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int kk = 0;
+                    for (; kk + 3 < c; kk += 4) {
+                        s0 = fma(-rj[kk], rc[kk], s0);
+                        s1 = fma(-rj[kk + 1], rc[kk + 1], s1);
+                        s2 = fma(-rj[kk + 2], rc[kk + 2], s2);
+                        s3 = fma(-rj[kk + 3], rc[kk + 3], s3);
                     }
-                    wave_sync();
+                    for (; kk < c; ++kk) s0 = fma(-rj[kk], rc[kk], s0);
+                    const double sj = (s0 + s1) + (s2 + s3);
+                    const double d = bcast(sj, c);
+                    if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+                    const double sd = sqrt(d);
+                    if (j == c) dg = sd;
+                    if (j >= c && j < pe) Ls[j * SM_LD + c] = (j == c) ? sd : sj / sd;
+                    wave_sync();                            // column c is in LDS: the next columns read it (this wave's LDS operations run in order)
                 }
                 if (!ok) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NOT_SPD; }
                 else {
-                    if (j < pe) bs[j] = gs[j];
-                    wave_sync();
+                    // the two triangular solves with the right-hand side in registers (lane j holds entry j), the entry being
+                    // eliminated broadcast by v_readlane: no LDS write, no synchronisation inside the loops
+                    const double rdg = 1.0 / dg;
+                    double bv = j < pe ? gs[j] : 0.0;
                     for (int c = 0; c < pe; ++c) {          // L z = g
-                        const double z = bs[c] / Ls[c * SM_LD + c];
-                        wave_sync();                        // every lane has read bs[c] before lane c overwrites it
-                        if (j == c) bs[c] = z;
-                        if (j > c && j < pe) bs[j] -= Ls[j * SM_LD + c] * z;
-                        wave_sync();
+                        const double z = bcast(bv, c) * bcast(rdg, c);
+                        const double ljc = rj[c];
+                        if (j == c) bv = z; else if (j > c) bv = fma(-ljc, z, bv);
                     }
                     for (int c = pe - 1; c >= 0; --c) {     // L' delta = z
-                        const double z = bs[c] / Ls[c * SM_LD + c];
-                        wave_sync();
-                        if (j == c) bs[c] = z;
-                        if (j < c) bs[j] -= Ls[c * SM_LD + j] * z;
-                        wave_sync();
+                        const double z = bcast(bv, c) * bcast(rdg, c);
+                        const double lcj = Ls[c * SM_LD + jj];
+                        if (j == c) bv = z; else if (j < c) bv = fma(-lcj, z, bv);
                     }
-                    const double dj = j < pe ? bs[j] : 0.0, bj = j < pe ? beta[j] : 0.0;
+                    const double dj = j < pe ? bv : 0.0, bj = j < pe ? beta[j] : 0.0;
                     const double dmax = wave_allreduce_max(fabs(dj)), bmax = wave_allreduce_max(fabs(bj));
                     if (!isfinite(dmax)) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NAN; }
                     else if (dmax <= a.tol * fmax(1.0, bmax)) state = 1;
