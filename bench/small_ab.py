@@ -16,7 +16,7 @@ for K, nk, p in shapes:
     ts = []
     for _ in range(7):
         torch.cuda.synchronize(); t = time.perf_counter()
-        mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs, small=True, batched=False)
+        mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs, batched=False)      # DLSA_IRLS_SMALL=2 forces the one-launch kernel, =0 the chains
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     print("K=%4d n_k=%6d p=%3d: %.3f ms (min %.3f), path %d, iters %s, ok %s" % (K, nk, p, sorted(ts)[3] * 1e3, min(ts) * 1e3, engine.irls_last_fit_path(),
                                                                                 mb.n_iter[:3], all(s == 0 for s in mb.status)), flush=True)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dlsa_lars_lsa_f64": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_int,
                                   c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp, c_sz, c_vp]),
     "dlsa_lars_grid_barrier_timeout": (c_int, [c_dbl]),
+    "dlsa_irls_small_cluster_timeout": (c_int, [c_dbl]),
     "dlsa_design_f64": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                 c_vp, c_i64, c_vp, c_vp]),
     "dlsa_design_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,

@@ -12,11 +12,17 @@
 //                   first pass);  the waves' partials meet in LDS in a fixed order (deterministic);
 //                   wave 0: Cholesky of H in LDS (lane = row), two triangular solves, step, stopping rule.
 // Stopping rule, step halving and the returned (coef, H at coef) are the oracle's / irls.hip's: |delta|_inf <= tol max(1, |beta|_inf).
+// CLUSTERS (round 4): with fewer partitions than CUs, C workgroups (on C CUs) share a partition: they deal its row batches, write
+// their partial H, g, loglik to global scratch and meet at a per-partition barrier (a counter with agent-scope release / acquire, as
+// the LARS grid kernel's; bounded: a timeout aborts the launch and the host reruns it with C = 1); workgroup 0 of the cluster
+// sums the partials in a fixed order, runs the Cholesky / step / stopping rule and publishes beta and the loop state before a
+// second barrier.  Config 1 (20 x 5 000 x 50) uses 160 CUs instead of 20.
 // Width: p + intercept <= 64 columns (4 tiles per side, 10 accumulator tiles per wave); the implicit intercept is the LAST
 // column inside the kernel and the FIRST one in the outputs (models.py:136-142).
 #include "common.h"
 #include "options.h"
 #include <algorithm>
+#include <atomic>
 #include <math.h>
 #include <vector>
 
@@ -42,7 +48,48 @@ struct SmallArgs {
     int* n_iter;              // [K] device
     int* status;              // [K] device
     double* loglik;           // [K] device
+    // clusters (C > 1)
+    int C;                    // workgroups per partition
+    double* scratch;          // [K][C][SM_SLOT]: partial H (rows < pe, pitch SM_LD), g, loglik
+    double* bcast;            // [K][SM_BSLOT]: beta, loop state, status, loglik from the cluster's workgroup 0
+    unsigned* bar;            // [K][16]: [0] arrivals; bar_abort: one word for the launch
+    unsigned* bar_abort;
+    long long bar_timeout;    // ticks of the 100 MHz wall clock
 };
+constexpr int SM_SLOT = SM_MAXP * SM_LD + SM_MAXP + 8;
+constexpr int SM_BSLOT = SM_MAXP + 8;
+
+// Barrier of the C workgroups of one partition (lars.hip's grid_barrier on a per-partition counter): relaxed agent-scope polling
+// with ONE acquire after the match; a wait longer than the timeout sets the launch's abort word and every workgroup leaves.
+__device__ __forceinline__ bool cluster_barrier(unsigned* bar, unsigned* abort_word, unsigned nwg, unsigned& phase, long long timeout) {
+    __shared__ int cb_ok;
+    __syncthreads();                 // this workgroup's global stores have been issued by every wave
+    if (threadIdx.x == 0) {
+        ++phase;
+        const unsigned target = phase * nwg;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins++ & 255u) == 0u) {
+                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                if (wall_clock64() - t0 > timeout) {
+                    __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cb_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return cb_ok != 0;
+}
 
 __device__ __forceinline__ double row16_sum(double v) {      // sum over the 16 lanes of a row group
     v += dpp_xor_f64<1>(v);
@@ -61,7 +108,11 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
     __shared__ double gs[SM_MAXP], beta[SM_MAXP], prev[SM_MAXP], stepv[SM_MAXP];
     __shared__ double sc[4];                    // [0] loglik  [1] loop state  [2] status
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.x;
+    const int C = a.C;
+    const int k = blockIdx.x / C, cpart = blockIdx.x - k * C;
+    const bool leader = cpart == 0;                 // workgroup 0 of the partition's cluster: sums, factorises, decides, writes the results
+    unsigned bphase = 0;
+    unsigned* const cbar = a.bar ? a.bar + 16 * k : nullptr;
     const int pe = a.pe, p = a.p;
     const int64_t nk = a.rows[k], r0 = a.first[k], pitch = a.ldx * a.step;
     const double* __restrict__ Xk = a.X + r0 * a.ldx;
@@ -69,6 +120,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
     const int kg = lane >> 4, cl = lane & 15;
 
     if (nk == 0) {      // empty partition: the reference's zero block (models.py:84-91)
+        if (!leader) return;
         for (int e = tid; e < pe * pe; e += SM_THREADS) a.sig[(int64_t)k * pe * pe + e] = 0.0;
         for (int e = tid; e < pe; e += SM_THREADS) { a.coef[(int64_t)k * pe + e] = 0.0; a.smc[(int64_t)k * pe + e] = 0.0; }
         if (tid == 0) { a.n_iter[k] = 0; a.status[k] = DLSA_PART_EMPTY; a.loglik[k] = 0.0; }
@@ -92,7 +144,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
         for (int t = 0; t < NTRI; ++t) acc[t] = acc_t{0, 0, 0, 0};
         double llw = 0.0;
         const int64_t nks = (nk + 3) / 4;
-        for (int64_t ks0 = (int64_t)wave * SM_U; ks0 < nks; ks0 += (int64_t)SM_WAVES * SM_U) {
+        for (int64_t ks0 = (int64_t)(cpart * SM_WAVES + wave) * SM_U; ks0 < nks; ks0 += (int64_t)C * SM_WAVES * SM_U) {
             // all loads of SM_U k-steps first (a k-step = 4 rows x 16 NT columns in the MFMA fragment layout), then the arithmetic
             double xs[SM_U][NT], ys[SM_U];
             bool vs[SM_U];
@@ -172,15 +224,36 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
             }
             __syncthreads();
         }
-        for (int e = tid; e < pe * pe; e += SM_THREADS) {          // mirror: the lower triangle is the transpose of the upper
-            const int i = e / pe, j = e - i * pe;
-            if (i > j) Hs[i * SM_LD + j] = Hs[j * SM_LD + i];
+        if (C > 1) {
+            // the cluster meets: partials to global scratch, barrier, workgroup 0 adds the others' in the order 1 .. C - 1
+            double* __restrict__ slot = a.scratch + ((int64_t)k * C + cpart) * SM_SLOT;
+            if (!leader) {
+                for (int e = tid; e < pe * SM_LD; e += SM_THREADS) slot[e] = Hs[e];
+                if (tid < pe) slot[SM_MAXP * SM_LD + tid] = gs[tid];
+                if (tid == 0) slot[SM_MAXP * SM_LD + SM_MAXP] = sc[0];
+            }
+            if (!cluster_barrier(cbar, a.bar_abort, (unsigned)C, bphase, a.bar_timeout)) return;
+            if (leader) {
+                for (int c = 1; c < C; ++c) {
+                    const double* __restrict__ src = a.scratch + ((int64_t)k * C + c) * SM_SLOT;
+                    for (int e = tid; e < pe * SM_LD; e += SM_THREADS) Hs[e] += src[e];
+                    if (tid < pe) gs[tid] += src[SM_MAXP * SM_LD + tid];
+                    if (tid == 0) sc[0] += src[SM_MAXP * SM_LD + SM_MAXP];
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        ll = sc[0];
+        if (leader) {
+            for (int e = tid; e < pe * pe; e += SM_THREADS) {          // mirror: the lower triangle is the transpose of the upper
+                const int i = e / pe, j = e - i * pe;
+                if (i > j) Hs[i * SM_LD + j] = Hs[j * SM_LD + i];
+            }
+            __syncthreads();
+            ll = sc[0];
+        }
         if (last_pass) break;                               // max_iter reached: H, loglik are those of the last iterate
         // ---- wave 0: safeguard, Cholesky, solve, step, stopping rule
-        if (wave == 0) {
+        if (leader && wave == 0) {
             const int j = lane;
             int state = 0;                                  // 0 continue, 1 converged, 2 failed (status in sc[2]), 3 step halved
             if (!isfinite(ll)) { state = 2; if (lane == 0) sc[2] = DLSA_PART_NAN; }
@@ -254,6 +327,21 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
             if (lane == 0) sc[1] = (double)state;
         }
         __syncthreads();
+        if (C > 1) {
+            // workgroup 0 publishes the new beta and the loop state; the others pick them up after the second barrier
+            double* __restrict__ bs = a.bcast + (int64_t)k * SM_BSLOT;
+            if (leader) {
+                if (tid < pe) bs[tid] = beta[tid];
+                if (tid == 0) { bs[SM_MAXP] = sc[1]; bs[SM_MAXP + 1] = sc[2]; bs[SM_MAXP + 2] = ll; }
+            }
+            if (!cluster_barrier(cbar, a.bar_abort, (unsigned)C, bphase, a.bar_timeout)) return;
+            if (!leader) {
+                if (tid < pe) beta[tid] = bs[tid];
+                if (tid == 0) { sc[1] = bs[SM_MAXP]; sc[2] = bs[SM_MAXP + 1]; }
+                ll = bs[SM_MAXP + 2];
+                __syncthreads();
+            }
+        }
         const int state = (int)sc[1];
         if (state == 3) {                                   // re-evaluate at the halved step (not a new iteration)
             ++halvings;
@@ -266,6 +354,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
         ll_prev = ll; have_prev = true; halvings = 0;
         if (iters >= a.max_iter) last_pass = true;
     }
+    if (!leader) return;
     // outputs: intercept first (models.py:136-142)
     auto omap = [&](int o) { return a.icpt ? (o == 0 ? pe - 1 : o - 1) : o; };
     for (int e = tid; e < pe * pe; e += SM_THREADS) {
@@ -282,6 +371,18 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
     if (tid == 0) { a.n_iter[k] = iters; a.status[k] = status; a.loglik[k] = ll; }
 }
 
+std::atomic<int> g_small_cluster_aborts{0};
+std::atomic<long long> g_small_cluster_timeout_ticks{200000000ll};      // 2 s of the 100 MHz wall clock
+
+// Workgroups per partition: as many as leave every CU at most one, while a workgroup keeps >= 512 rows (below that the two cluster
+// barriers and the partial sums cost what the shorter pass saves).  DLSA_IRLS_SMALL_CLUSTER = C forces it (1 .. 16).
+static int small_cluster_count(int K, int64_t nmax) {
+    int C = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(8, kNumCU / std::max(K, 1)), nmax / 512));
+    if (const char* e = knob("DLSA_IRLS_SMALL_CLUSTER")) C = std::max(1, std::min(16, atoi(e)));
+    if ((int64_t)K * C > 2 * kNumCU) C = 1;              // (co-residency: two workgroups of this kernel fit a CU)
+    return C;
+}
+
 bool irls_small_enabled() {
     const char* e = knob("DLSA_IRLS_SMALL");       // 0: always the host-driven path (valid results, A/B runs)
     return e ? atoi(e) != 0 : true;
@@ -296,15 +397,18 @@ bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     int64_t nmax = 0;
     for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
     if (nmax > 65536) return false;
-    const double rounds = (double)((K + kNumCU - 1) / kNumCU);
+    if (const char* f = knob("DLSA_IRLS_SMALL")) if (atoi(f) == 2) return true;      // 2: this kernel whatever the cost model says (A/B runs)
+    const int C = small_cluster_count(K, nmax);
+    const double rounds = (double)(((int64_t)K * C + kNumCU - 1) / kNumCU);
     // the host-driven path fits such partitions on up to four concurrent chains (irls.hip, irls_fit_core): 0.55 ms per partition on one
-    // chain, 0.23 on four (K = 20, p = 50, 10000 .. 60000 rows: 4.5 ms whatever the row count; this kernel 2.6 / 4.5 / 6.4 / 9.5 ms
-    // at 10000 / 20000 / 30000 / 45000 rows -- bench/ab_small_vs_chains.sh)
+    // chain, 0.23 on four (K = 20, p = 50, 10000 .. 60000 rows: 4.5 ms whatever the row count).  This kernel (round 4: clusters,
+    // left-looking Cholesky; bench/small_ab.py, p = 50, ms): 0.8 + 1.9e-4 n_k / C -- K = 20: 1.01 / 1.28 / 2.05 at 5000 / 20000 /
+    // 50000 rows (C = 8), K = 100: 1.36 / 2.73 / 6.66 at 5000 / 20000 / 60000 (C = 2), K = 200 x 5000: 1.72 (C = 1)
     const char* e = knob("DLSA_IRLS_CHAINS");
     const int cap = e ? std::min(8, std::max(1, atoi(e))) : 4;
     const int S = std::max(1, std::min(cap, (K - 1) / 2));
     static const double per_partition_ms[5] = {0.55, 0.55, 0.37, 0.29, 0.23};
-    const double t_small = (1.0 + 1.9e-4 * (double)nmax * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
+    const double t_small = (0.8 + 1.9e-4 * ((double)nmax / C) * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
     return t_small < t_host;
 }
 
@@ -331,13 +435,39 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
     a.pe = p + a.icpt; a.max_iter = max_iter; a.tol = tol; a.coef = coef; a.sig = Sig_inv; a.smc = Sig_invMcoef;
     a.n_iter = d_iter; a.status = d_status; a.loglik = d_ll;
     const int nt = (a.pe + 15) / 16;
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(irls_small_kernel<1>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(irls_small_kernel<2>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(irls_small_kernel<3>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
-        default: hipLaunchKernelGGL(irls_small_kernel<4>, dim3(K), dim3(SM_THREADS), 0, s, a); break;
+    int64_t nmax = 0;
+    for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
+    int C = small_cluster_count(K, nmax);
+    char* pool = nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        a.C = C; a.scratch = nullptr; a.bcast = nullptr; a.bar = nullptr; a.bar_abort = nullptr; a.bar_timeout = g_small_cluster_timeout_ticks.load();
+        if (C > 1) {
+            const size_t b_scr = align_up((size_t)K * C * SM_SLOT * sizeof(double), 256), b_bc = align_up((size_t)K * SM_BSLOT * sizeof(double), 256),
+                         b_bar = align_up(((size_t)K * 16 + 16) * sizeof(unsigned), 256);
+            DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, b_scr + b_bc + b_bar, s));
+            a.scratch = (double*)pool; a.bcast = (double*)(pool + b_scr); a.bar = (unsigned*)(pool + b_scr + b_bc); a.bar_abort = a.bar + (size_t)K * 16;
+            DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, b_bar, s));
+        }
+        const dim3 grid((unsigned)(K * C));
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(irls_small_kernel<1>, grid, dim3(SM_THREADS), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(irls_small_kernel<2>, grid, dim3(SM_THREADS), 0, s, a); break;
+            case 3: hipLaunchKernelGGL(irls_small_kernel<3>, grid, dim3(SM_THREADS), 0, s, a); break;
+            default: hipLaunchKernelGGL(irls_small_kernel<4>, grid, dim3(SM_THREADS), 0, s, a); break;
+        }
+        DLSA_HIP_CHECK(hipGetLastError());
+        if (C == 1) break;
+        // a cluster barrier that timed out (the workgroups of a partition were not all resident) set the abort word: nothing
+        // was written; run again with one workgroup per partition, which needs no co-residency
+        unsigned aborted = 0;
+        DLSA_HIP_CHECK(hipMemcpyAsync(&aborted, a.bar_abort, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        DLSA_HIP_CHECK(hipFreeAsync(pool, s));
+        pool = nullptr;
+        if (!aborted) break;
+        g_small_cluster_aborts.fetch_add(1);
+        C = 1;
     }
-    DLSA_HIP_CHECK(hipGetLastError());
     std::vector<int> hi((size_t)K), hs((size_t)K);
     std::vector<double> hl((size_t)K);
     DLSA_HIP_CHECK(hipMemcpyAsync(hi.data(), d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -360,3 +490,15 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
 }
 
 }  // namespace dlsa
+
+extern "C" {
+
+// Test / diagnostics hook for the bounded cluster barrier of irls_small_kernel (no reference counterpart: the reference fits its
+// partitions in Spark tasks, dlsa/models.py:110-131): sets the barrier timeout in seconds (<= 0 restores the 2 s default) and
+// returns how many clustered launches of this process have been given up and rerun with one workgroup per partition.
+int dlsa_irls_small_cluster_timeout(double seconds) {
+    dlsa::g_small_cluster_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 200000000ll);
+    return dlsa::g_small_cluster_aborts.load();
+}
+
+}  // extern "C"

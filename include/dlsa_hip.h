@@ -274,6 +274,12 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
  * launches of this process have been given up and rerun on the single-workgroup kernel so far. */
 int dlsa_lars_grid_barrier_timeout(double seconds);
 
+/* The same for the one-launch kernel of many small partitions (dlsa_irls_fit*_f64 with K >= 2 partitions of <= 64 columns and
+ * <= 65 536 rows; models.py:110-131 per partition): with fewer partitions than CUs several workgroups share a partition and meet
+ * at a bounded per-partition barrier; a launch whose barrier times out is rerun with one workgroup per partition.  Sets the
+ * timeout in seconds (<= 0 restores the 2 s default), returns the number of such reruns of this process so far. */
+int dlsa_irls_small_cluster_timeout(double seconds);
+
 /* ---- design matrix (N2) ----
  * Replaces pd.get_dummies + drop(baselines) + standardise + reindex (dlsa/models.py:56-104) and the
  * leading ones column (models.py:121-122) for one chunk whose categorical columns arrive as integer

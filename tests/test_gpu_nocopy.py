@@ -134,6 +134,57 @@ def test_many_small_partitions_one_launch_matches_oracle(eng, orc, monkeypatch, 
     assert np.allclose(ref.loglik, mb.loglik, rtol=1e-10)
 
 
+@pytest.mark.parametrize("C", [1, 3, 8, 16])
+def test_small_partition_clusters_give_the_single_workgroup_result(eng, orc, monkeypatch, C):
+    """With fewer partitions than CUs, C workgroups share a partition (irls_small.hip: partial sums through global scratch, a
+    bounded per-partition barrier, workgroup 0 decides).  Any C gives the MLE / Hessian of the oracle; the strided, implicit-
+    intercept call and ragged partitions (one with fewer row batches than workgroups, an empty one) included."""
+    import dlsa_amd
+    monkeypatch.setenv("DLSA_IRLS_SMALL_CLUSTER", str(C))
+    monkeypatch.setenv("DLSA_IRLS_SMALL", "2")
+    K, nk, p = 7, 4003, 37
+    X, y = orc.synth_logistic(83, 0, K * nk, p)
+    mb = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K, fit_intercept=True)
+    assert eng.irls_last_fit_path() == eng.IRLS_PATH_SMALL and mb.status == [0] * K
+    parts = orc.partition_rows(K * nk, K)
+    for k in (0, 3, 6):
+        c, smc, sig = orc.logistic_model_block(X[parts[k]], y[parts[k]], True)
+        assert rel_inf(mb.coef[k].cpu().numpy(), c) < TOL_MLE
+        assert rel_inf(mb.Sig_inv[k].cpu().numpy(), sig) < TOL_MLE
+        assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), smc) < TOL_MLE
+    offs = [0, 9000, 9040, 9040, 15000, 21000]                     # 9000 rows, 40 rows (separable or not: status only), empty, 5960, 6000
+    r = eng.irls_fit(dev(X[:21000]), dev(y[:21000]), offs)
+    assert r["status"][0] == 0 and r["status"][2] == 4 and r["status"][3] == 0 and r["status"][4] == 0
+    c0, _, s0 = orc.logistic_model_block(X[:9000], y[:9000])
+    assert rel_inf(r["coef"][0].cpu().numpy(), c0) < TOL_MLE and rel_inf(r["Sig_inv"][0].cpu().numpy(), s0) < TOL_MLE
+    c4, _, s4 = orc.logistic_model_block(X[15000:21000], y[15000:21000])
+    assert rel_inf(r["coef"][4].cpu().numpy(), c4) < TOL_MLE and rel_inf(r["Sig_inv"][4].cpu().numpy(), s4) < TOL_MLE
+
+
+def test_small_partition_cluster_barrier_timeout_falls_back(eng, orc, monkeypatch):
+    """The cluster barrier is bounded: with a timeout of one tick every wait is too long, the launch is given up (nothing written) and
+    rerun with one workgroup per partition -- same results, nothing hangs."""
+    import dlsa_amd
+    from dlsa_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setenv("DLSA_IRLS_SMALL", "2")
+    K, nk, p = 5, 6000, 20
+    X, y = orc.synth_logistic(85, 0, K * nk, p)
+    before = lib.dlsa_irls_small_cluster_timeout(1e-9)
+    try:
+        mb = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K)
+        after = lib.dlsa_irls_small_cluster_timeout(0.0)
+    finally:
+        lib.dlsa_irls_small_cluster_timeout(0.0)
+    assert after > before and mb.status == [0] * K
+    parts = orc.partition_rows(K * nk, K)
+    c, smc, sig = orc.logistic_model_block(X[parts[2]], y[parts[2]])
+    assert rel_inf(mb.coef[2].cpu().numpy(), c) < TOL_MLE and rel_inf(mb.Sig_inv[2].cpu().numpy(), sig) < TOL_MLE
+    mb2 = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K)          # default timeout: the clusters complete
+    assert lib.dlsa_irls_small_cluster_timeout(0.0) == after
+    assert float((mb2.coef - mb.coef).abs().max()) < 1e-12 * float(mb.coef.abs().max())
+
+
 def test_small_partition_kernel_soft_failures(eng, orc):
     """Empty, collinear, NaN and separable partitions in one launch: per-partition statuses as the host-driven path reports them."""
     X, y = orc.synth_logistic(71, 0, 4000, 6)
