@@ -23,6 +23,7 @@
 #include "options.h"
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <math.h>
 #include <vector>
 
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
 }
 
 std::atomic<int> g_small_cluster_aborts{0};
+std::mutex g_small_cluster_mu;                                         // serialises this process's clustered launches (launch .. completion)
 std::atomic<long long> g_small_cluster_timeout_ticks{200000000ll};      // 2 s of the 100 MHz wall clock
 
 // Workgroups per partition: as many as leave every CU at most one, while a workgroup keeps >= 512 rows (below that the two cluster
@@ -379,7 +381,7 @@ std::atomic<long long> g_small_cluster_timeout_ticks{200000000ll};      // 2 s o
 static int small_cluster_count(int K, int64_t nmax) {
     int C = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(8, kNumCU / std::max(K, 1)), nmax / 512));
     if (const char* e = knob("DLSA_IRLS_SMALL_CLUSTER")) C = std::max(1, std::min(16, atoi(e)));
-    if ((int64_t)K * C > 2 * kNumCU) C = 1;              // (co-residency: two workgroups of this kernel fit a CU)
+    if ((int64_t)K * C > kNumCU) C = 1;                  // (co-residency: a CU takes one workgroup of this kernel -- 256 registers x 512 threads)
     return C;
 }
 
@@ -448,6 +450,10 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
             a.scratch = (double*)pool; a.bcast = (double*)(pool + b_scr); a.bar = (unsigned*)(pool + b_scr + b_bc); a.bar_abort = a.bar + (size_t)K * 16;
             DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, b_bar, s));
         }
+        // clustered launches of this process run one at a time: two of them could each hold part of the CUs the other's queued
+        // workgroups need (a CU takes one workgroup of this kernel).  Other processes on the GPU are covered by the timeout alone.
+        std::unique_lock<std::mutex> cluster_lock(g_small_cluster_mu, std::defer_lock);
+        if (C > 1) cluster_lock.lock();
         const dim3 grid((unsigned)(K * C));
         switch (nt) {
             case 1: hipLaunchKernelGGL(irls_small_kernel<1>, grid, dim3(SM_THREADS), 0, s, a); break;
