@@ -385,6 +385,9 @@ struct IrlsData {
     // says whether that launch really is the fused kernel for this many leading rows (else logit + gram are called)
     std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s)> pass;
     std::function<bool(int64_t nrows)> fusable;
+    // the fused launch needs no weight vector written (w == nullptr is allowed in `pass` and `logit`): at a fusable size every
+    // Hessian then comes from `pass`, and the 8 bytes per row of every pass stay unwritten
+    bool lean_w = false;
 };
 
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
@@ -416,7 +419,7 @@ static bool qn_enabled() {
 // only if those steps stop contracting.  The fixed point is the same MLE; only the path changes.
 static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_iter,
                       double freeze_at, double* H, const IrlsBuffers& b, hipStream_t s, int* status, int* iters,
-                      int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0) {
+                      int* gram_passes, double* loglik, bool* fresh, double inherit_scale = 0.0, bool lean = false) {
     double ll_prev = -INFINITY, ll = 0.0, dprev = INFINITY, dprev2 = INFINITY;
     const char* env_pred = knob("DLSA_IRLS_PREDICT");
     // prediction leaves Sig_inv / loglik evaluated up to 10 tol away from the returned coef (see below): only when that
@@ -436,6 +439,8 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     const char* env_fl = knob("DLSA_IRLS_FUSE_LAST");
     const bool can_fuse = d.pass && d.fusable && d.fusable(n);
     const bool fuse_last = can_fuse && (env_fl ? atoi(env_fl) != 0 : true);
+    // lean: no weights are written -- every Hessian of this run comes from the fused pass, the closing one too (irls_fit_core)
+    double* const wout = (lean && d.lean_w && can_fuse) ? nullptr : b.w;
     bool peek_next = false;
     for (int it = 1; it <= max_iter; ++it) {
         ++*iters;
@@ -446,10 +451,10 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         peek_next = false;
         int rc;
         if ((fresh_now || peek) && can_fuse) {
-            rc = d.pass(b.beta, n, b.w, b.g, b.stats + 3, H, b, s);      // w, g, loglik and H in one read of the rows
+            rc = d.pass(b.beta, n, wout, b.g, b.stats + 3, H, b, s);     // w, g, loglik and H in one read of the rows
             if (rc) return rc;
         } else {
-            rc = d.logit(b.beta, n, b.w, b.g, b.stats + 3, b, s);
+            rc = d.logit(b.beta, n, fresh_now ? b.w : wout, b.g, b.stats + 3, b, s);
             if (rc) return rc;
             if (fresh_now) {
                 rc = d.gram(b.w, n, H, b, s);
@@ -724,6 +729,11 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
     // (~n p bytes each): worth it once the Gram pass costs several logit passes, i.e. for p of a few hundred
     // (measured: 2.5e7 x 500 fit 0.41 -> 0.33 s; at p = 100 the extra iterations cost more than the Gram they save).
     const bool inherit_ok = env_inh ? atoi(env_inh) != 0 : (p >= 192);
+    // Lean passes (round 4): where the fused Newton pass serves a partition (49 <= p <= 120) no pass writes the weight vector --
+    // the stand-in Hessians of inherited factors are the one consumer the fused pass does not replace, so only without them.
+    // Config 2: the fused pass 2.53 -> 2.22 ms, the logit pass 1.39 -> 1.3 ms.  DLSA_IRLS_LEAN=0 keeps the weights.
+    const char* env_lean = knob("DLSA_IRLS_LEAN");
+    const bool lean = (env_lean ? atoi(env_lean) != 0 : true) && !inherit_ok;
     const char* env_fd = knob("DLSA_IRLS_FACTOR_DIV");
     const int fac_div = env_fd ? atoi(env_fd) : 4;              // rows / fac_div feed the stand-in Hessian (0/1: the subsample's)
     // Pooled preconditioner: the exact Hessians of the finished partitions (their Sig_inv, evaluated at their MLEs) are
@@ -813,13 +823,13 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
                         const int64_t nsub2 = nsub / sub_div;
                         if (nsub2 >= 100 * (int64_t)p && nsub2 >= 20000) {
                             rc = newton_run(d, nsub2, p, 1e-3, max_iter, freeze_at, Hk, cs.b, s, &st_sub, &it_sub, &gr_sub,
-                                            &ll_sub, &fresh);
+                                            &ll_sub, &fresh, 0.0, lean);
                             if (rc) return rc;
                             if (st_sub != DLSA_PART_OK) DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
                             st_sub = 0; it_sub = 0; gr_sub = 0;
                         }
                         rc = newton_run(d, nsub, p, 1e-6, max_iter, freeze_at, Hk, cs.b, s, &st_sub, &it_sub,
-                                        &gr_sub, &ll_sub, &fresh);
+                                        &gr_sub, &ll_sub, &fresh, 0.0, lean);
                         if (rc) return rc;
                         if (st_sub != DLSA_PART_OK) {   // degenerate subsample: plain cold start
                             DLSA_HIP_CHECK(hipMemsetAsync(cs.b.beta, 0, (size_t)p * sizeof(double), s));
@@ -851,7 +861,7 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
                     }
                 }
                 rc = newton_run(d, nk, p, tol, max_iter, freeze_at, Hk, cs.b, s, &st, &iters, &grams, &ll, &fresh,
-                                inherit);
+                                inherit, lean);
                 if (rc) return rc;
                 if (grams > 0) cs.factor_rows = nk;         // cs.b.L now factors a Hessian of this partition
                 else if (inherit > 0.0 && cs.factor_rows == 0) cs.factor_rows = cs.factor_rows_sub;
@@ -863,7 +873,9 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
             if (st == DLSA_PART_OK && !fresh) {
                 // Sig_inv must be the Hessian AT the returned coef: cs.b.w holds the weights of the last logit pass, which ran
                 // at exactly this beta -- or, after a predicted exit (newton_run), one step of <= 10 tol before it
-                rc = d.gram(cs.b.w, nk, Hk, cs.b, s);
+                // (lean runs wrote no weights: the fused pass evaluates H at the returned coef itself)
+                if (lean && d.lean_w && d.pass && d.fusable && d.fusable(nk)) rc = d.pass(cs.b.beta, nk, nullptr, cs.b.g, cs.b.stats + 3, Hk, cs.b, s);
+                else rc = d.gram(cs.b.w, nk, Hk, cs.b, s);
                 if (rc) return rc;
             } else if (st == DLSA_PART_NOT_CONVERGED) {
                 // report the Hessian at the last iterate
@@ -1059,6 +1071,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
             return irls_pass_impl(Xk, ldx, yk, beta, nrows, p, H, p, g, ll, w, nullptr, b.ws_pass, b.ws_pass_bytes, s, nullptr);
         };
         d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, ldx, yk, nrows, p); };
+        d.lean_w = true;
         return d;
     };
     int64_t max_rows = 0;
@@ -1145,6 +1158,7 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
                 return irls_pass_impl(Xk, pitch, yk, beta, nrows, p, H, p, g, ll, w, nullptr, b.ws_pass, b.ws_pass_bytes, s, nullptr);
             };
             d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, pitch, yk, nrows, p); };
+            d.lean_w = true;
         } else {                 // round 4: the fused kernel carries the implicit intercept as a ones column in its LDS stages
             d.pass = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* H, const IrlsBuffers& b, hipStream_t s) {
                 *b.border_rows = -1;                   // (this launch rewrites b.w: the border a logit pass left belongs to other weights)

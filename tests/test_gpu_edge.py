@@ -92,6 +92,32 @@ def test_logit_pass_p_limit_and_invalid_arguments(eng):
     assert rc == 1 and "bad shape" in _lib.last_error()
 
 
+def test_fits_at_fused_widths_write_no_weights_and_agree_with_the_weighted_form(eng, orc, monkeypatch):
+    """49 <= p <= 120: every Hessian of a fit, the closing one too, comes from the fused pass, so no pass writes the weight vector
+    (DLSA_IRLS_LEAN, default on).  Same MLE / Hessian / loglik as the form that keeps the weights, as the oracle, and as a run whose
+    switches force the cases that need weights again (inherited factors)."""
+    n, p = 150_000, 100
+    X, y = eng.synth(123, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    offs = [0, 70_001, n]
+    lean = eng.irls_fit(X, y, offs)
+    assert lean["status"] == [0, 0]
+    monkeypatch.setenv("DLSA_IRLS_LEAN", "0")
+    kept = eng.irls_fit(X, y, offs)
+    monkeypatch.delenv("DLSA_IRLS_LEAN")
+    monkeypatch.setenv("DLSA_IRLS_INHERIT", "1")              # stand-in Hessians read the weights: lean switches itself off
+    inh = eng.irls_fit(X, y, offs)
+    monkeypatch.delenv("DLSA_IRLS_INHERIT")
+    monkeypatch.setenv("DLSA_IRLS_FUSE_LAST", "0")            # the run ends on a logit pass: the closing Hessian is a fused pass of its own
+    nolast = eng.irls_fit(X, y, offs)
+    for other in (kept, inh, nolast):
+        assert other["status"] == [0, 0]
+        assert rel_inf(lean["coef"].cpu().numpy(), other["coef"].cpu().numpy()) < 1e-11
+        assert rel_inf(lean["Sig_inv"].cpu().numpy(), other["Sig_inv"].cpu().numpy()) < 1e-11
+        assert np.allclose(lean["loglik"], other["loglik"], rtol=1e-11)
+    c, _, sg = orc.logistic_model_block(X[:70_001].cpu().numpy(), y[:70_001].cpu().numpy())
+    assert rel_inf(lean["coef"][0].cpu().numpy(), c) < 1e-10 and rel_inf(lean["Sig_inv"][0].cpu().numpy(), sg) < 1e-10
+
+
 def test_irls_result_does_not_depend_on_acceleration_switches(eng, orc):
     """Subsample warm start, frozen / inherited Cholesky factors, secant corrections and partition warm starts only change the
     path of the iteration: the MLE and the Hessian at the MLE must agree to the solver tolerance."""
