@@ -435,6 +435,8 @@ class IrlsOptions:
     batched: Optional[bool] = None          # lock-step fit of all partitions together (narrow designs)
     qn_threads: Optional[int] = None
     trace: Optional[bool] = None
+    lean: Optional[bool] = None             # fits at fused widths write no weight vector
+    small_cluster: Optional[int] = None     # workgroups per partition of the one-launch kernel, 1..16
     freeze_at: Optional[float] = None       # 0: never freeze the factor
 
     def as_c(self):

@@ -164,6 +164,8 @@ typedef struct dlsa_irls_options {
     int batched;         /* lock-step fit of all partitions of a call together (narrow designs; -1 = by a cost model)  */
     int qn_threads;      /* workgroup size of the quasi-Newton step kernel (64..1024)                                   */
     int trace;           /* print step norms to stderr                                                                  */
+    int lean;            /* fits at fused widths write no weight vector (every Hessian from the fused pass)             */
+    int small_cluster;   /* workgroups per partition of the one-launch kernel: 1..16; -1 = by the partitions' count    */
     double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
 } dlsa_irls_options;
 /* which driver the calling thread's last dlsa_irls_fit_f64 / dlsa_irls_fit_ex_f64 took: 0 = host-driven partition chains, 1 = the

@@ -104,6 +104,9 @@ def test_fits_at_fused_widths_write_no_weights_and_agree_with_the_weighted_form(
     monkeypatch.setenv("DLSA_IRLS_LEAN", "0")
     kept = eng.irls_fit(X, y, offs)
     monkeypatch.delenv("DLSA_IRLS_LEAN")
+    with eng.irls_options(lean=False):                        # the same switch as an option field of the C ABI
+        kept_opt = eng.irls_fit(X, y, offs)
+    assert torch.equal(kept_opt["coef"], kept["coef"]) and torch.equal(kept_opt["Sig_inv"], kept["Sig_inv"])
     monkeypatch.setenv("DLSA_IRLS_INHERIT", "1")              # stand-in Hessians read the weights: lean switches itself off
     inh = eng.irls_fit(X, y, offs)
     monkeypatch.delenv("DLSA_IRLS_INHERIT")

@@ -152,6 +152,12 @@ def test_small_partition_clusters_give_the_single_workgroup_result(eng, orc, mon
         assert rel_inf(mb.coef[k].cpu().numpy(), c) < TOL_MLE
         assert rel_inf(mb.Sig_inv[k].cpu().numpy(), sig) < TOL_MLE
         assert rel_inf(mb.Sig_invMcoef[k].cpu().numpy(), smc) < TOL_MLE
+    if C == 3:                                                     # the cluster size as an option field instead of the environment
+        monkeypatch.delenv("DLSA_IRLS_SMALL_CLUSTER")
+        with eng.irls_options(small_cluster=3):
+            mo = dlsa_amd.fit_logistic_partitions(dev(X), dev(y), partition_num=K, fit_intercept=True)
+        assert torch.equal(mo.coef, mb.coef) and torch.equal(mo.Sig_inv, mb.Sig_inv)
+        monkeypatch.setenv("DLSA_IRLS_SMALL_CLUSTER", "3")
     offs = [0, 9000, 9040, 9040, 15000, 21000]                     # 9000 rows, 40 rows (separable or not: status only), empty, 5960, 6000
     r = eng.irls_fit(dev(X[:21000]), dev(y[:21000]), offs)
     assert r["status"][0] == 0 and r["status"][2] == 4 and r["status"][3] == 0 and r["status"][4] == 0
