@@ -1169,6 +1169,7 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
                 return irls_pass_icpt_impl(Xk, pitch, yk, beta, nrows, p, H, pe, g, ll, w, b.ws_pass, b.ws_pass_bytes, s);
             };
             d.fusable = [=](int64_t nrows) { return irls_pass_fused_icpt_eligible(Xk, pitch, yk, nrows, p); };
+            d.lean_w = true;
         }
         return d;
     };

@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void fused_reduce_icpt_kernel(const double* __
 int irls_pass_icpt_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* H, int64_t ldh,
                         double* g, double* loglik, double* w_out, void* ws, size_t ws_bytes, hipStream_t stream) {
     const int pe = p + 1;
-    DLSA_REQUIRE(X && y && beta && H && w_out && ldh >= pe, "irls_pass (intercept): null argument or ldh < p + 1");
+    DLSA_REQUIRE(X && y && beta && H && ldh >= pe, "irls_pass (intercept): null argument or ldh < p + 1");      // (w_out may be null: no weights written)
     FusedArgs a;
     a.slabs = nullptr; a.active = nullptr; a.beta_stride = 0;
     a.X = X; a.y = y; a.beta = beta; a.w_out = w_out; a.ldx = ldx; a.n = n; a.p = p; a.PP = (int)fp_pp(pe);
@@ -988,11 +988,12 @@ int irls_pass_icpt_impl(const double* X, int64_t ldx, const double* y, const dou
     a.partial = (double*)ws;
     a.gpart = (double*)((char*)ws + part);
     a.clk = (unsigned long long*)((char*)ws + part + gpb);
-#define DLSA_LAUNCH_FPI(NTV, GV) do { \
+#define DLSA_LAUNCH_FPI_W(WO, NTV, GV) do { \
         const size_t shm = fp_hess_lds(NTV, GV); \
-        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<true, true, NTV, GV, false, true>), \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<WO, true, NTV, GV, false, true>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL((irls_pass_narrow_kernel<true, true, NTV, GV, false, true>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<WO, true, NTV, GV, false, true>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
+#define DLSA_LAUNCH_FPI(NTV, GV) do { if (w_out) DLSA_LAUNCH_FPI_W(true, NTV, GV); else DLSA_LAUNCH_FPI_W(false, NTV, GV); } while (0)
 #define DLSA_LAUNCH_FPI_G(NTV) do { switch (gt) { \
         case 0: DLSA_LAUNCH_FPI(NTV, 0); break; case 1: DLSA_LAUNCH_FPI(NTV, 1); break; \
         case 2: DLSA_LAUNCH_FPI(NTV, 2); break; default: DLSA_LAUNCH_FPI(NTV, 3); break; } } while (0)
@@ -1004,8 +1005,9 @@ int irls_pass_icpt_impl(const double* X, int64_t ldx, const double* y, const dou
     }
 #undef DLSA_LAUNCH_FPI_G
 #undef DLSA_LAUNCH_FPI
+#undef DLSA_LAUNCH_FPI_W
     DLSA_HIP_CHECK(hipGetLastError());
-    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<true,true,%d,%d,icpt>", nt > 6 ? 7 : nt, nt > 6 ? (gt > 2 ? 2 : gt) : gt);
+    note_gram_kernel(a.clk, stream, "irls_pass_narrow_kernel<%s,true,%d,%d,icpt>", w_out ? "true" : "false", nt > 6 ? 7 : nt, nt > 6 ? (gt > 2 ? 2 : gt) : gt);
     hipLaunchKernelGGL(fused_reduce_icpt_kernel, dim3((pe + 15) / 16, pe), dim3(256), 0, stream, (const double*)ws, nslab, a.PP, pe, H, ldh);
     hipLaunchKernelGGL(irls_pass_finish_kernel, dim3((pe + 1 + 15) / 16), dim3(256), 0, stream, (const double*)a.gpart, nslab, GP, pe,
                        16 * ntc, g, loglik, 1);
