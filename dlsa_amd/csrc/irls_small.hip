@@ -380,6 +380,9 @@ std::atomic<long long> g_small_cluster_timeout_ticks{200000000ll};      // 2 s o
 // barriers and the partial sums cost what the shorter pass saves).  DLSA_IRLS_SMALL_CLUSTER = C forces it (1 .. 16).
 static int small_cluster_count(int K, int64_t nmax) {
     int C = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(8, kNumCU / std::max(K, 1)), nmax / 512));
+    // sixteen only for long partitions: workgroup 0 adds 15 partials of 33 KB and the barriers span 16 CUs (K = 4: 5000 rows 0.72 ms at
+    // C = 8 / 1.02 at 16, 20000 rows 1.08 / 1.18, 60000 rows 2.01 / 1.64)
+    if (C == 8 && kNumCU / std::max(K, 1) >= 16 && nmax >= 30000) C = 16;
     if (const char* e = knob("DLSA_IRLS_SMALL_CLUSTER")) C = std::max(1, std::min(16, atoi(e)));
     if ((int64_t)K * C > kNumCU) C = 1;                  // (co-residency: a CU takes one workgroup of this kernel -- 256 registers x 512 threads)
     return C;
@@ -410,7 +413,7 @@ bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     const int cap = e ? std::min(8, std::max(1, atoi(e))) : 4;
     const int S = std::max(1, std::min(cap, (K - 1) / 2));
     static const double per_partition_ms[5] = {0.55, 0.55, 0.37, 0.29, 0.23};
-    const double t_small = (0.8 + 1.9e-4 * ((double)nmax / C) * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
+    const double t_small = ((C > 8 ? 1.0 : 0.8) + 1.9e-4 * ((double)nmax / C) * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
     return t_small < t_host;
 }
 
