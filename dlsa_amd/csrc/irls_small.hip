@@ -287,6 +287,18 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
                     const double* __restrict__ rc = Ls + c * SM_LD;
                     double s0 = Hs[jj * SM_LD + c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
                     int kk = 0;
+                    for (; kk + 15 < c; kk += 16) {          // sixteen pairs of loads in flight: a trip costs one LDS round trip, not four
+                        double a[16], b[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { a[q] = rj[kk + q]; b[q] = rc[kk + q]; }
+#pragma unroll
+                        for (int q = 0; q < 16; q += 4) {
+                            s0 = fma(-a[q], b[q], s0);
+                            s1 = fma(-a[q + 1], b[q + 1], s1);
+                            s2 = fma(-a[q + 2], b[q + 2], s2);
+                            s3 = fma(-a[q + 3], b[q + 3], s3);
+                        }
+                    }
                     for (; kk + 3 < c; kk += 4) {
                         s0 = fma(-rj[kk], rc[kk], s0);
                         s1 = fma(-rj[kk + 1], rc[kk + 1], s1);
