@@ -235,11 +235,28 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
             }
             if (!cluster_barrier(cbar, a.bar_abort, (unsigned)C, bphase, a.bar_timeout)) return;
             if (leader) {
-                for (int c = 1; c < C; ++c) {
-                    const double* __restrict__ src = a.scratch + ((int64_t)k * C + c) * SM_SLOT;
-                    for (int e = tid; e < pe * SM_LD; e += SM_THREADS) Hs[e] += src[e];
-                    if (tid < pe) gs[tid] += src[SM_MAXP * SM_LD + tid];
-                    if (tid == 0) sc[0] += src[SM_MAXP * SM_LD + SM_MAXP];
+                // element by element: the C - 1 loads of an element go out together (one L2 round trip per element, not one per
+                // partial), the additions keep the order 1 .. C - 1
+                const double* __restrict__ src0 = a.scratch + (int64_t)k * C * SM_SLOT;
+                auto gather_add = [&](int e, double acc) {
+                    double v[15];
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) v[c - 1] = c < C ? src0[(int64_t)c * SM_SLOT + e] : 0.0;
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) if (c < C) acc += v[c - 1];
+                    return acc;
+                };
+                if (C >= 4) {
+                    for (int e = tid; e < pe * SM_LD; e += SM_THREADS) Hs[e] = gather_add(e, Hs[e]);
+                    if (tid < pe) gs[tid] = gather_add(SM_MAXP * SM_LD + tid, gs[tid]);
+                    if (tid == 0) sc[0] = gather_add(SM_MAXP * SM_LD + SM_MAXP, sc[0]);
+                } else {
+                    for (int c = 1; c < C; ++c) {
+                        const double* __restrict__ src = src0 + (int64_t)c * SM_SLOT;
+                        for (int e = tid; e < pe * SM_LD; e += SM_THREADS) Hs[e] += src[e];
+                        if (tid < pe) gs[tid] += src[SM_MAXP * SM_LD + tid];
+                        if (tid == 0) sc[0] += src[SM_MAXP * SM_LD + SM_MAXP];
+                    }
                 }
                 __syncthreads();
             }
