@@ -1,4 +1,4 @@
-"""Randomised LARS / lasso paths outside the suite: python bench/lars_fuzz.py [cases] [seed]
+"""Randomised LARS / lasso paths outside the suite: python bench/lars_fuzz.py [cases] [seed] [wide]      (wide = 1: widths up to 1020)
 Every case runs lars_q.hip (default build for its width, plus one forced build) and lars.hip (DLSA_LARS_Q=0) and compares the whole
 path, beta0, AIC and BIC with the oracle's restatement of lsa.py:90-212."""
 import os, sys, time
@@ -25,7 +25,7 @@ def problem(p, rho, seed):
 
 
 def run(S, b, intercept, n, typ, env):
-    for k in ("DLSA_LARS_Q", "DLSA_LARS_Q_THREADS", "DLSA_LARS_Q_LDS"):
+    for k in ("DLSA_LARS_Q", "DLSA_LARS_Q_THREADS", "DLSA_LARS_Q_LDS", "DLSA_LARS_Q_WGS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     r = engine.lars_path(torch.from_numpy(S).cuda(), torch.from_numpy(b).cuda(), intercept, float(n), type=typ)
@@ -40,11 +40,14 @@ def main():
     t0 = time.time()
     for c in range(cases):
         p = int(rng.choice([rng.integers(1, 30), rng.integers(30, 110), rng.integers(110, 260), rng.integers(260, 420)]))
+        if len(sys.argv) > 3 and sys.argv[3] != "0":
+            p = int(rng.choice([rng.integers(400, 520), rng.integers(520, 1021)]))
         intercept = bool(rng.random() < 0.4) and p > 1
         typ = "lasso" if rng.random() < 0.6 else "lar"
         rho = float(rng.choice([0.0, 0.5, 0.9, 0.98]))
         S, b, n = problem(p, rho, 31000 + c)
-        forced = {"DLSA_LARS_Q_THREADS": str(rng.choice([256, 512, 1024])), "DLSA_LARS_Q_LDS": str(rng.integers(0, 2))}
+        forced = {"DLSA_LARS_Q_THREADS": str(rng.choice([256, 512, 1024])), "DLSA_LARS_Q_LDS": str(rng.integers(0, 2)),
+                  "DLSA_LARS_Q_WGS": str(rng.choice([1, 2, 3, 5, 8]))}
         got = [run(S, b, intercept, n, typ, {}), run(S, b, intercept, n, typ, forced), run(S, b, intercept, n, typ, {"DLSA_LARS_Q": "0"})]
         ref = orc.lars_lsa(S, b, intercept, n, type=typ) if p <= 420 else got[2]
         kinds["oracle" if p <= 420 else "kernels only"] = kinds.get("oracle" if p <= 420 else "kernels only", 0) + 1

@@ -2,6 +2,7 @@
 // Cholesky rows, one workgroup).  Reference: lars_lsa, dlsa/lsa.py:90-212.
 #pragma once
 #include "common.h"
+#include <mutex>
 
 namespace dlsa {
 
@@ -26,11 +27,15 @@ struct LarsArgs {
     double* upart;    // G x ld: per-workgroup partial sums of Sigma[:,active] w
     unsigned* bar;    // grid barrier: [0] arrival counter, [1] abort word (both zero at launch)
     long long bar_timeout;   // ticks of the 100 MHz wall clock a workgroup waits at a grid barrier before it aborts the launch
+    int nwg;          // lars_q.hip: workgroups sharing the rows of the fused pass (1: none)
 };
 
+extern std::mutex g_lars_grid_mu;      // lars.hip: serialises this process's multi-workgroup path launches (launch .. completion)
+
 // lars_q.hip: the path kernel for narrow problems (m = p - intercept <= LARS_Q_MAX_M)
-constexpr int LARS_Q_MAX_M = 400;
+constexpr int LARS_Q_MAX_M = 1020;
 bool lars_q_eligible(int p, int intercept);
-int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s);
+// returns DLSA_OK with *aborted = 1 when a clustered launch gave up at its barrier (nothing usable was written: run again with max_wgs = 1)
+int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used);
 
 }  // namespace dlsa

@@ -1011,12 +1011,24 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.bar_timeout = g_lars_barrier_timeout_ticks.load();
     int steps = 0, wgs_used = 1;
     if (lars_q_eligible(p, intercept)) {
-        // narrow problems: one workgroup on the carried Cholesky rows (lars_q.hip); every entry of its matrices is written before
-        // it is read, so nothing is cleared
-        const int rc = lars_q_run(a, p, intercept, s);
-        if (rc) return rc;
-        DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
-        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        // up to 510 variables: the carried Cholesky rows (lars_q.hip) -- one workgroup, or a few that share the fused pass and meet
+        // at a bounded grid barrier (a launch that gave up there is rerun on one workgroup).  Every entry of its matrices is written
+        // before it is read, so nothing is cleared.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            std::unique_lock<std::mutex> grid_lock(g_lars_grid_mu, std::defer_lock);
+            const int max_wgs = attempt == 0 ? LARS_MAX_WGS : 1;
+            if (max_wgs > 1 && p - (intercept ? 1 : 0) > 108) grid_lock.lock();
+            const int rc = lars_q_run(a, p, intercept, s, max_wgs, &wgs_used);
+            if (rc) return rc;
+            DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
+            DLSA_HIP_CHECK(hipStreamSynchronize(s));
+            if (steps >= 0) break;
+            g_lars_grid_aborts.fetch_add(1);
+            if (attempt == 1 || wgs_used == 1) {
+                set_error("lars_lsa: the path kernel aborted (grid barrier timeout with %d workgroups)", wgs_used);
+                return DLSA_ERR_HIP;
+            }
+        }
         if (n_steps_host) *n_steps_host = steps;
         return DLSA_OK;
     }

@@ -22,6 +22,7 @@
 #include "options.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace dlsa {
 namespace {
@@ -41,6 +42,50 @@ __shared__ long long q_prof_c0, q_prof_w0;
 // Workgroup barrier for data exchanged through LDS.  __syncthreads() also drains the wave's global loads and stores (vmcnt(0)):
 // with it every step waited for its path-record stores and for the prefetched row of S at the next barrier (~1.5 us per step).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The workgroups that share a fused pass (clusters, m > 108): lars.hip's bounded grid barrier -- a monotonic counter with agent-scope
+// release / acquire, relaxed polling with ONE acquire after the match; a wait longer than the timeout sets the abort word and every
+// workgroup leaves (the host then runs the path on one workgroup).
+struct QGrid {
+    int nwg, wg, xld;
+    double* xbuf;            // [2][nwg][xld]: the workgroups' partial sums of a pass, two buffers used alternately
+    unsigned* bar;
+    long long timeout;
+    unsigned phase;          // barrier count of this launch
+    int passes;              // exchanged passes so far (buffer parity)
+    bool failed;
+};
+__device__ __forceinline__ bool q_grid_barrier(QGrid& gr) {
+    __shared__ int gb_ok;
+    __syncthreads();                 // this workgroup's global stores have been issued by every wave
+    if (threadIdx.x == 0) {
+        ++gr.phase;
+        const unsigned target = gr.phase * (unsigned)gr.nwg;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(gr.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(gr.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins++ & 255u) == 0u) {
+                if (__hip_atomic_load(gr.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                if (wall_clock64() - t0 > gr.timeout) {
+                    __hip_atomic_store(gr.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        gb_ok = ok ? 1 : 0;
+    } else {
+        ++gr.phase;
+    }
+    __syncthreads();
+    return gb_ok != 0;
+}
 
 // Values every lane holds alike (sums reduced over the wave, LDS words read by all lanes) that steer control flow or count loops:
 // moved to a scalar register, or the compiler predicates every loop and branch they touch with lane masks.
@@ -127,10 +172,10 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // workgroup better than one G for both.  i0 = the first row the thread reads (RT's column pair (c2, c2 + 1) exists from row c2
 // on), `stride` = the distance between the row groups' partial sums of one column pair in `part` (indexed by thread).
 struct QLayout {
-    int G, g, c2, i0, stride;
+    int G, Gl, g, c2, i0, stride;      // G: row stride of a thread's walk (all workgroups' row groups), Gl: this workgroup's row groups
     bool isq, live;
 };
-__device__ __forceinline__ QLayout q_layout(int T, int tid, int m, bool lds) {
+__device__ __forceinline__ QLayout q_layout(int T, int tid, int m, bool lds, int nwg, int wg) {
     QLayout L;
     const int NQ = ((m + 1) & ~1) >> 1, NR = (m + 2) >> 1;
     int GQ = 1, GR = 1;
@@ -145,21 +190,24 @@ __device__ __forceinline__ QLayout q_layout(int T, int tid, int m, bool lds) {
         }
     } else {
         // Q and RT in global memory: the pass is bound by what one CU streams from L2 (~75 GB/s in 16-byte loads); more loading
-        // threads only lengthen the slowest walk (p = 260, GQ = 2 / GR = 1: 2.35 ms; one G for both: 2.13 ms)
+        // threads only lengthen the slowest walk (p = 260, GQ = 2 / GR = 1: 2.35 ms; one G for both: 2.13 ms) -- more CUs do
+        // help: nwg workgroups deal the row groups among them (group wg * Gl + g of nwg * Gl)
         GQ = GR = max(1, T / (NQ + NR));
     }
     const int nq_threads = NQ * GQ;
     L.isq = tid < nq_threads;
     const int u = L.isq ? tid : tid - nq_threads;
     const int width = L.isq ? NQ : NR;
-    L.G = L.isq ? GQ : GR;
+    L.Gl = L.isq ? GQ : GR;
+    L.G = L.Gl * nwg;
     L.stride = width;
     L.g = u / width;
     const int jx = u - L.g * width;
-    L.live = L.g < L.G;
+    L.live = L.g < L.Gl;
     L.c2 = 2 * jx;
-    L.i0 = L.g;
-    if (!L.isq && L.c2 > L.g) L.i0 = L.g + (L.c2 - L.g + L.G - 1) / L.G * L.G;
+    const int gidx = wg * L.Gl + L.g;
+    L.i0 = gidx;
+    if (!L.isq && L.c2 > gidx) L.i0 = gidx + (L.c2 - gidx + L.G - 1) / L.G * L.G;
     return L;
 }
 
@@ -169,7 +217,7 @@ __device__ __forceinline__ QLayout q_layout(int T, int tid, int m, bool lds) {
 // allowed.  Per row a thread spends two pointer additions, two loads and two FMAs (an integer multiplication costs four FMAs'
 // issue time with one wave per SIMD): row offsets advance by constants, the packed RT's by a running difference.
 template <int T, bool LDSQ, typename EQ, typename ER>
-__device__ __forceinline__ void fused_mv(const QLayout& L, const double* __restrict__ Qm, int ld, const double* __restrict__ RT, int ncolR,
+__device__ __forceinline__ void fused_mv(const QLayout& L, QGrid& gr, const double* __restrict__ Qm, int ld, const double* __restrict__ RT, int ncolR,
                                          int n, const double* __restrict__ x, int xs, double2* part, EQ&& eq, ER&& er) {
     const bool mine = L.live && (L.isq || L.c2 < ncolR);
     if (mine) {
@@ -240,11 +288,25 @@ __device__ __forceinline__ void fused_mv(const QLayout& L, const double* __restr
     QTICK(4);
     lds_barrier();
     QTICK(5);
+    double2 t = {0.0, 0.0};
     if (mine && L.g == 0) {
-        double2 t = part[threadIdx.x];
-        for (int q = 1; q < L.G; ++q) { const double2 u = part[threadIdx.x + q * L.stride]; t.x += u.x; t.y += u.y; }
-        if (L.isq) eq(L.c2, t); else er(L.c2, t);
+        t = part[threadIdx.x];
+        for (int q = 1; q < L.Gl; ++q) { const double2 u = part[threadIdx.x + q * L.stride]; t.x += u.x; t.y += u.y; }
     }
+    if (gr.nwg > 1) {
+        // the workgroups' partial sums meet in global memory: publish, one grid barrier, add in the order 0 .. nwg - 1 (every
+        // workgroup the same numbers: the emits below are replicated)
+        const int pos = (L.isq ? 0 : ld) + L.c2;
+        double* __restrict__ buf = gr.xbuf + (size_t)(gr.passes & 1) * gr.nwg * gr.xld;
+        if (mine && L.g == 0) *reinterpret_cast<double2*>(buf + (size_t)gr.wg * gr.xld + pos) = t;
+        ++gr.passes;
+        if (!q_grid_barrier(gr)) { gr.failed = true; return; }
+        if (mine && L.g == 0) {
+            t = *reinterpret_cast<const double2*>(buf + pos);
+            for (int w = 1; w < gr.nwg; ++w) { const double2 u = *reinterpret_cast<const double2*>(buf + (size_t)w * gr.xld + pos); t.x += u.x; t.y += u.y; }
+        }
+    }
+    if (mine && L.g == 0) { if (L.isq) eq(L.c2, t); else er(L.c2, t); }
     QTICK(6);
     // the emitted rows are read by other threads in later passes: through LDS, or (global variant) through the CU's L1 / L2, for
     // which the stores must have completed
@@ -254,7 +316,7 @@ __device__ __forceinline__ void fused_mv(const QLayout& L, const double* __restr
 
 __host__ __device__ inline size_t lars_q_lds_doubles(int m, int T, bool ldsq) {
     const size_t ld = (size_t)((m + 1) & ~1);
-    size_t n = 2 * (size_t)T + 10 * ld + 2 * ld;                          // part | ten double vectors | four int vectors
+    size_t n = 2 * (size_t)T + 11 * ld + 2 * ld;                          // part | eleven double vectors | four int vectors
     if (ldsq) n += (size_t)m * ld + (size_t)rt_off_packed(m) + 16;         // Q | packed RT
     return n;
 }
@@ -284,7 +346,8 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
     double* tv = sgn + ld;               // R^{-T} sgn, by active position
     double* gi1 = tv + ld;               // R^{-1} R^{-T} sgn, by active position
     double* rv = gi1 + ld;               // column `new` of Q
-    int* state = reinterpret_cast<int*>(rv + ld);   // 0 inactive, 1 active, 2 ignored
+    double* lastq = rv + ld;             // the row of Q the last append made (clusters: not yet visible in global memory to the others)
+    int* state = reinterpret_cast<int*>(lastq + ld);   // 0 inactive, 1 active, 2 ignored
     int* act = state + ld;               // active list (variable ids)
     int* dropf = act + ld;               // by active position
     int* pos = dropf + ld;               // position in the active list, m when not active
@@ -298,7 +361,18 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         RT = a.Rinv;
     }
     auto rt_off = [&](int l) { return LDSQ ? rt_off_packed(l) : l * ld; };
-    const QLayout L = q_layout(T, tid, m, LDSQ);
+    QGrid grid;
+    grid.nwg = LDSQ ? 1 : max(1, a.nwg);
+    grid.wg = LDSQ ? 0 : (int)blockIdx.x;
+    grid.xld = 2 * ld;
+    grid.xbuf = a.upart;
+    grid.bar = a.bar;
+    grid.timeout = a.bar_timeout;
+    grid.phase = 0; grid.passes = 0; grid.failed = false;
+    const bool writer = grid.wg == 0;              // workgroup 0 writes the path (every workgroup computes it)
+    const QLayout L = q_layout(T, tid, m, LDSQ, grid.nwg, grid.wg);
+    // the workgroup that owns row i of Q / RT (reads it in its passes, so writes it): the one of row group i mod G
+    auto owns_row = [&](int i) { return LDSQ || (i % (L.Gl * grid.nwg)) / L.Gl == grid.wg; };
     double* __restrict__ S = a.S;
 
     QPROF_DECL;
@@ -337,22 +411,23 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
     }
     __syncthreads();
     // Cvec = b' Sigma (lsa.py:114), rows of the symmetric S
-    fused_mv<T, false>(L, S, ld, nullptr, 0, m, bsgn, 1, part,
+    fused_mv<T, false>(L, grid, S, ld, nullptr, 0, m, bsgn, 1, part,
                        [&](int j, double2 t) { cvec[j] = t.x; cvec[j + 1] = j + 1 < m ? t.y : 0.0; }, [&](int, double2) {});
+    if (grid.failed) { if (tid == 0 && writer) *a.n_steps = -1; return; }
     const int max_steps = a.max_steps > 0 ? a.max_steps : 8 * m;
     const double logn = log(a.n);
     double Cmax;
     {
         double rss[1] = {0.0}, cm[1] = {0.0};
         for (int j = tid; j < m; j += T) {
-            a.beta_path[j] = 0.0;
+            if (writer) a.beta_path[j] = 0.0;
             const double c = cvec[j];
             rss[0] += bsgn[j] * c;
             cm[0] = fmax(cm[0], fabs(c));
         }
         B::reduce2(rss, WaveOpSum(), cm, WaveOpMax(), red, red_phase);
         Cmax = cm[0];
-        if (tid == 0) {
+        if (tid == 0 && writer) {
             a.aic[0] = rss[0]; a.bic[0] = rss[0];
             a.beta0[0] = a.intercept ? beta0c : 0.0;
         }
@@ -374,6 +449,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
     if (tid < ld) ckey[tid] = own ? r_cvec : __builtin_nan("");
     lds_barrier();
 
+    int last_pos = -1;         // the position whose row of Q is in `lastq`
     // Append variable `inew` with sign `sg` at position n_at (lsa.py:12-32 on the carried rows); returns 1 if the rank grew, 0 if
     // the column is machine-singular (nothing is modified then).
     auto append = [&](int n_at, int inew, double sg, double eps_rank) -> int {
@@ -385,7 +461,9 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         const double* xr = Q + inew;
         int xs = ld;
         if constexpr (!LDSQ) {
-            for (int i = tid; i < n_at; i += T) rv[i] = Q[i * ld + inew];
+            // (clusters: the row the previous append made was written by its owner after that append's barrier -- not yet visible
+            // here; every workgroup kept it in LDS)
+            for (int i = tid; i < n_at; i += T) rv[i] = (i == last_pos) ? lastq[inew] : Q[i * ld + inew];
             lds_barrier();
             xr = rv; xs = 1;
         }
@@ -409,14 +487,16 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         QTICK(3);
         double* __restrict__ qrow = Q + n_at * ld;
         double* __restrict__ rrow = RT + rt_off(n_at);
-        fused_mv<T, LDSQ>(L, Q, ld, RT, n_at + 1, n_at, xr, xs, part,
+        const bool mine_row = owns_row(n_at);
+        fused_mv<T, LDSQ>(L, grid, Q, ld, RT, n_at + 1, n_at, xr, xs, part,
             [&](int j, double2 t) {
                 double q0 = (s2.x - t.x) * rinv, q1 = (s2.y - t.y) * rinv;
                 const int2 pj = *reinterpret_cast<const int2*>(pos + j);
                 double2 vj = *reinterpret_cast<double2*>(v + j);
                 if (pj.x < n_at) q0 = 0.0;            // a variable appended earlier: its entry of the Schur complement is zero
                 if (pj.y < n_at) q1 = 0.0;
-                *reinterpret_cast<double2*>(qrow + j) = double2{q0, q1};
+                if (mine_row) *reinterpret_cast<double2*>(qrow + j) = double2{q0, q1};
+                if constexpr (!LDSQ) *reinterpret_cast<double2*>(lastq + j) = double2{q0, q1};
                 vj.x = fma(q0, tn, vj.x); vj.y = fma(q1, tn, vj.y);
                 *reinterpret_cast<double2*>(v + j) = vj;
             },
@@ -424,11 +504,13 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
                 // new column of R^{-1} (a row of RT): c = [-R^{-1} r / rpp ; 1/rpp];  Gi1 += c tn
                 const double c0 = i < n_at ? -t.x * rinv : (i == n_at ? rinv : 0.0);
                 const double c1 = i + 1 < n_at ? -t.y * rinv : (i + 1 == n_at ? rinv : 0.0);
-                *reinterpret_cast<double2*>(rrow + i) = double2{c0, c1};
+                if (mine_row) *reinterpret_cast<double2*>(rrow + i) = double2{c0, c1};
                 if (i < n_at) gi1[i] = fma(c0, tn, gi1[i]); else if (i == n_at) gi1[i] = c0 * tn;
                 if (i + 1 < n_at) gi1[i + 1] = fma(c1, tn, gi1[i + 1]); else if (i + 1 == n_at) gi1[i + 1] = c1 * tn;
                 if (i == n_at || i + 1 == n_at) { tv[n_at] = tn; sgn[n_at] = sg; act[n_at] = inew; pos[inew] = n_at; }
             });
+        if (grid.failed) return -1;
+        last_pos = n_at;
         return 1;
     };
 
@@ -471,6 +553,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
                 break;
             }
             const int grew = append(n_at, inew, sg, eps_rank);
+            if (grew < 0) { if (tid == 0 && writer) *a.n_steps = -1; return; }      // a cluster barrier gave up: the host reruns on one workgroup
             if (tid == inew) r_pos = grew ? n_at : m;
             if (rebuild) { ++re_i; continue; }
             if (tid == inew) { r_state = grew ? 1 : 2; ckey[inew] = __builtin_nan(""); }      // 2: machine-singular, ignored (lsa.py:139-144)
@@ -523,7 +606,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
             r_cvec -= gamhat * uj;
             ckey[tid] = r_state == 0 ? r_cvec : __builtin_nan("");
             const double ub = r_absb * r_beta;
-            a.beta_path[(int64_t)k * m + tid] = ub;
+            if (writer) a.beta_path[(int64_t)k * m + tid] = ub;
             rec[0] = (r_bsgn - r_beta) * r_cvec;
             nonzero = fabs(ub) > eps;
             if (a.intercept) rec[2] = r_a12 * ub;
@@ -540,7 +623,7 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
         }
         QTICK(12);
         Cmax = rec[3];
-        if (tid == T - 64) {      // (a wave that owns no variable: off the path of the waves that do)
+        if (tid == T - 64 && writer) {      // (a wave that owns no variable: off the path of the waves that do)
             a.aic[k] = rec[0] + 2.0 * rec[1];
             a.bic[k] = rec[0] + logn * rec[1];
             a.beta0[k] = a.intercept ? beta0c - rec[2] / a11 : 0.0;
@@ -562,9 +645,11 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
             double ts = 0.0;
             for (int i = lane; i < first; i += 64) ts = fma(tv[i], tv[i], ts);
             tsq = wave_allreduce_sum(ts);
-            fused_mv<T, LDSQ>(L, Q, ld, RT, first, first, tv, 1, part,
+            fused_mv<T, LDSQ>(L, grid, Q, ld, RT, first, first, tv, 1, part,
                 [&](int j, double2 t) { *reinterpret_cast<double2*>(v + j) = t; },
                 [&](int i, double2 t) { gi1[i] = t.x; if (i + 1 < first) gi1[i + 1] = t.y; });
+            if (grid.failed) { if (tid == 0 && writer) *a.n_steps = -1; return; }
+            last_pos = -1;                 // (the barrier of this pass published every row written so far)
             re_i = first; re_end = keep;
             na = keep;
         }
@@ -579,15 +664,18 @@ __global__ __launch_bounds__(T) void lars_q_kernel(LarsArgs a) {
                q_prof_t[9] * 0.01, q_prof_t[10] * 0.01, q_prof_t[11] * 0.01, q_prof_t[12] * 0.01, q_prof_t[13] * 0.01);
     }
 #endif
-    if (tid == 0) *a.n_steps = k;
+    if (tid == 0 && writer) *a.n_steps = k;
 }
 
 template <int T, bool LDSQ>
-int launch_q(LarsArgs& a, int m, hipStream_t s) {
+int launch_q(LarsArgs& a, int m, hipStream_t s, int nwg = 1) {
     const size_t shm = lars_q_lds_doubles(m, T, LDSQ) * sizeof(double);
     if (shm > 48 * 1024)
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_q_kernel<T, LDSQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((lars_q_kernel<T, LDSQ>), dim3(1), dim3(T), shm, s, a);
+    a.nwg = LDSQ ? 1 : nwg;
+    if (a.nwg > 1) DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
+    // (a plain launch, as lars.hip's grid kernel: co-residency of the few workgroups follows from the idle CUs; the barrier is bounded)
+    hipLaunchKernelGGL((lars_q_kernel<T, LDSQ>), dim3(a.nwg), dim3(T), shm, s, a);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
@@ -604,21 +692,33 @@ bool lars_q_eligible(int p, int intercept) {
     return true;
 }
 
+// Workgroups that share the fused pass when Q and RT are in global memory: the pass is bound by what ONE CU streams from L2, so the
+// row groups are dealt over nwg CUs at the price of one grid barrier per append (~1.4 us) and the exchange of the partial sums
+// (bench/lars_ab.py).  DLSA_LARS_Q_WGS overrides (1 .. 8).
+static int lars_q_workgroups(int m) {
+    int nwg = m <= 200 ? 1 : (m <= 420 ? 4 : 8);
+    if (const char* e = getenv("DLSA_LARS_Q_WGS")) nwg = atoi(e);
+    return std::max(1, std::min(nwg, 8));
+}
+
 // DLSA_LARS_Q_THREADS: 256 | 512 | 1024 forces the workgroup size; DLSA_LARS_Q_LDS=0 keeps Q and RT in global memory
-int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s) {
+int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used) {
     const int m = p - (intercept ? 1 : 0);
     int threads = 0;
     if (const char* e = getenv("DLSA_LARS_Q_THREADS")) threads = atoi(e);
     bool want_lds = true;
     if (const char* e = getenv("DLSA_LARS_Q_LDS")) want_lds = atoi(e) != 0;
+    if (wgs_used) *wgs_used = 1;
     auto fits = [&](int T) { return lars_q_lds_doubles(m, T, true) * 8 + LARS_Q_STATIC_LDS <= (size_t)kLdsBytes && (m + 2) <= T; };
     if (want_lds) {
         const int T = threads == 512 ? 512 : 256;
         if (fits(T)) return T == 512 ? launch_q<512, true>(a, m, s) : launch_q<256, true>(a, m, s);
         if (threads == 0 && fits(256)) return launch_q<256, true>(a, m, s);
     }
-    if (threads == 1024) return launch_q<1024, false>(a, m, s);
-    return launch_q<512, false>(a, m, s);      // (p = 260: 2.47 ms with 512 threads, 2.56 with 1024)
+    const int nwg = std::min(lars_q_workgroups(m), std::max(1, max_wgs));
+    if (wgs_used) *wgs_used = nwg;
+    if (threads == 1024 || m + 2 > 512) return launch_q<1024, false>(a, m, s, nwg);
+    return launch_q<512, false>(a, m, s, nwg);      // (p = 260: 2.47 ms with 512 threads, 2.56 with 1024)
 }
 
 }  // namespace dlsa

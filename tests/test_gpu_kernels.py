@@ -474,6 +474,37 @@ def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypa
     _lars_reference_cases(eng, orc)
 
 
+def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, monkeypatch):
+    """m > 200: a few workgroups share the fused pass of lars_q.hip and meet at the same bounded grid barrier; a launch that gives
+    up there is rerun on one workgroup.  Any workgroup count walks the oracle's path (p = 300 with drops, p = 700 on the 1024-thread
+    build against lars.hip)."""
+    from dlsa_amd import _lib
+    lib = _lib.load()
+    S, b, n = _correlated_lsa_problem(300, 0.9, 3)
+    ro = orc.lars_lsa(S, b, False, n, type="lasso")
+    for wgs in ("1", "3", "8"):
+        monkeypatch.setenv("DLSA_LARS_Q_WGS", wgs)
+        r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
+        assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7, wgs
+        assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
+    monkeypatch.delenv("DLSA_LARS_Q_WGS")
+    before = lib.dlsa_lars_grid_barrier_timeout(1e-9)
+    try:
+        r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
+        after = lib.dlsa_lars_grid_barrier_timeout(0.0)
+    finally:
+        lib.dlsa_lars_grid_barrier_timeout(0.0)
+    assert after > before
+    assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
+    S, b, n = _correlated_lsa_problem(700, 0.9, 19)
+    rq = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
+    monkeypatch.setenv("DLSA_LARS_Q", "0")
+    r0 = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
+    assert rq["beta"].shape == r0["beta"].shape
+    assert rel_inf(rq["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
+    assert rel_inf(rq["beta0"].cpu().numpy(), r0["beta0"].cpu().numpy()) < 1e-7
+
+
 @pytest.mark.parametrize("threads,lds", [(256, 1), (512, 1), (512, 0), (1024, 0)])
 def test_lars_q_kernel_variants_match_golden_and_oracle(eng, orc, monkeypatch, threads, lds):
     """lars_q.hip (carried Cholesky rows, the default up to m = 400) in its four builds -- Q and RT in LDS or in global memory,
