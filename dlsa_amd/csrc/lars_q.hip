@@ -1,4 +1,4 @@
-// LARS / lasso path of the least-squares approximation for narrow problems (m = p - intercept <= LARS_Q_MAX_M): one workgroup,
+// LARS / lasso path of the least-squares approximation up to LARS_Q_MAX_M penalised variables (m = p - intercept): one workgroup (or a few),
 // the Cholesky rows of ALL variables carried along the path (reference: lars_lsa and updateR, dlsa/lsa.py:12-32, 90-212).
 //
 // lars.hip keeps R^{-1} and, per step, gathers x = Sigma[active, new], forms r = R^{-T} x, the new column of R^{-1} and
@@ -15,7 +15,8 @@
 //     select (every wave scans Cvec in LDS redundantly: no barrier) -> gather r, |r|^2 and r.t per wave (1 barrier) ->
 //     the fused pass (2) -> step length and lasso crossing (one min-reduction, 2) -> move + path record + next Cmax (one reduction, 2).
 // For m <= ~108 Q and the packed RT live in LDS (160 KB); wider problems keep them in global memory (L2) with 8 row loads in
-// flight per thread.  A lasso drop (lsa.py:179-186) truncates Q / RT to the positions before the first dropped one, recomputes v and
+// flight per thread, and beyond m = 200 a few workgroups (CLUSTERS) deal the row groups of the pass among them: one bounded grid
+// barrier per append, partial sums through global memory added in a fixed order, everything else replicated (QGrid, fused_mv).  A lasso drop (lsa.py:179-186) truncates Q / RT to the positions before the first dropped one, recomputes v and
 // Gi1 from them with the same fused pass and appends the kept positions again (the factor of an ordered set is unique), as lars.hip.
 #include "common.h"
 #include "lars.h"
