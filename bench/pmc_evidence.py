@@ -40,7 +40,11 @@ KERNELS = {
     "logit_p50": dict(cmd=["bench/fused_quick.py", "10000000", "50"], pat="irls_pass_narrow_kernel<true, false",
                       src=["irls_pass.hip", "logistic.h", "common.h"], rows=10_000_000, p=50, elem=8, kind="logit"),
     "logit_p500": dict(cmd=["bench/logit_one.py", "10000000", "500"], pat="logit_kernel",
-                       src=["logit.hip", "logistic.h", "common.h"], rows=10_000_000, p=500, elem=8, kind="logit"),
+                       src=["logit.hip", "rowdot.h", "logistic.h", "common.h"], rows=10_000_000, p=500, elem=8, kind="logit"),
+    "wide_syrk_p500": dict(cmd=["bench/wide_syrk_probe.py", "1000000", "500"], pat="wide_syrk_kernel",
+                           src=["irls_wide.hip", "common.h"], rows=1_000_000, p=500, elem=2, kind="syrk"),
+    "logit_img_p500": dict(cmd=["bench/wide_syrk_probe.py", "1000000", "500"], pat="logit_kernel<4, 4, true, false, true>",
+                           src=["logit.hip", "rowdot.h", "logistic.h", "common.h"], rows=1_000_000, p=500, elem=8, kind="logit"),
     "onehot_c4": dict(cmd=["bench/onehot_one.py", "14000000", "14"], pat="oh_gram_kernel",
                       src=["onehot.hip", "common.h"], rows=1_000_000, p=260, elem=8, kind="onehot"),
 }
@@ -67,6 +71,16 @@ def sources_sha16(src):
 
 def evidence_path(round_tag, tag):
     return os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (round_tag, tag))
+
+
+ROUNDS = ("r05", "r04")           # newest first: a kernel untouched since an earlier round keeps that round's evidence
+
+
+def latest_evidence_path(tag):
+    for r in ROUNDS:
+        if os.path.exists(evidence_path(r, tag)):
+            return evidence_path(r, tag)
+    return evidence_path(ROUNDS[0], tag)
 
 
 def collect(round_tag, tag):
@@ -123,7 +137,7 @@ def collect(round_tag, tag):
 
 
 def main():
-    round_tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    round_tag = sys.argv[1] if len(sys.argv) > 1 else ROUNDS[0]
     tags = sys.argv[2:] or list(KERNELS)
     for t in tags:
         collect(round_tag, t)

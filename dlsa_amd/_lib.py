@@ -20,7 +20,7 @@ c_u64 = ctypes.c_uint64
 class IrlsOptionsC(ctypes.Structure):
     """include/dlsa_hip.h: dlsa_irls_options (field for field)"""
     _fields_ = [(n, c_int) for n in ("struct_bytes", "chains", "seeded", "subsample_div", "factor_div", "warm", "inherit", "pool", "secant",
-                                     "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace", "lean", "small_cluster")] + [("freeze_at", c_dbl)]
+                                     "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace", "lean", "small_cluster", "own_hessian")] + [("freeze_at", c_dbl)]
 
 
 SIGNATURES = {
@@ -55,6 +55,9 @@ SIGNATURES = {
                                   ctypes.POINTER(c_dbl), c_vp, c_sz, c_vp]),
     "dlsa_logit_pass_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dlsa_loglik_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "dlsa_newton_wide_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
+    "dlsa_newton_wide_eligible": (c_int, [c_vp, c_i64, c_i64, c_int, c_int]),
+    "dlsa_newton_wide_pass_f64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dlsa_gram_icpt_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dlsa_gram_icpt_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dlsa_irls_ex_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_i64]),

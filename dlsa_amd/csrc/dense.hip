@@ -35,12 +35,66 @@ __global__ void sum_blocks_kernel(const double* __restrict__ in, int64_t stride,
     out[e] = s;
 }
 
+// y = alpha * A x + beta * z   (A p x p row-major, one wave per row; z nullable; y may be z)
+__global__ void matvec_axpy_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ x, int p, double alpha,
+                                   const double* z, double beta, double* y) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= p) return;
+    double s0 = 0.0, s1 = 0.0;
+    const double* a = A + (int64_t)row * lda;
+    int k = lane;
+    for (; k + 64 < p; k += 128) { s0 = fma(a[k], x[k], s0); s1 = fma(a[k + 64], x[k + 64], s1); }
+    if (k < p) s0 = fma(a[k], x[k], s0);
+    double s = s0 + s1;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) y[row] = z ? fma(alpha, s, beta * z[row]) : alpha * s;
+}
+
+// stats[0] = |delta|_inf, stats[1] = |ref|_inf, stats[2] = 2 when delta holds a non-finite value, else 0 (the step statistics the
+// Cholesky solve kernels leave, for steps that come from elsewhere)
+__global__ __launch_bounds__(1024) void step_stats_kernel(const double* __restrict__ delta, const double* __restrict__ ref, int p,
+                                                          double* __restrict__ stats) {
+    __shared__ double red[3][16];
+    double mx = 0.0, mr = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < p; i += blockDim.x) {
+        const double v = delta[i];
+        mx = fmax(mx, fabs(v));
+        if (!isfinite(v)) bad = 1.0;
+        mr = fmax(mr, fabs(ref[i]));
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, m, 64));
+        mr = fmax(mr, __shfl_xor(mr, m, 64));
+        bad = fmax(bad, __shfl_xor(bad, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mx; red[1][threadIdx.x >> 6] = mr; red[2][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a = fmax(a, red[0][k]); b = fmax(b, red[1][k]); c = fmax(c, red[2][k]); }
+        stats[0] = a; stats[1] = b; stats[2] = c != 0.0 ? 2.0 : 0.0;
+    }
+}
+
 int launch_chol_solve(const double* A, int64_t lda, int64_t strideA, const double* rhs, int64_t stride_rhs,
                       const double* ref, int64_t stride_ref, int p, int nsys, double* Lws, double* xout,
                       int64_t stride_x, double* stats, int64_t stride_stats, hipStream_t s, int reuse_factor);   // chol.hip
 
 int launch_matvec(const double* A, int64_t lda, const double* x, int p, double* y, hipStream_t s) {
     hipLaunchKernelGGL(matvec_kernel, dim3((p + 3) / 4), dim3(256), 0, s, A, lda, x, p, y);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+int launch_matvec_axpy(const double* A, int64_t lda, const double* x, int p, double alpha, const double* z, double beta, double* y, hipStream_t s) {
+    hipLaunchKernelGGL(matvec_axpy_kernel, dim3((p + 3) / 4), dim3(256), 0, s, A, lda, x, p, alpha, z, beta, y);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+int launch_step_stats(const double* delta, const double* ref, int p, double* stats, hipStream_t s) {
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, s, delta, ref, p, stats);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

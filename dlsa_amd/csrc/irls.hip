@@ -79,6 +79,14 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
 int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
                      const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s, bool irls_weights);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
+int launch_matvec_axpy(const double* A, int64_t lda, const double* x, int p, double alpha, const double* z, double beta, double* y, hipStream_t s);
+int launch_step_stats(const double* delta, const double* ref, int p, double* stats, hipStream_t s);
+// irls_wide.hip: the logit pass of a wide design that also yields the partition's own Hessian in reduced precision (bf16 products)
+bool irls_wide_eligible(const double* X, int64_t ldx, int64_t n, int p, int icpt);
+size_t irls_wide_workspace_bytes(int64_t n, int p, int icpt);
+int irls_wide_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, int icpt, double* w_out,
+                        double* g, double* loglik, double* Happrox, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t stream);
+constexpr int64_t kWideMaxRows = 4000000;        // (the pass keeps a bf16 image of the partition: p / 2 KiB... 1 KiB per row at p = 500)
 // irls_batch.hip: the lock-step fit of all partitions of a call together
 bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step);
 int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int64_t row_step, int K,
@@ -91,7 +99,7 @@ static thread_local int g_last_fit_path = 0;
 constexpr int QN_PAIRS = 6;       // secant pairs kept for the quasi-Newton correction
 
 struct IrlsLayout {
-    size_t w, g, beta, beta_prev, delta, stats, L, Linv, Hinv, Hpool, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, border, total;
+    size_t w, g, beta, beta_prev, delta, stats, L, Linv, Hinv, Hpool, Ha, rr, pass, pass_bytes, qn_s, qn_y, qn_rho, qn_alpha, qn_q, qn_gprev, border, total;
 };
 
 // pass_bytes: scratch of the data source's logit / Gram passes (they never run concurrently)
@@ -109,6 +117,8 @@ static IrlsLayout irls_layout(int64_t max_rows, int p, size_t pass_bytes) {
     l.Linv = take((size_t)p * p * sizeof(double));
     l.Hinv = take((size_t)p * p * sizeof(double));
     l.Hpool = take((size_t)p * p * sizeof(double));
+    l.Ha = (p >= 121 && p <= 512) ? take((size_t)p * p * sizeof(double)) : 0;      // the partition's own reduced-precision Hessian (wide designs; offset 0 = none: w sits there)
+    l.rr = take((size_t)p * sizeof(double));
     // ... and of the p x p Gram pass that forms the explicit inverse of a reused factor
     l.pass_bytes = std::max(pass_bytes, gram_workspace_bytes_impl(p, p, 8));
     l.pass = take(l.pass_bytes);
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(1024) void qn_step_kernel(const double* __restrict_
 
 struct IrlsBuffers {
     double *w, *g, *beta, *prev, *delta, *stats, *L, *Linv, *Hinv, *Hpool;
+    double *Ha = nullptr, *rr = nullptr;       // own reduced-precision Hessian (null: not served) and the residual of its inner solve
     int* inv_valid;      // host flag: Linv is the inverse of the factor currently in L (bit 0), Hinv = Linv' Linv (bit 1)
     double* border;      // the Hessian's intercept border [sum w | X'w] of the LAST logit pass (fits with the implicit intercept)
     int64_t* border_rows;   // host: the row count that pass ran over (-1: none): a Gram over the same rows and weights takes it
@@ -388,6 +399,10 @@ struct IrlsData {
     // the fused launch needs no weight vector written (w == nullptr is allowed in `pass` and `logit`): at a fusable size every
     // Hessian then comes from `pass`, and the 8 bytes per row of every pass stay unwritten
     bool lean_w = false;
+    // optional (wide designs, irls_wide.hip): the logit pass that ALSO yields the partition's own Hessian in reduced precision -- a
+    // preconditioner for the steps, never a result
+    std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, double* Happrox, const IrlsBuffers& b, hipStream_t s)> approx;
+    std::function<bool(int64_t nrows)> approxable;
 };
 
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
@@ -436,12 +451,37 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     const size_t qn_shm = ((size_t)p + 16) * sizeof(double);
     *status = DLSA_PART_NOT_CONVERGED;
     *fresh = false;
+    const char* env_tr = knob("DLSA_IRLS_TRACE");
+    const bool trace_on = env_tr && atoi(env_tr) != 0;           // (0 = off, as the header documents)
     const char* env_fl = knob("DLSA_IRLS_FUSE_LAST");
     const bool can_fuse = d.pass && d.fusable && d.fusable(n);
     const bool fuse_last = can_fuse && (env_fl ? atoi(env_fl) != 0 : true);
     // lean: no weights are written -- every Hessian of this run comes from the fused pass, the closing one too (irls_fit_core)
     double* const wout = (lean && d.lean_w && can_fuse) ? nullptr : b.w;
     bool peek_next = false;
+    // Own reduced-precision Hessian (wide designs): the steps of a reused factor contract at the rate of that factor's sampling error
+    // against THIS partition (~0.05 with the pooled factor at 1e6 x 500: nine to ten passes).  After the first such step the pass is
+    // taken in the form that also yields H~ = the partition's own Hessian from bf16 products (irls_wide.hip), and every later step
+    // solves H~ delta = g -- by iterative refinement on the explicit inverse of the factor in hand (||I - H0^-1 H~|| ~ 0.05: three
+    // sweeps of two mat-vecs, no factorisation).  H~ at an iterate e away from the MLE contracts by ~2e + 1.5e-4 per pass; it is
+    // refreshed when that is not enough.  The gradient, the stopping rule and the safeguard stay fp64: the fixed point is the MLE.
+    const char* env_own = knob("DLSA_IRLS_OWN_HESSIAN");
+    const bool can_approx = (env_own ? atoi(env_own) != 0 : true) && d.approx && d.approxable && b.Ha && d.approxable(n) && inv_enabled(p);
+    bool have_Ha = false, approx_ok = true, want_refresh = false;
+    constexpr int kRefine = 3;
+    auto ensure_inverse = [&]() -> int {
+        if (!(*b.inv_valid & 1)) {
+            int rc = launch_tri_inverse(b.L, p, b.Linv, s);
+            if (rc) return rc;
+            *b.inv_valid = 1;
+        }
+        if (!(*b.inv_valid & 2)) {
+            int rc = gram_impl_f64(b.Linv, p, nullptr, p, p, b.Hinv, p, 0, b.ws_pass, b.ws_pass_bytes, s);
+            if (rc) return rc;
+            *b.inv_valid |= 2;
+        }
+        return DLSA_OK;
+    };
     for (int it = 1; it <= max_iter; ++it) {
         ++*iters;
         const bool fresh_now = need_H || !have_factor;
@@ -453,6 +493,11 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         if ((fresh_now || peek) && can_fuse) {
             rc = d.pass(b.beta, n, wout, b.g, b.stats + 3, H, b, s);     // w, g, loglik and H in one read of the rows
             if (rc) return rc;
+        } else if (can_approx && approx_ok && !fresh_now && !peek && ((!have_Ha && it >= 2) || (have_Ha && want_refresh))) {
+            rc = d.approx(b.beta, n, b.w, b.g, b.stats + 3, b.Ha, b, s);    // w, g, loglik as the logit pass + the partition's own H~
+            if (rc) return rc;
+            have_Ha = true;
+            want_refresh = false;
         } else {
             rc = d.logit(b.beta, n, fresh_now ? b.w : wout, b.g, b.stats + 3, b, s);
             if (rc) return rc;
@@ -465,8 +510,25 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             ++*gram_passes;
             gscale = 1.0;
             ord.m = 0;                               // a new H0: the old pairs go
+            have_Ha = false;                         // (... and the exact factor serves from here)
         }
-        const bool qn_now = qn_on && !fresh_now;
+        if (have_Ha) {
+            // delta = H~^-1 g by refinement on M = gscale * H0^-1:  delta = M g;  delta += M (g - H~ delta), kRefine times
+            rc = ensure_inverse();
+            if (rc) return rc;
+            rc = launch_matvec_axpy(b.Hinv, p, b.g, p, gscale, nullptr, 0.0, b.delta, s);
+            if (rc) return rc;
+            for (int k = 0; k < kRefine; ++k) {
+                rc = launch_matvec_axpy(b.Ha, p, b.delta, p, -1.0, b.g, 1.0, b.rr, s);
+                if (rc) return rc;
+                rc = launch_matvec_axpy(b.Hinv, p, b.rr, p, gscale, b.delta, 1.0, b.delta, s);
+                if (rc) return rc;
+            }
+            rc = launch_step_stats(b.delta, b.beta, p, b.stats, s);
+            if (rc) return rc;
+            ord.m = 0; qn_have_gprev = false;        // (the secant pairs belong to the steps of the bare factor)
+        }
+        const bool qn_now = qn_on && !fresh_now && !have_Ha;
         int push_slot = -1;
         if (qn_now && qn_have_gprev) {               // the accepted step prev -> beta gives a curvature pair
             push_slot = qn_next;
@@ -475,7 +537,9 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             else { for (int k = 0; k + 1 < QN_PAIRS; ++k) ord.idx[k] = ord.idx[k + 1]; ord.idx[QN_PAIRS - 1] = push_slot; }
         }
         const bool fused = qn_now && inv_enabled(p) && ((size_t)4 * p + 48 + 2 * QN_PAIRS) * sizeof(double) <= 64 * 1024;
-        if (fused) {
+        if (have_Ha) {
+            // (the step is there)
+        } else if (fused) {
             // reused factor, secant correction on: invert the factor once, then ONE launch per iteration
             if (!(*b.inv_valid & 1)) {
                 rc = launch_tri_inverse(b.L, p, b.Linv, s);
@@ -556,13 +620,14 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
         ll = h[3];
         *loglik = ll;
-        if (knob("DLSA_IRLS_TRACE")) fprintf(stderr, "[irls] n=%lld it=%d fresh=%d step=%.3e |beta|=%.3e ll=%.10e\n", (long long)n, it, (int)fresh_now, h[0], h[1], ll);
+        if (trace_on) fprintf(stderr, "[irls] n=%lld it=%d fresh=%d step=%.3e |beta|=%.3e ll=%.10e\n", (long long)n, it, (int)fresh_now + 2 * (int)have_Ha, h[0], h[1], ll);
         if (h[2] == 1.0) { *status = DLSA_PART_NOT_SPD; return DLSA_OK; }
         if (h[2] == 2.0 || !isfinite(ll)) { *status = DLSA_PART_NAN; return DLSA_OK; }
         // safeguard: the previous step overshot (log-likelihood dropped) -> halve it, refresh H
         if (have_prev && ll < ll_prev - 1e-12 * fabs(ll_prev) && halvings < 30) {
             ++halvings;
             ord.m = 0; qn_have_gprev = false;                            // the rejected step gives no valid pair
+            approx_ok = false; have_Ha = false;                          // (whatever preconditioner produced it: exact Hessians from here)
             rc = launch_axpby(b.beta, b.prev, -1.0, p, b.delta, s);      // delta = beta - prev
             if (rc) return rc;
             rc = launch_axpby(b.prev, b.delta, 0.5, p, b.beta, s);       // beta = prev + delta/2
@@ -596,6 +661,9 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
                 return DLSA_OK;
             }
         }
+        // H~ taken e away from the MLE contracts by ~2e per pass: once a step of it shrank by less than 100x and several passes are
+        // still ahead, the next pass refreshes it (one refresh at the second iterate is what a warm-started partition needs)
+        if (have_Ha && isfinite(dprev) && h[0] > 1e-2 * dprev && h[0] > 1e-9 * scale) want_refresh = true;
         // frozen-Hessian policy: keep the factor while steps are small and still shrinking fast
         if (!fresh_now && h[0] > 0.25 * dprev) need_H = true;            // stalled: refresh
         else need_H = h[0] > freeze_at * scale;
@@ -761,6 +829,8 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
         b.Linv = (double*)(base + l.Linv);
         b.Hinv = (double*)(base + l.Hinv);
         b.Hpool = (double*)(base + l.Hpool);
+        b.Ha = l.Ha ? (double*)(base + l.Ha) : nullptr;
+        b.rr = (double*)(base + l.rr);
         b.inv_valid = &cs.inv_valid_flag;
         b.border = (double*)(base + l.border); b.border_rows = &cs.border_rows;
         b.qn_s = (double*)(base + l.qn_s); b.qn_y = (double*)(base + l.qn_y); b.qn_rho = (double*)(base + l.qn_rho);
@@ -988,7 +1058,8 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
 }
 
 static size_t dense_pass_bytes(int64_t rows, int p) {
-    return std::max(irls_pass_workspace_bytes_impl(rows, p), std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p)));
+    const size_t wide = (p >= 121 && p <= 512 && rows >= 32768 && rows <= kWideMaxRows) ? irls_wide_workspace_bytes(rows, p, 0) : 0;
+    return std::max(std::max(irls_pass_workspace_bytes_impl(rows, p), wide), std::max(gram_workspace_bytes_impl(rows, p, 8), logit_workspace_bytes_impl(rows, p)));
 }
 
 // ---- implicit intercept (the ones column of models.py:121-122 is never materialised) --------------------------------
@@ -1072,6 +1143,10 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         };
         d.fusable = [=](int64_t nrows) { return irls_pass_fused_eligible(Xk, ldx, yk, nrows, p); };
         d.lean_w = true;
+        d.approx = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* Ha, const IrlsBuffers& b, hipStream_t s) {
+            return irls_wide_pass_impl(Xk, ldx, yk, beta, nrows, p, 0, w, g, ll, Ha, p, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        d.approxable = [=](int64_t nrows) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, ldx, nrows, p, 0); };
         return d;
     };
     int64_t max_rows = 0;
@@ -1171,6 +1246,11 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
             d.fusable = [=](int64_t nrows) { return irls_pass_fused_icpt_eligible(Xk, pitch, yk, nrows, p); };
             d.lean_w = true;
         }
+        d.approx = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* Ha, const IrlsBuffers& b, hipStream_t s) {
+            if (intercept) *b.border_rows = -1;             // (this pass rewrites b.w: the border a logit pass left belongs to other weights)
+            return irls_wide_pass_impl(Xk, pitch, yk, beta, nrows, p, intercept, w, g, ll, Ha, pe, b.ws_pass, b.ws_pass_bytes, s);
+        };
+        d.approxable = [=](int64_t nrows) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, pitch, nrows, p, intercept); };
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },

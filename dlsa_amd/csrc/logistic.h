@@ -41,14 +41,13 @@ __device__ __forceinline__ double exp_neg(double a) {      // exp(-a), a >= 0
 }
 
 // e = exp(-|eta|) -> mu = sigmoid(eta), wgt = mu(1-mu) = e/(1+e)^2, softplus(eta) = max(eta,0) + log1p(e)
-template <bool WANT_MU>
-__device__ __forceinline__ void logistic_terms(double eta, double& mu, double& wgt, double& softplus) {
-    const double e = exp_neg(fabs(eta));
-    if (WANT_MU) {
-        const double inv = rcp_newton(1.0 + e);
-        mu = eta >= 0.0 ? inv : e * inv;
-        wgt = e * inv * inv;
-    }
+// (three pieces, so that a caller can interleave other work between them: irls_wide.hip; logistic_terms is their composition)
+__device__ __forceinline__ void logistic_mu_w(double eta, double e, double& mu, double& wgt) {
+    const double inv = rcp_newton(1.0 + e);
+    mu = eta >= 0.0 ? inv : e * inv;
+    wgt = e * inv * inv;
+}
+__device__ __forceinline__ double logistic_softplus(double eta, double e) {
     const bool big = e > 0.41421356237309503;               // t = 1 + e > sqrt(2)
     const double num = big ? fma(0.5, e, -0.5) : e;         // t' - 1 with t' = t/2 or t
     const double den = big ? fma(0.5, e, 1.5) : 2.0 + e;    // t' + 1
@@ -66,6 +65,11 @@ __device__ __forceinline__ void logistic_terms(double eta, double& mu, double& w
     q = fma(q, z, 1.0 / 3.0);
     q = fma(q, z, 1.0);
     const double l1p = fma(2.0 * sv, q, big ? 6.931471805599453094e-01 : 0.0);
-    softplus = fmax(eta, 0.0) + l1p;
+    return fmax(eta, 0.0) + l1p;
 }
-
+template <bool WANT_MU>
+__device__ __forceinline__ void logistic_terms(double eta, double& mu, double& wgt, double& softplus) {
+    const double e = exp_neg(fabs(eta));
+    if (WANT_MU) logistic_mu_w(eta, e, mu, wgt);
+    softplus = logistic_softplus(eta, e);
+}

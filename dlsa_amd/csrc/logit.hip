@@ -40,84 +40,7 @@ constexpr int LOGIT_THREADS = 256;
 constexpr int LOGIT_WAVES = LOGIT_THREADS / 64;
 constexpr int LOGIT_MAX_BLOCKS = 2048;
 
-// Cross-lane exchanges without LDS round trips: dpp_xor_f64 / swap_f64 of common.h.
-// (lane & M ? hi : lo) of this lane + the same quantity of lane ^ M
-template <int M>
-__device__ __forceinline__ double exch_add(double lo, double hi, int lane) {
-    if constexpr (M >= 16) {
-        double a2, b2;
-        swap_f64<M>(lo, hi, a2, b2);        // no select: a2 + b2 is the kept value plus the partner's copy in both halves
-        return a2 + b2;
-    } else {
-        const double s0 = lo + dpp_xor_f64<M>(lo), s1 = hi + dpp_xor_f64<M>(hi);
-        return (lane & M) ? s1 : s0;
-    }
-}
-template <int M>
-__device__ __forceinline__ double xor_add(double s) {           // s + s of lane ^ M
-    if constexpr (M >= 16) return exch_add<M>(s, s, 0);
-    else return s + dpp_xor_f64<M>(s);
-}
-template <int L>
-__device__ __forceinline__ double read_lane_f64(double v) {     // broadcast of lane L through SGPRs
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
-}
-
-template <int RB>
-__device__ __forceinline__ double merged_reduce(double (&v)[RB], int lane) {
-    // after this, every lane holds the wave-sum of row rsel(lane): log2(RB) halving steps (masks 32, 16, ...), then
-    // plain xor-sums over the remaining masks
-    if constexpr (RB >= 2) {
-#pragma unroll
-        for (int i = 0; i < RB / 2; ++i) v[i] = exch_add<32>(v[i], v[i + RB / 2], lane);
-    }
-    if constexpr (RB >= 4) {
-#pragma unroll
-        for (int i = 0; i < RB / 4; ++i) v[i] = exch_add<16>(v[i], v[i + RB / 4], lane);
-    }
-    if constexpr (RB >= 8) {
-#pragma unroll
-        for (int i = 0; i < RB / 8; ++i) v[i] = exch_add<8>(v[i], v[i + RB / 8], lane);
-    }
-    if constexpr (RB >= 16) {
-#pragma unroll
-        for (int i = 0; i < RB / 16; ++i) v[i] = exch_add<4>(v[i], v[i + RB / 16], lane);
-    }
-    if constexpr (RB >= 32) v[0] = exch_add<2>(v[0], v[1], lane);
-    static_assert(RB <= 32, "merged_reduce: at most 32 values");
-    double s = v[0];
-    if constexpr (RB < 2) s = xor_add<32>(s);
-    if constexpr (RB < 4) s = xor_add<16>(s);
-    if constexpr (RB < 8) s = xor_add<8>(s);
-    if constexpr (RB < 16) s = xor_add<4>(s);
-    if constexpr (RB < 32) s = xor_add<2>(s);
-    s = xor_add<1>(s);
-    return s;
-}
-
-// row handled by `lane` after merged_reduce, and the representative lane of row i
-template <int RB>
-__device__ __forceinline__ int row_of_lane(int lane) {
-    int r = 0, m = 32;
-#pragma unroll
-    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) r += ((lane & m) ? 1 : 0) * (cnt / 2);
-    return r;
-}
-template <int RB>
-__host__ __device__ constexpr int lane_of_row(int i) {
-    int lane = 0, m = 32;
-    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) {
-        if (i >= cnt / 2) { lane |= m; i -= cnt / 2; }
-    }
-    return lane;
-}
-template <int RB>
-__host__ __device__ constexpr int rep_mask() {   // lane bits that must be zero for a representative lane
-    int used = 0, m = 32;
-    for (int cnt = RB; cnt > 1; cnt >>= 1, m >>= 1) used |= m;
-    return 63 & ~used;
-}
-
+#include "rowdot.h"       // exch_add, merged_reduce, row_of_lane, lane_of_row, rep_mask, read_lane_f64
 #include "logistic.h"      // rcp_newton, exp_neg, logistic_terms: shared with the fused Newton pass (irls_pass.hip)
 
 struct LogitArgs {
@@ -139,23 +62,62 @@ struct LogitArgs {
     // anyway -- hpart [nblocks][NC*128] = X'w per block, swpart [nblocks] = sum w -- so that the Gram that follows needs no pass of its own
     double* hpart = nullptr;
     double* swpart = nullptr;
+    // IMG form (irls_wide.hip): the pass also leaves S = sqrt(w) [X | 1] rounded to bf16 as chunk images of 16 rows in the layout the
+    // bf16 Gram kernel's MFMA fragments read -- [chunk][k-group of 8 rows][column block of 32][half of 4 rows][32 columns][4 rows x 2 B]
+    // (img_nb column blocks; img_ones: the design's column p is the intercept's ones column)
+    unsigned* img = nullptr;
+    int img_nb = 0;
+    int img_ones = 0;
 };
 
-// g += sum_i resid(row i) * x_i : the residual of row i sits in lane lane_of_row(i) and is broadcast through SGPRs
-template <int RB, int NC, int I>
-__device__ __forceinline__ void rank1_update(double resid, const double2 (&x)[RB][NC], double2 (&g)[NC]) {
+// IMG form: the batch's RB rows (RB = 4 or 8) scaled by sqrt(w) and rounded to bf16, a lane's two columns of a chunk half (4 rows x 2 B
+// each) as 16 contiguous bytes.  Columns past p (clamped loads) are masked; column p is the ones column when img_ones.
+typedef __bf16 logit_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float logit_f2v __attribute__((ext_vector_type(2)));
+typedef unsigned logit_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned logit_pack_bf16(float lo, float hi) {
+    const logit_f2v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, logit_bf16x2));
+}
+template <int RB, int I>
+__device__ __forceinline__ void logit_bcast_rows(float swf, float (&sw)[RB]) {
     if constexpr (I < RB) {
-        const double ri = read_lane_f64<lane_of_row<RB>(I)>(resid);
+        sw[I] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, swf), lane_of_row<RB>(I)));
+        logit_bcast_rows<RB, I + 1>(swf, sw);
+    }
+}
+template <int RB, int NC, class Args>
+__device__ __forceinline__ void logit_image(const Args& a, int64_t bt, int lane, float swf, const double2 (&x)[RB][NC]) {
+    static_assert(RB == 4 || RB == 8, "image: a batch is one or two halves of a k-group");
+    float sw[RB];
+    logit_bcast_rows<RB, 0>(swf, sw);
+    const int64_t row0 = bt * RB;
+    const int64_t chunk = row0 >> 4;
+    const int sub = (int)(row0 & 15) >> 2;                 // first 4-row piece of the batch within its chunk: k-group sub >> 1, half sub & 1
+    unsigned* base = a.img + chunk * ((int64_t)a.img_nb * 256);        // (img_nb * 1024 bytes per chunk)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            g[c].x = fma(ri, x[I][c].x, g[c].x);
-            g[c].y = fma(ri, x[I][c].y, g[c].y);
+    for (int c = 0; c < NC; ++c) {
+        const int col = c * 128 + 2 * lane, blk = 4 * c + (lane >> 4);
+        if (blk < a.img_nb) {
+            const bool in0 = col < a.p, in1 = col + 1 < a.p;
+            const float o0 = (a.img_ones && col == a.p) ? 1.0f : 0.0f, o1 = (a.img_ones && col + 1 == a.p) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int h = 0; h < RB / 4; ++h) {
+                float f0[4], f1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f0[i] = (in0 ? (float)x[4 * h + i][c].x : o0) * sw[4 * h + i];
+                    f1[i] = (in1 ? (float)x[4 * h + i][c].y : o1) * sw[4 * h + i];
+                }
+                const int piece = sub + h;
+                const logit_u4v v = {logit_pack_bf16(f0[0], f0[1]), logit_pack_bf16(f0[2], f0[3]), logit_pack_bf16(f1[0], f1[1]), logit_pack_bf16(f1[2], f1[3])};
+                *reinterpret_cast<logit_u4v*>(base + ((((piece >> 1) * a.img_nb + blk) * 2 + (piece & 1)) * 64 + (lane & 15) * 4)) = v;
+            }
         }
-        rank1_update<RB, NC, I + 1>(resid, x, g);
     }
 }
 
-template <int NC, int RB, bool VEC, bool BORDER = false>
+template <int NC, int RB, bool VEC, bool BORDER = false, bool IMG = false>
 __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     __shared__ double red[NC * 128 + 2];
     __shared__ double redh[BORDER ? NC * 128 + 1 : 1];
@@ -179,7 +141,8 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
     const int myrow = row_of_lane<RB>(lane);
     const bool rep = (lane & rep_mask<RB>()) == 0;
 
-    const int64_t nbatch = (a.n + RB - 1) / RB;
+    // (IMG: whole chunks of 16 rows -- a batch past n writes zeros into its share of the last chunk's image)
+    const int64_t nbatch = IMG ? (a.n + 15) / 16 * (16 / RB) : (a.n + RB - 1) / RB;
     const int64_t stride = (int64_t)gridDim.x * LOGIT_WAVES;
 
     // (the label of the lane's own row travels with the batch: a load issued later would make its s_waitcnt
@@ -237,6 +200,7 @@ __global__ __launch_bounds__(LOGIT_THREADS) void logit_kernel(LogitArgs a) {
             s0 += resid;
         }
         rank1_update<RB, NC, 0>(resid, x, g);
+        if constexpr (IMG) logit_image<RB, NC>(a, bt, lane, valid ? __builtin_sqrtf((float)wgt) : 0.0f, x);
         if constexpr (BORDER) {                 // X'w and sum w of the same rows (a clamped row past n weighs nothing)
             const double wv = valid ? wgt : 0.0;
             if (rep) sw += wv;
@@ -388,6 +352,13 @@ static int logit_blocks(int64_t n, int rb) {
 
 template <int NC, int RB>
 static void launch_logit(const LogitArgs& a, bool vec, int blocks, hipStream_t s) {
+    if constexpr (RB == 4 || RB == 8) {
+        if (a.img) {        // IMG form (irls_wide_pass_impl)
+            if (vec) hipLaunchKernelGGL((logit_kernel<NC, RB, true, false, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+            else hipLaunchKernelGGL((logit_kernel<NC, RB, false, false, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
+            return;
+        }
+    }
     if (a.hpart) {          // BORDER form (vector loads only: logit_border_ok)
         hipLaunchKernelGGL((logit_kernel<NC, RB, true, true>), dim3(blocks), dim3(LOGIT_THREADS), 0, s, a);
         return;
@@ -411,7 +382,8 @@ int irls_pass_impl(const double* X, int64_t ldx, const double* y, const double* 
                    int* fused_out);
 
 static int logit_pass_run(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
-                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border);
+                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border,
+                          unsigned* img = nullptr, int img_nb = 0);
 
 // intercept != 0: beta and g have p + 1 entries, [intercept | the p columns of X]; X itself has p columns.
 int logit_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
@@ -429,19 +401,29 @@ int logit_pass_border_impl(const double* X, int64_t ldx, const double* y, const 
     return logit_pass_run(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, stream, 1, border);
 }
 
+// The logit pass that also leaves the bf16 chunk images of sqrt(w) [X | 1] (IMG form; 129 <= p <= 512 runs four rows per wave, narrower eight).
+int logit_pass_image_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, double* w_out, double* g,
+                          double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, unsigned* img, int img_nb) {
+    DLSA_REQUIRE(img && img_nb > 0 && p <= 512, "logit_pass (image): needs an image buffer and p <= 512");
+    return logit_pass_run(X, ldx, y, beta, n, p, w_out, g, loglik, ws, ws_bytes, stream, intercept, nullptr, img, img_nb);
+}
+
 static int logit_pass_run(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p,
-                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border) {
+                          double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, hipStream_t stream, int intercept, double* border,
+                          unsigned* img, int img_nb) {
     DLSA_REQUIRE(X && y && beta, "logit_pass: null X, y or beta");
     DLSA_REQUIRE(p > 0 && n >= 0 && ldx >= p, "logit_pass: bad shape n=%lld p=%d ldx=%lld", (long long)n, p, (long long)ldx);
     DLSA_REQUIRE(p <= 2048, "logit_pass: p=%d > 2048 not supported", p);
-    const int nc = logit_nc(p);
-    if (!ws || ws_bytes < logit_workspace_bytes_impl(n, p) || ((uintptr_t)ws & 255)) {
-        set_error("logit_pass: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, p), ws_bytes);
+    // (IMG with the intercept: the ones column is column p of the image, so the lanes' column chunks must reach it -- p = 128, 256: one chunk more)
+    const int pw = img ? p + (intercept ? 1 : 0) : p;
+    const int nc = logit_nc(pw);
+    if (!ws || ws_bytes < logit_workspace_bytes_impl(n, pw) || ((uintptr_t)ws & 255)) {
+        set_error("logit_pass: workspace %zu bytes needed (256-aligned), got %zu", logit_workspace_bytes_impl(n, pw), ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
     // Narrow designs (49 <= p <= 120, aligned rows): the rows come through the LDS-DMA ring of the fused Newton pass, which streams
     // at the HBM rate where this kernel's register loads reach 5.2-5.5 TB/s (DLSA_LOGIT_RING=0: keep the register-load kernel).
-    if (!intercept && irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0)) {
+    if (!img && !intercept && irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0)) {
         const char* e = getenv("DLSA_LOGIT_RING");
         if (!e || atoi(e) != 0)
             return irls_pass_impl(X, ldx, y, beta, n, p, nullptr, p, g, loglik, w_out, nullptr, ws, ws_bytes, stream, nullptr);
@@ -455,6 +437,7 @@ static int logit_pass_run(const double* X, int64_t ldx, const double* y, const d
     a.beta0 = intercept ? beta : nullptr;
     a.hpart = border ? (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * nc * 128 * sizeof(double)) : nullptr;
     a.swpart = border ? (double*)ar.take((size_t)LOGIT_MAX_BLOCKS * sizeof(double)) : nullptr;
+    a.img = img; a.img_nb = img_nb; a.img_ones = (img && intercept) ? 1 : 0;
     const bool vec = (ldx % 2 == 0) && (p % 2 == 0) && (((uintptr_t)X & 15) == 0);
     int blocks;
     switch (nc) {

@@ -7,6 +7,7 @@ tensors that own the results.  There is no CPU path -- a CPU tensor raises.
 import contextlib
 import ctypes
 import dataclasses
+import threading
 from typing import Optional
 
 import numpy as np
@@ -354,6 +355,29 @@ def irls_pass(X, y, beta, want_w=False):
     return H, g, ll, w
 
 
+def newton_wide_pass(X, y, beta, fit_intercept=False, want_w=False):
+    """The wide Newton pass (dlsa_newton_wide_pass_f64): g, loglik (and w) of the logit pass at beta plus, from the SAME read of
+    the rows, the reduced-precision Hessian that preconditions the fit's Newton steps (bf16 products, fp32 accumulation; never a
+    result).  Returns (H_approx, g, loglik, w or None); raises when the shape is not served (121 <= p + intercept <= 512,
+    >= 32768 aligned rows)."""
+    lib = _lib.load()
+    _require_gpu(X, y, beta)
+    _f64(X, "X"); _f64(y, "y"); _f64(beta, "beta")
+    n, p = X.shape
+    pe = p + (1 if fit_intercept else 0)
+    if y.numel() != n or beta.numel() != pe:
+        raise ValueError("newton_wide_pass: y must have n = %d and beta %d elements" % (n, pe))
+    dev = X.device
+    H = torch.empty((pe, pe), dtype=torch.float64, device=dev)
+    g = torch.empty((pe,), dtype=torch.float64, device=dev)
+    ll = torch.empty((1,), dtype=torch.float64, device=dev)
+    w = torch.empty((n,), dtype=torch.float64, device=dev) if want_w else None
+    ws = _workspace(lib.dlsa_newton_wide_workspace_bytes(n, p, 1 if fit_intercept else 0), dev)
+    check(lib.dlsa_newton_wide_pass_f64(_ptr(X), _rowmajor(X), _ptr(y), _ptr(beta), n, p, 1 if fit_intercept else 0, _ptr(w), _ptr(g),
+                                        _ptr(ll), _ptr(H), pe, _ptr(ws), ws.numel(), _stream()))
+    return H, g, ll, w
+
+
 def gram_icpt(X, w=None, out=None):
     """H = [1 | X]' diag(w) [1 | X], (p + 1) x (p + 1), without materialising the ones column (models.py:121-130)."""
     lib = _lib.load()
@@ -437,6 +461,7 @@ class IrlsOptions:
     trace: Optional[bool] = None
     lean: Optional[bool] = None             # fits at fused widths write no weight vector
     small_cluster: Optional[int] = None     # workgroups per partition of the one-launch kernel, 1..16
+    own_hessian: Optional[bool] = None      # wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian
     freeze_at: Optional[float] = None       # 0: never freeze the factor
 
     def as_c(self):
@@ -450,10 +475,14 @@ class IrlsOptions:
         return c
 
 
+_options_stack = threading.local()          # the calling thread's active IrlsOptions, innermost last
+
+
 @contextlib.contextmanager
 def irls_options(options=None, **fields):
     """The calling thread's IRLS driver options for the fits (and workspace sizes) inside the block: an IrlsOptions, or its fields as
-    keyword arguments (`with engine.irls_options(chains=1, fused=False): ...`).  Cleared on exit."""
+    keyword arguments (`with engine.irls_options(chains=1, fused=False): ...`).  Blocks nest: the fields set here are merged over the
+    enclosing block's, and the enclosing options are restored on exit (automatic only when the outermost block ends)."""
     if options is None:
         options = IrlsOptions(**fields) if fields else None
     elif fields:
@@ -462,12 +491,25 @@ def irls_options(options=None, **fields):
         yield
         return
     lib = _lib.load()
+    stack = getattr(_options_stack, "items", None)
+    if stack is None:
+        stack = _options_stack.items = []
+    if stack:           # merge over the enclosing block's options
+        outer = stack[-1]
+        options = dataclasses.replace(outer, **{f.name: getattr(options, f.name) for f in dataclasses.fields(options)
+                                               if getattr(options, f.name) is not None})
     c = options.as_c()
     check(lib.dlsa_irls_set_options(ctypes.byref(c)))
+    stack.append(options)
     try:
         yield
     finally:
-        lib.dlsa_irls_set_options(None)
+        stack.pop()
+        if stack:
+            c = stack[-1].as_c()
+            lib.dlsa_irls_set_options(ctypes.byref(c))
+        else:
+            lib.dlsa_irls_set_options(None)
 
 
 IRLS_PATH_CHAINS, IRLS_PATH_SMALL, IRLS_PATH_BATCHED = 0, 1, 2

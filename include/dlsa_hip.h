@@ -166,6 +166,7 @@ typedef struct dlsa_irls_options {
     int trace;           /* print step norms to stderr                                                                  */
     int lean;            /* fits at fused widths write no weight vector (every Hessian from the fused pass)             */
     int small_cluster;   /* workgroups per partition of the one-launch kernel: 1..16; -1 = by the partitions' count    */
+    int own_hessian;     /* wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian */
     double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
 } dlsa_irls_options;
 /* which driver the calling thread's last dlsa_irls_fit_f64 / dlsa_irls_fit_ex_f64 took: 0 = host-driven partition chains, 1 = the
@@ -204,6 +205,18 @@ int dlsa_logit_pass_icpt_f64(const double* X, int64_t ldx, const double* y, cons
                              double* w_out, double* g, double* loglik, void* ws, size_t ws_bytes, void* stream);
 int dlsa_loglik_icpt_f64(const double* X, int64_t ldx, const double* y, int64_t n, int p, const double* par,
                          int64_t ldpar, int c, double* out, void* ws, size_t ws_bytes, void* stream);
+/* ---- Wide Newton pass (round 5): the logit pass of a wide design (121 <= p + intercept <= 512) that, in the same read of the
+ * rows, also accumulates a reduced-precision copy of the partition's own Hessian (models.py:110-114 and :130 in one read):
+ * w_out (nullable), g, loglik exactly as dlsa_logit_pass[_icpt]_f64; H_approx = [1 | X]' diag(w) [1 | X] from bf16-rounded
+ * sqrt(w) x products accumulated in fp32 (relative error ~1e-3 per entry, far less in the spectrum) -- (p + intercept)^2 doubles,
+ * both triangles, intercept first.  H_approx is the PRECONDITIONER of the fit's Newton steps (dlsa_irls_fit*_f64 uses it when a
+ * partition is eligible); Sig_inv is never taken from it.  dlsa_newton_wide_eligible: >= 32768 rows, 16-byte aligned rows of
+ * even pitch. */
+size_t dlsa_newton_wide_workspace_bytes(int64_t n, int p, int intercept);
+int dlsa_newton_wide_eligible(const double* X, int64_t ldx, int64_t n, int p, int intercept);
+int dlsa_newton_wide_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, int intercept,
+                              double* w_out, double* g, double* loglik, double* H_approx, int64_t ldh, void* ws, size_t ws_bytes,
+                              void* stream);
 size_t dlsa_gram_icpt_workspace_bytes(int64_t n, int p);
 int dlsa_gram_icpt_f64(const double* X, int64_t ldx, const double* w, int64_t n, int p, double* H, int64_t ldh,
                        void* ws, size_t ws_bytes, void* stream);

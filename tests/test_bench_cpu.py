@@ -164,13 +164,14 @@ def test_preflight_only_run_needs_no_json_line(monkeypatch):
 
 
 def test_committed_kernel_evidence_matches_the_tree():
-    """profiles/r04_pmc_<kernel>.json (bench/pmc_evidence.py) carry the hash of the sources they were taken from: a kernel whose
-    sources changed since needs its counters taken again (python3 bench/pmc_evidence.py r04 <tag> on the GPU box)."""
+    """profiles/r0N_pmc_<kernel>.json (bench/pmc_evidence.py; the newest round's file per kernel) carry the hash of the sources they
+    were taken from: a kernel whose sources changed since needs its counters taken again (python3 bench/pmc_evidence.py r05 <tag> on
+    the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "bench"))
     import pmc_evidence as ev
     stale = []
     for tag, k in ev.KERNELS.items():
-        path = ev.evidence_path("r04", tag)
+        path = ev.latest_evidence_path(tag)
         assert os.path.exists(path), "missing " + path
         doc = json.load(open(path))
         if doc["sources_sha16"] != ev.sources_sha16(k["src"]):
