@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TF = 78.6    # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (= fp32 vector 157.3 / 2)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+STRONG_MIN_ROWS = 65536     # rows per launch below which the library leaves the cyclic p = 500 Gram kernel (gram.hip)
 
 
 def parse(argv=None):
@@ -205,8 +206,9 @@ def preflight(args, rank, world, local, timeout_s=60.0):
         dist.all_reduce(one)
         torch.cuda.synchronize()
         wd.cancel()
-        if int(one.item()) != world:
-            raise SystemExit("[bench] preflight FAILED on rank %d: the 8-byte all-reduce returned %r, expected %d" % (rank, one.item(), world))
+        if int(one.item()) != world or dist.get_world_size() != world:
+            raise SystemExit("[bench] preflight FAILED on rank %d: the 8-byte all-reduce returned %r over a communicator of %d ranks, expected %d"
+                             % (rank, one.item(), dist.get_world_size(), world))
     print("[bench] preflight ok: rank %d/%d device %d of %d, %.1f GB free, backend %s%s" % (
         rank, world, local % max(1, ndev), ndev, free / 1e9, backend if world > 1 else "-", " (%d ranks per GPU)" % sharing if sharing > 1 else ""),
         file=sys.stderr, flush=True)
@@ -348,7 +350,14 @@ def worker(args):
 
     # ---- strong scaling leg (N > 1): the SAME total rows as one GPU's shard, split evenly over the ranks
     strong = None
-    if dist is not None and args.scaling in ("strong", "both"):
+    if dist is not None and args.scaling in ("strong", "both") and R // world < STRONG_MIN_ROWS:
+        # fewer rows per rank than the p = 500 Gram kernel of the weak-scaling line takes: another kernel would run, and the leg would
+        # compare kernels, not GPUs -- say so instead of changing kernels silently
+        strong = {"scaling": "strong", "skipped": "rows_per_gpu / N = %d is under the %d rows per launch the metric's kernel needs "
+                                                  "(gram_cyclic_kernel); run with a larger --rows-per-gpu" % (R // world, STRONG_MIN_ROWS)}
+        if rank == 0:
+            print("[bench] strong-scaling leg skipped: " + strong["skipped"], file=sys.stderr, flush=True)
+    elif dist is not None and args.scaling in ("strong", "both"):
         Rs = R // world
         s_el, s_kern, s_comm, _ = timed_steps(X[:Rs], w[:Rs], args.steps, args.warmup)
         s_name, _ = engine.gram_last_kernel()
@@ -389,7 +398,9 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "rccl_ranks": world if backend == "nccl" else 0,
+            # ranks of the COMMUNICATOR whose all-reduce the preflight verified (sum of ones == ranks), not the environment's word for it
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 1) if backend == "nccl" else 0,
+            "comm_ranks": dist.get_world_size() if dist is not None else 1,
             "value_per_gpu": value / world,          # weak scaling: compare with the N = 1 line's value
             "sustained_block": sustained, "second_block": second_block,
             "config": {"workload": "Logistic DLSA config 3 per-GPU row shard: synthetic Gaussian n=%d x p=%d fp64 "

@@ -126,6 +126,18 @@ static inline int gram_dbg_env() {
 #endif
 }
 
+// a block from the stream-ordered pool that goes back on every way out of the scope (the error returns of DLSA_HIP_CHECK included)
+struct PoolBlock {
+    char* p = nullptr;
+    hipStream_t s = nullptr;
+    PoolBlock() = default;
+    PoolBlock(const PoolBlock&) = delete;
+    PoolBlock& operator=(const PoolBlock&) = delete;
+    ~PoolBlock() { release(); }
+    hipError_t alloc(size_t bytes, hipStream_t stream) { release(); s = stream; return hipMallocAsync((void**)&p, bytes, stream); }
+    void release() { if (p) { (void)hipFreeAsync(p, s); p = nullptr; } }
+};
+
 constexpr int kNumXCD = 8;
 constexpr int kNumCU = 256;
 constexpr int kLdsBytes = 160 * 1024;     // LDS per CU (one workgroup may take all of it)

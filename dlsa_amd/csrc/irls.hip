@@ -1113,6 +1113,17 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
     DLSA_REQUIRE(K > 0 && p > 0 && p <= 2048 && ldx >= p, "irls_fit: bad shape K=%d p=%d ldx=%lld", K, p, (long long)ldx);
     DLSA_REQUIRE(max_iter > 0 && tol > 0, "irls_fit: bad tol/max_iter");
     {
+        // the workspace contract holds whichever driver the shapes pick (the lock-step driver allocates from the stream's pool, but a
+        // call that is wrong for one driver must not pass because the cost model chose another)
+        int64_t mx = 0;
+        for (int k = 0; k < K; ++k) mx = std::max(mx, part_offsets_host[k + 1] - part_offsets_host[k]);
+        const size_t need = align_up(irls_layout(mx, p, dense_pass_bytes(mx, p)).total, 256);
+        if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) {
+            set_error("irls_fit: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
+            return DLSA_ERR_WORKSPACE;
+        }
+    }
+    {
         std::vector<int64_t> rows((size_t)K);
         bool mono = true;
         for (int k = 0; k < K; ++k) { rows[(size_t)k] = part_offsets_host[k + 1] - part_offsets_host[k]; mono &= rows[(size_t)k] >= 0; }

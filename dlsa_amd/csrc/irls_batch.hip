@@ -134,12 +134,13 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
     }
 }
 
-// between the subsample phase and the full-row phase: everybody is live again, the safeguard's memory is cleared (another objective)
+// between the subsample phase and the full-row phase: everybody is live again, the safeguard's memory is cleared (another objective),
+// and the iteration count starts over -- max_iter and n_iter mean full-row iterations, as on the chained path (its it_sub is dropped too)
 __global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __restrict__ active) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     BatchState s = st[k];
-    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0;
+    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0; s.iters = 0;
     st[k] = s;
     active[k] = 1;
 }

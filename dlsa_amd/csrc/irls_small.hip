@@ -472,13 +472,14 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
     int64_t nmax = 0;
     for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
     int C = small_cluster_count(K, nmax);
-    char* pool = nullptr;
+    PoolBlock blk;                 // (released on every return below, the error ones too)
     for (int attempt = 0; attempt < 2; ++attempt) {
         a.C = C; a.scratch = nullptr; a.bcast = nullptr; a.bar = nullptr; a.bar_abort = nullptr; a.bar_timeout = g_small_cluster_timeout_ticks.load();
         if (C > 1) {
             const size_t b_scr = align_up((size_t)K * C * SM_SLOT * sizeof(double), 256), b_bc = align_up((size_t)K * SM_BSLOT * sizeof(double), 256),
                          b_bar = align_up(((size_t)K * 16 + 16) * sizeof(unsigned), 256);
-            DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, b_scr + b_bc + b_bar, s));
+            DLSA_HIP_CHECK(blk.alloc(b_scr + b_bc + b_bar, s));
+            char* pool = blk.p;
             a.scratch = (double*)pool; a.bcast = (double*)(pool + b_scr); a.bar = (unsigned*)(pool + b_scr + b_bc); a.bar_abort = a.bar + (size_t)K * 16;
             DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, b_bar, s));
         }
@@ -500,8 +501,7 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
         unsigned aborted = 0;
         DLSA_HIP_CHECK(hipMemcpyAsync(&aborted, a.bar_abort, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
-        DLSA_HIP_CHECK(hipFreeAsync(pool, s));
-        pool = nullptr;
+        blk.release();
         if (!aborted) break;
         g_small_cluster_aborts.fetch_add(1);
         C = 1;

@@ -1011,7 +1011,7 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.bar_timeout = g_lars_barrier_timeout_ticks.load();
     int steps = 0, wgs_used = 1;
     if (lars_q_eligible(p, intercept)) {
-        // up to 510 variables: the carried Cholesky rows (lars_q.hip) -- one workgroup, or a few that share the fused pass and meet
+        // up to 1020 variables: the carried Cholesky rows (lars_q.hip) -- one workgroup, or a few that share the fused pass and meet
         // at a bounded grid barrier (a launch that gave up there is rerun on one workgroup).  Every entry of its matrices is written
         // before it is read, so nothing is cleared.
         for (int attempt = 0; attempt < 2; ++attempt) {

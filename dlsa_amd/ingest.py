@@ -40,22 +40,30 @@ def read_csv_frame(path, usecols_x, Y_name, dummy_columns=(), binarize=True, nro
         # dictionary types AT READ TIME: the parser builds the dictionaries block by block on its threads (3e6 rows x 6 columns here:
         # 1.9 s against 4.3 s for read + dictionary_encode, 8.6 s for pandas' parser with exact float conversion)
         types = {c: (pa.dictionary(pa.int32(), pa.string()) if c in dummy_columns else pa.float64()) for c in cols}
-        # the SAME missing-value spellings as the pandas branch (and Spark's dropna of the reference, which drops null AND NaN): pandas
-        # reads all of _NA_VALUES as missing in every column, numeric or string
+        # Missing values as the reference's reader sees them (spark.read.csv with an explicit schema, logistic_dlsa.py:218-237, then
+        # dropna()): a NUMERIC field that does not parse is null whatever its spelling ("NA", "NULL", "nan", ...), but in a STRING
+        # (factor) column only the empty field is null -- "NA" or "None" there is a level like any other, and its rows stay.  Arrow's
+        # null spellings are global, so string columns are read with strings_can_be_null = False and their empty fields dropped below.
         tab = pacsv.read_csv(path, convert_options=pacsv.ConvertOptions(include_columns=cols, column_types=types,
-                                                                          null_values=list(_NA_VALUES), strings_can_be_null=True))
+                                                                          null_values=list(_NA_VALUES), strings_can_be_null=False))
         pdf = tab.drop_null().unify_dictionaries().to_pandas()   # dictionary columns -> pandas category, doubles stay columnar
         # a NaN that reached a double column through another spelling ("NAN", "+nan") is a value to Arrow, a missing one to dropna()
         ok = None
         for c in cols:
             if c not in dummy_columns:
                 m = ~np.isnan(pdf[c].to_numpy(dtype=np.float64))
-                ok = m if ok is None else (ok & m)
+            else:
+                m = (pdf[c].astype(object) != "").to_numpy()
+            ok = m if ok is None else (ok & m)
         if ok is not None and not ok.all():
             pdf = pdf[ok].reset_index(drop=True)
+            for c in dummy_columns:
+                if c in pdf.columns and hasattr(pdf[c], "cat"):
+                    pdf[c] = pdf[c].cat.remove_unused_categories()
     else:
         dtypes = {c: "str" for c in dummy_columns}
-        pdf = pd.read_csv(path, usecols=cols, dtype=dtypes, nrows=nrows, engine="c", na_values=list(_NA_VALUES), float_precision="round_trip")
+        na = {c: ([""] if c in dummy_columns else list(_NA_VALUES)) for c in cols}          # (per column: see the Arrow branch)
+        pdf = pd.read_csv(path, usecols=cols, dtype=dtypes, nrows=nrows, engine="c", na_values=na, keep_default_na=False, float_precision="round_trip")
         pdf = pdf.dropna().reset_index(drop=True)
         for c in usecols_x:
             if c not in dummy_columns:
@@ -65,7 +73,8 @@ def read_csv_frame(path, usecols_x, Y_name, dummy_columns=(), binarize=True, nro
     return pdf[cols]
 
 
-# what pandas.read_csv treats as missing by default (keep_default_na) + "NA" -- passed to both readers so that the rows that reach
+# what pandas.read_csv treats as missing by default (keep_default_na) + "NA" -- the spellings of a missing NUMERIC field, passed to
+# both readers (a factor column's only missing value is the empty field) so that the rows that reach
 # the fit, hence n, K = ceil(n / 1e6) and the dummy counts, do not depend on which reader is installed
 _NA_VALUES = ("", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA", "NULL",
               "NaN", "None", "n/a", "nan", "null")

@@ -270,12 +270,14 @@ int dlsa_sym_pinv_solve_f64(const double* S, int64_t lds, const double* v, int p
  * Sigma0 p x p, b0 p (device).  type 0 = 'lar', 1 = 'lasso'.  max_steps <= 0 -> 8*m.
  * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
  * aic, bic (max_steps+1 each); n_steps_host = number of steps taken (path has n_steps+1
- * rows).  Runs as one persistent kernel on the device: a single workgroup for p < 256, a
- * grid of 4..32 workgroups (two grid barriers per step) above.  The grid kernel is a PLAIN
- * launch whose hand-rolled barrier needs its workgroups resident together: its launches are
- * serialised inside a process, every barrier wait is bounded (2 s), and a launch that gives
- * up (CUs held by other work: another process on the GPU, a CU-masked device) is rerun on
- * the single-workgroup kernel -- slower, same path; DLSA_ERR_HIP only if that is impossible.
+ * rows).  Runs as one persistent kernel on the device.  Up to 1020 variables the carried-rows
+ * form (lars_q.hip): one workgroup up to 200 variables, 4 (beyond 420: 8) workgroups that share
+ * the fused pass above; beyond 1020 a grid of up to 32 workgroups (lars.hip, two grid barriers
+ * per step).  The multi-workgroup kernels need their workgroups resident together: they are
+ * launched cooperatively (hipLaunchCooperativeKernel: co-residency or a clean launch error),
+ * as a plain launch only where that is refused; their launches are serialised inside a
+ * process, every barrier wait is bounded, and a launch that gives up is rerun on a single
+ * workgroup -- slower, same path; DLSA_ERR_HIP only if that is impossible.
  * p is bounded by the LDS per workgroup: about 2400 columns for the grid kernel, 3300 for
  * the single workgroup it falls back to. */
 size_t dlsa_lars_workspace_bytes(int p);
