@@ -3,7 +3,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlsa_amd import engine
-for (rows, p) in [(20_000_000, 50), (10_000_000, 100), (10_000_000, 128), (10_000_000, 250), (25_000_000, 500), (5_000_000, 1000), (5_000_000, 2000)]:
+shapes = [(20_000_000, 50), (10_000_000, 100), (10_000_000, 128), (10_000_000, 250), (25_000_000, 500), (5_000_000, 1000), (5_000_000, 2000)]
+if len(sys.argv) > 2:
+    shapes = [(int(float(sys.argv[1])), int(sys.argv[2]))]          # one shape: logit_quick.py rows p
+for (rows, p) in shapes:
     X, y = engine.synth(1, 0, rows, p, kind=engine.SYNTH_GAUSSIAN)
     beta = torch.zeros(p, dtype=torch.float64, device="cuda"); beta[: int(0.4 * p)] = 1.0
     engine.logit_pass(X, y, beta); torch.cuda.synchronize()

@@ -14,8 +14,9 @@
 //        and its status and leaves the active set; its slabs return at once in later passes.
 //   One 4-byte read-back per iteration (the number of live partitions).
 // Every partition starts from beta = 0 (no warm start from its neighbour: that is what lock step gives up); the MLE and the Hessian at
-// it are those of the host-driven path to the solver tolerance.  Shapes: what the fused pass and the one-launch inverse take (even
-// 50 <= p <= 112, aligned rows, no implicit intercept, contiguous partitions); chosen by a cost model against the chained path.
+// it are those of the host-driven path to the solver tolerance.  Shapes: what the fused pass and the one-launch inverse take (49 <= p
+// + intercept <= 112; aligned rows of even width, or packed rows of odd width without the intercept; contiguous or i % K strided
+// partitions); chosen by a cost model against the chained path.
 // Scratch beyond the caller's workspace comes from the stream-ordered pool and is freed before the call returns.
 #include "common.h"
 #include "options.h"
@@ -29,7 +30,7 @@ namespace dlsa {
 int irls_pass_batched_pp(int p);
 int irls_pass_batched_gp(int p);
 int irls_pass_batched_ll_at(int p);
-bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept);
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept, int64_t base_ldx);
 int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
                              unsigned long long* clk, hipStream_t stream);
@@ -154,7 +155,7 @@ bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const 
     const int pe = p + (intercept ? 1 : 0);
     // strided partitions (partition_id = i % K, models.py:33: rows first, first + step, ...): the row pitch is ldx * step, and a slab of
     // at least 2048 rows must stay inside the 32-bit DMA offsets
-    if (row_step < 1 || K < 2 || !irls_pass_batched_shape_ok(X, ldx * row_step, y, p, intercept) || !chol_small_ok(pe)) return false;
+    if (row_step < 1 || K < 2 || !irls_pass_batched_shape_ok(X, ldx * row_step, y, p, intercept, ldx) || !chol_small_ok(pe)) return false;
     if ((double)(2048 + 8 * 32) * (double)ldx * (double)row_step * 8.0 >= 2.0e9) return false;
     int64_t total = 0, mn = INT64_MAX;
     for (int k = 0; k < K; ++k) { total += rows_host[k]; mn = std::min(mn, rows_host[k]); }

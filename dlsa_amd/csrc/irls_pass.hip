@@ -840,13 +840,26 @@ static int fp_slabs(int64_t n, int64_t& rows_per_slab, int wgs_per_cu = 1) {
 
 static size_t fp_pp(int p) { return ((size_t)(p + 15) / 16 * 16 + 63) / 64 * 64; }
 
+// Rows the 16-byte DMA pieces may stream.  Even p: rows of even pitch from a 16-byte aligned base (every piece aligned, none leaves its
+// row).  ODD p (round 5; dummy-encoded widths are arbitrary, models.py:56-104): the piece of the row's last column also carries the
+// 8 bytes behind it -- harmless when those are DATA: a packed matrix (ldx == p), where they are the next row's first element (finite
+// whenever the data is; beta is zero there, and H's column p is never written out) or, behind the slab's last row, out of the
+// descriptor's range (zero).  A padded odd-width row would put the caller's padding bytes there (possibly NaN): not served.  The
+// pieces of such rows sit at 8-byte offsets, which the LDS-DMA takes (bench: p = 99, 101, 111 exact against the oracle).
+static bool fp_rows_ok(const double* X, int64_t ldx, int p, int64_t base_ldx = 0) {
+    // (base_ldx: the matrix's own row pitch when `ldx` is the pitch of a strided VIEW of it -- rows k, k + K, ...: the bytes behind a
+    // row of the view are the next row of the matrix)
+    if (p & 1) return (base_ldx ? base_ldx : ldx) == p && ((uintptr_t)X % 8) == 0;
+    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0;
+}
+
 bool irls_pass_fused_eligible(const double* X, int64_t ldx, const double* y, int64_t n, int p) {
-    if (p < FP_MIN_P || p > FP_MAX_P || (p & 1) || n < FP_MIN_ROWS) return false;
+    if (p < FP_MIN_P || p > FP_MAX_P || n < FP_MIN_ROWS) return false;
     const char* e = knob("DLSA_IRLS_FUSED");
     if (e && atoi(e) == 0) return false;          // A/B runs: the two-launch form
     int64_t rps;
     fp_slabs(n, rps);
-    return ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0 &&          // (the y pieces are dword-aligned buffer loads)
+    return fp_rows_ok(X, ldx, p) && ((uintptr_t)y % 8) == 0 &&          // (the y pieces are dword-aligned buffer loads)
            (double)(rps + 8 * FP_KC) * (double)ldx * 8.0 < 2.0e9;                    // 32-bit DMA offsets
 }
 
@@ -1028,9 +1041,11 @@ int irls_pass_batched_ll_at(int p) {
     return 16 * (nt + (gt > 0 ? 1 : 0));
 }
 // (p = data columns; with the implicit intercept the kernel's shape is that of p + 1 columns, the PP / GP / ll_at queries take p + 1)
-bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept) {
+bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept, int64_t base_ldx) {
     const int pe = p + (intercept ? 1 : 0);
-    return pe >= FP_MIN_P && pe <= FP_MAX_P && !(p & 1) && ldx % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)y % 8) == 0;
+    // (the implicit intercept's ones column is column p of a stage, which the DMA must never write: even p only)
+    if (intercept && (p & 1)) return false;
+    return pe >= FP_MIN_P && pe <= FP_MAX_P && fp_rows_ok(X, ldx, p, base_ldx) && ((uintptr_t)y % 8) == 0;
 }
 int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,

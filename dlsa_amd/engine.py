@@ -119,10 +119,13 @@ def rows_to_device(a, device="cuda"):
 def empty_rows(n, p, dtype=torch.float64, device="cuda"):
     """[n, p] row-major matrix whose row pitch is a whole number of 16-byte units (an odd fp64 p gets one pad
     element per row, zeroed): the Gram kernels stage such rows with vector loads / the LDS-DMA for any p, whereas
-    rows that start at odd multiples of 8 bytes take the scalar staging path (p=501: 28.8 vs 20.6 ms per 5e6 rows)."""
+    rows that start at odd multiples of 8 bytes take the scalar staging path (p=501: 28.8 vs 20.6 ms per 5e6 rows).
+    Exception (round 5): an odd fp64 width of the fused Newton pass's class (49 .. 120) stays PACKED -- that kernel streams packed
+    odd rows (the piece of a row's last column carries the next row's first element: data, where a pad element would be bytes the
+    library cannot vouch for), and a fit at these widths takes every Hessian from it."""
     unit = 16 // torch.empty((), dtype=dtype).element_size()
     ld = (p + unit - 1) // unit * unit
-    if ld == p:
+    if ld == p or (dtype == torch.float64 and (p & 1) and 49 <= p <= 120):
         return torch.empty((n, p), dtype=dtype, device=device)
     buf = torch.empty((n, ld), dtype=dtype, device=device)
     buf[:, p:] = 0

@@ -28,7 +28,9 @@ def orc():
 
 @pytest.mark.parametrize("p,sizes", [(64, [3000, 70000, 5000, 24577, 4100, 33000, 2500, 9000, 3100, 12000]),
                                      (100, [20000] * 12 + [50001, 2000]),
-                                     (50, [2048, 4096, 100000, 3000, 7000, 2100, 2200, 2300])])
+                                     (50, [2048, 4096, 100000, 3000, 7000, 2100, 2200, 2300]),
+                                     (99, [20000] * 9 + [33001]), (101, [9000, 30000, 12000, 8192, 15000, 21000, 9100, 9200]),
+                                     (111, [10000] * 8), (51, [4000, 9000, 70000, 3000, 5000, 2500, 2600, 2700])])
 def test_lock_step_fit_equals_chained_fit_and_oracle(eng, orc, p, sizes):
     n, K = sum(sizes), len(sizes)
     X, y = eng.synth(4242 + p, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
@@ -68,9 +70,13 @@ def test_lock_step_is_chosen_for_many_small_partitions_only(eng):
         assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and r["status"] == [0] * 64
     r = eng.irls_fit(X, y, [0, 96000, 192000])                    # two large partitions: the chained path
     assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS and r["status"] == [0, 0]
-    Xo, yo = eng.synth(8, 0, 40000, 63, kind=eng.SYNTH_GAUSSIAN)          # odd width: not the fused class
+    Xo, yo = eng.synth(8, 0, 40000, 40, kind=eng.SYNTH_GAUSSIAN)          # too narrow: not the fused class
     with eng.irls_options(batched=True, small=False):
         eng.irls_fit(Xo, yo, [4000 * k for k in range(11)])
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS
+    Xp = eng.synth(9, 0, 40000, 64, kind=eng.SYNTH_GAUSSIAN)[0][:, :63]   # odd width in PADDED rows (pitch 64): the bytes behind a row are not data
+    with eng.irls_options(batched=True, small=False):
+        eng.irls_fit(Xp, yo, [4000 * k for k in range(11)])
         assert eng.irls_last_fit_path() == eng.IRLS_PATH_CHAINS
 
 
@@ -111,3 +117,29 @@ def test_lock_step_with_intercept_and_strided_partitions(eng, orc, p, K, n, icpt
     assert rel_inf(b.Sig_invMcoef[k].cpu().numpy(), smc) < 1e-10
     out = dlsa_amd.dlsa_mapred(b)                                   # and the reduce takes the blocks as they are
     assert list(out.columns[:2]) == ["beta_byOLS", "beta_byONESHOT"] and out.shape == (p + int(icpt), 2 + p + int(icpt))
+
+
+def test_max_iter_means_full_row_iterations_on_every_driver(eng):
+    """the lock-step driver counted its subsample phase against the caller's max_iter and reported it in n_iter; the
+    chained driver counts full-row iterations only.  Partitions long enough for the subsample phase, a small max_iter that the
+    full-row phase just meets: the same status on both drivers, and n_iter of the same meaning (full-row iterations)."""
+    p, sizes = 80, [40000] * 10
+    n, K = sum(sizes), len(sizes)
+    X, y = eng.synth(77, 0, n, p, kind=eng.SYNTH_GAUSSIAN)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    with eng.irls_options(batched=True, small=False):
+        ref = eng.irls_fit(X, y, offs)                  # generous max_iter: how many full-row iterations the lock step needs
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and ref["status"] == [0] * K
+    need = max(ref["n_iter"])
+    assert need <= 8, ref["n_iter"]                     # (full-row iterations only: the subsample phase took the first ones)
+    with eng.irls_options(batched=True, small=False):
+        b = eng.irls_fit(X, y, offs, max_iter=need)
+    assert b["status"] == [0] * K and max(b["n_iter"]) <= need      # (before: the subsample phase's iterations used the budget up)
+    with eng.irls_options(batched=True, small=False):
+        b12 = eng.irls_fit(X, y, offs, max_iter=12)
+    with eng.irls_options(batched=False, small=False):
+        c12 = eng.irls_fit(X, y, offs, max_iter=12)       # (the chains take more, cheaper iterations: reused factors contract linearly)
+    assert b12["status"] == c12["status"] == [0] * K
+    with eng.irls_options(batched=True, small=False):
+        short = eng.irls_fit(X, y, offs, max_iter=1)     # one full-row iteration cannot converge: NOT_CONVERGED on every partition, n_iter = 1
+    assert all(s != 0 for s in short["status"]) and short["n_iter"] == [1] * K

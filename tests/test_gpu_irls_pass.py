@@ -31,9 +31,11 @@ def dev(a):
 
 
 # NT = 3..7 full tiles x G = 0..3 tail groups; ragged row counts (not a multiple of the 32-row chunk, of the slab)
+# (round 5: odd widths too -- packed rows at 8-byte offsets, the piece of a row's last column carries the next row's first element)
 @pytest.mark.parametrize("p,n", [(50, 8192), (52, 9001), (56, 10000), (60, 12345), (64, 8200), (66, 20000), (72, 15000), (76, 9999),
                                  (80, 30011), (84, 8192), (88, 17000), (92, 8193), (96, 40000), (100, 60000), (104, 25001),
-                                 (108, 33333), (112, 50001), (116, 20000), (120, 30001)])
+                                 (108, 33333), (112, 50001), (116, 20000), (120, 30001),
+                                 (49, 9000), (51, 8192), (63, 10001), (65, 20000), (81, 12000), (99, 60000), (101, 20001), (111, 50000), (119, 9999)])
 def test_fused_pass_matches_oracle(eng, orc, p, n):
     X, y = orc.synth_logistic(300 + p, 0, n, p, orc.SYNTH_GAUSSIAN)
     rng = np.random.default_rng(p)
@@ -71,7 +73,7 @@ def test_fused_pass_equals_two_launch_form_and_extreme_eta(eng, monkeypatch):
 
 
 def test_other_shapes_take_the_two_launches(eng, orc):
-    for p, n in ((30, 9000), (101, 20000), (200, 9000), (100, 5000), (122, 20000)):   # too narrow, odd, too wide, too few rows, 7 tiles + 3 groups
+    for p, n in ((30, 9000), (48, 20000), (200, 9000), (100, 5000), (122, 20000)):   # too narrow (twice), too wide, too few rows, 7 tiles + 3 groups
         X, y = orc.synth_logistic(p, 0, n, p)
         beta = orc.true_beta(p) * 0.5
         H, g, ll, w = eng.irls_pass(dev(X), dev(y), dev(beta), want_w=True)
