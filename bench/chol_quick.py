@@ -7,6 +7,7 @@ from dlsa_amd import _lib
 if len(sys.argv) > 2:
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from dlsa_amd import engine
+_ko = engine.kernel_options(engine.kernel_options_from_env()); _ko.__enter__()      # DLSA_GRAM_DBG etc. from the shell: applied by the host layer (the library reads no environment variable for them)
 p = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = 20000
 X, y = engine.synth(1, 0, n, p, kind=engine.SYNTH_GAUSSIAN)

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlsa_amd import engine
+_ko = engine.kernel_options(engine.kernel_options_from_env()); _ko.__enter__()      # DLSA_GRAM_DBG etc. from the shell: applied by the host layer (the library reads no environment variable for them)
 
 rows, p, ld, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 Xf, _ = engine.synth(1, 0, rows, ld, kind=engine.SYNTH_GAUSSIAN, labels=False)

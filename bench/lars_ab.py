@@ -15,13 +15,13 @@ for p in [int(v) for v in sys.argv[1:]] or [50, 100, 260]:
     b = torch.from_numpy(np.where(np.arange(p) < 0.4 * p, 1.0, 0.0) + 0.05 * rng.standard_normal(p)).cuda()
     out = []
     for q in ("0", "1"):
-        os.environ["DLSA_LARS_Q"] = q
-        for typ in ("lar", "lasso"):
-            engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
-            reps = []
-            for _ in range(9):
-                t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
-                reps.append((time.perf_counter() - t) * 1e3)
-            reps.sort()
-            out.append("Q=%s %s %.3f / %.3f ms (%d steps)" % (q, typ, reps[0], reps[len(reps) // 2], r["beta"].shape[0] - 1))
+        with engine.kernel_options(lars_q=int(q)):
+            for typ in ("lar", "lasso"):
+                engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
+                reps = []
+                for _ in range(9):
+                    t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n), type=typ); torch.cuda.synchronize()
+                    reps.append((time.perf_counter() - t) * 1e3)
+                reps.sort()
+                out.append("Q=%s %s %.3f / %.3f ms (%d steps)" % (q, typ, reps[0], reps[len(reps) // 2], r["beta"].shape[0] - 1))
     print("p=%d: " % p + "  ".join(out), flush=True)

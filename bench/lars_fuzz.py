@@ -25,10 +25,9 @@ def problem(p, rho, seed):
 
 
 def run(S, b, intercept, n, typ, env):
-    for k in ("DLSA_LARS_Q", "DLSA_LARS_Q_THREADS", "DLSA_LARS_Q_LDS", "DLSA_LARS_Q_WGS"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    r = engine.lars_path(torch.from_numpy(S).cuda(), torch.from_numpy(b).cuda(), intercept, float(n), type=typ)
+    # (the switches go through dlsa_kernel_options: the library reads no environment variable for them)
+    with engine.kernel_options(engine.kernel_options_from_env(env)):
+        r = engine.lars_path(torch.from_numpy(S).cuda(), torch.from_numpy(b).cuda(), intercept, float(n), type=typ)
     return {k: r[k].cpu().numpy() for k in ("beta", "beta0", "AIC", "BIC")}
 
 

@@ -11,12 +11,12 @@ S = torch.from_numpy(X.T @ ((rng.random(n) * 0.25)[:, None] * X)).cuda()
 b = torch.from_numpy(np.where(np.arange(p) < 0.4 * p, 1.0, 0.0) + 0.05 * rng.standard_normal(p)).cuda()
 ref = None
 for w in sys.argv[2:]:
-    os.environ["DLSA_LARS_WGS"] = w
-    engine.lars_path(S, b, False, float(n)); torch.cuda.synchronize()
-    ts = []
-    for _ in range(3):
-        t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n)); torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t) * 1e3)
+    with engine.kernel_options(lars_wgs=int(w), lars_q=0):
+        engine.lars_path(S, b, False, float(n)); torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); r = engine.lars_path(S, b, False, float(n)); torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
     beta = r["beta"].cpu().numpy()
     if ref is None: ref = beta
     print("p=%d wgs=%s: %.2f ms (%d steps) max|beta - first| %.2e" % (p, w, min(ts), beta.shape[0] - 1, np.abs(beta - ref).max() if beta.shape == ref.shape else -1))

@@ -28,7 +28,7 @@ def timed(fn, reps=5):
     return sorted(ts)[len(ts) // 2], out
 
 for mode in ("1", "0", "1", "0"):
-    os.environ["DLSA_OH_ORDERED"] = mode
+  with engine.kernel_options(onehot_ordered=int(mode)):
     tl, (w, gvec, ll) = timed(lambda: engine.onehot_logit_pass(plan, num, codes, y, beta))
     tg, H = timed(lambda: engine.onehot_gram(plan, num, codes, w))
     same_g = all(torch.equal(gvec, engine.onehot_logit_pass(plan, num, codes, y, beta)[1]) for _ in range(4))

@@ -23,11 +23,19 @@ class IrlsOptionsC(ctypes.Structure):
                                      "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace", "lean", "small_cluster", "own_hessian")] + [("freeze_at", c_dbl)]
 
 
+class KernelOptionsC(ctypes.Structure):
+    """include/dlsa_hip.h: dlsa_kernel_options (field for field)"""
+    _fields_ = [(n, c_int) for n in ("struct_bytes", "lars_q", "lars_q_wgs", "lars_q_threads", "lars_q_lds", "lars_wgs", "lars_threads", "logit_ring",
+                                     "chol_small", "gram_wide_f32", "onehot_ordered", "gram_variant", "cooperative")]
+
+
 SIGNATURES = {
     "dlsa_version": (c_int, []),
     "dlsa_irls_last_fit_path": (c_int, []),
     "dlsa_irls_options_init": (None, [ctypes.POINTER(IrlsOptionsC)]),
     "dlsa_irls_set_options": (c_int, [ctypes.POINTER(IrlsOptionsC)]),
+    "dlsa_kernel_options_init": (None, [ctypes.POINTER(KernelOptionsC)]),
+    "dlsa_kernel_set_options": (c_int, [ctypes.POINTER(KernelOptionsC)]),
     "dlsa_last_error": (c_int, [ctypes.c_char_p, c_int]),
     "dlsa_synth_f64": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dlsa_synth_f32": (c_int, [c_u64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void spd_inverse_small_kernel(const double* __
 }
 
 bool chol_small_ok(int p) {
-    const char* e = getenv("DLSA_CHOL_SMALL");           // 0: always the blocked path (A/B runs)
+    const char* e = kernel_knob("DLSA_CHOL_SMALL");           // 0: always the blocked path (A/B runs)
     return p <= CS_MAXP && (!e || atoi(e) != 0);
 }
 

@@ -116,8 +116,9 @@ __device__ __forceinline__ double wave_allreduce_min(double s) { return wave_all
 #define DLSA_DBG_WRONG(mask, bit) 0
 #endif
 constexpr int kGramDbgValidBits = 2 | 4 | 8 | 32 | 64 | 256;
+const char* kernel_knob(const char* env_name);      // options.cpp: dlsa_kernel_options (the environment only in DLSA_DEBUG_KNOBS builds)
 static inline int gram_dbg_env() {
-    const char* e = getenv("DLSA_GRAM_DBG");
+    const char* e = kernel_knob("DLSA_GRAM_DBG");
     const int v = e ? atoi(e) : 0;
 #ifdef DLSA_DEBUG_KNOBS
     return v;

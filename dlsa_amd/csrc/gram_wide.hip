@@ -527,7 +527,7 @@ bool gram_wide_f32_shape_ok(int64_t n, int p) {
 }
 
 bool gram_wide_f32_eligible(const float* X, int64_t ldx, const float* w, int64_t n, int p) {
-    if (getenv("DLSA_GRAM_NOWIDE")) return false;
+    { const char* e = kernel_knob("DLSA_GRAM_WIDE_F32"); if (e && atoi(e) == 0) return false; }      // dlsa_kernel_options.gram_wide_f32 = 0: the panel kernel (A/B runs, tests)
     if (!gram_wide_f32_shape_ok(n, p) || (ldx % 4) || ((uintptr_t)X & 15) || (w && ((uintptr_t)w & 15))) return false;
     int nslab; int64_t rps;
     choose_wide_slabs(n, p, wide_counts(p).second, nslab, rps);

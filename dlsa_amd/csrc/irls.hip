@@ -1029,9 +1029,11 @@ static int irls_fit_core(const IrlsMakeData& make_data, const std::function<size
         }
         std::vector<std::thread> workers;
         const dlsa_irls_options caller_opt = irls_options_snapshot();      // the chains' threads run under the caller's options
+        const dlsa_kernel_options caller_kopt = kernel_options_snapshot();
         for (int c = 1; c < S; ++c)
             workers.emplace_back([&, c]() {
                 irls_options_adopt(caller_opt);
+                kernel_options_adopt(caller_kopt);
                 IrlsChain& cs = chains[(size_t)c];
                 if (hipSetDevice(dev) != hipSuccess) { cs.rc = DLSA_ERR_HIP; cs.err = "hipSetDevice failed in a chain thread"; return; }
                 cs.rc = run_chain(c, st[(size_t)c]);

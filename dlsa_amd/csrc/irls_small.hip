@@ -403,7 +403,7 @@ __global__ __launch_bounds__(SM_THREADS) void irls_small_kernel(SmallArgs a) {
 
 std::atomic<int> g_small_cluster_aborts{0};
 std::mutex g_small_cluster_mu;                                         // serialises this process's clustered launches (launch .. completion)
-std::atomic<long long> g_small_cluster_timeout_ticks{200000000ll};      // 2 s of the 100 MHz wall clock
+std::atomic<long long> g_small_cluster_timeout_ticks{25000000ll};       // 0.25 s of the 100 MHz wall clock (a barrier wait is microseconds; cooperative launches cannot miss co-residency)
 
 // Workgroups per partition: as many as leave every CU at most one, while a workgroup keeps >= 512 rows (below that the two cluster
 // barriers and the partial sums cost what the shorter pass saves).  DLSA_IRLS_SMALL_CLUSTER = C forces it (1 .. 16).
@@ -488,11 +488,18 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
         std::unique_lock<std::mutex> cluster_lock(g_small_cluster_mu, std::defer_lock);
         if (C > 1) cluster_lock.lock();
         const dim3 grid((unsigned)(K * C));
-        switch (nt) {
-            case 1: hipLaunchKernelGGL(irls_small_kernel<1>, grid, dim3(SM_THREADS), 0, s, a); break;
-            case 2: hipLaunchKernelGGL(irls_small_kernel<2>, grid, dim3(SM_THREADS), 0, s, a); break;
-            case 3: hipLaunchKernelGGL(irls_small_kernel<3>, grid, dim3(SM_THREADS), 0, s, a); break;
-            default: hipLaunchKernelGGL(irls_small_kernel<4>, grid, dim3(SM_THREADS), 0, s, a); break;
+        // clusters meet at device barriers: the plain launch with its bounded barrier (rerun on one workgroup per partition when a wait
+        // times out), or -- dlsa_kernel_options.cooperative = 1 -- a cooperative launch (every workgroup resident, or a clean refusal)
+        const void* fn = nt == 1 ? (const void*)irls_small_kernel<1> : nt == 2 ? (const void*)irls_small_kernel<2> :
+                         nt == 3 ? (const void*)irls_small_kernel<3> : (const void*)irls_small_kernel<4>;
+        void* kargs[] = {(void*)&a};
+        if (C == 1 || launch_cooperative(fn, grid, dim3(SM_THREADS), kargs, 0, s) != hipSuccess) {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(irls_small_kernel<1>, grid, dim3(SM_THREADS), 0, s, a); break;
+                case 2: hipLaunchKernelGGL(irls_small_kernel<2>, grid, dim3(SM_THREADS), 0, s, a); break;
+                case 3: hipLaunchKernelGGL(irls_small_kernel<3>, grid, dim3(SM_THREADS), 0, s, a); break;
+                default: hipLaunchKernelGGL(irls_small_kernel<4>, grid, dim3(SM_THREADS), 0, s, a); break;
+            }
         }
         DLSA_HIP_CHECK(hipGetLastError());
         if (C == 1) break;
@@ -532,10 +539,10 @@ int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t*
 extern "C" {
 
 // Test / diagnostics hook for the bounded cluster barrier of irls_small_kernel (no reference counterpart: the reference fits its
-// partitions in Spark tasks, dlsa/models.py:110-131): sets the barrier timeout in seconds (<= 0 restores the 2 s default) and
+// partitions in Spark tasks, dlsa/models.py:110-131): sets the barrier timeout in seconds (<= 0 restores the 0.25 s default) and
 // returns how many clustered launches of this process have been given up and rerun with one workgroup per partition.
 int dlsa_irls_small_cluster_timeout(double seconds) {
-    dlsa::g_small_cluster_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 200000000ll);
+    dlsa::g_small_cluster_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 25000000ll);
     return dlsa::g_small_cluster_aborts.load();
 }
 

@@ -22,6 +22,7 @@
 //     set is unique.
 #include "common.h"
 #include "lars.h"
+#include "options.h"
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -34,7 +35,7 @@ namespace dlsa {
 constexpr int LARS_MAX_WGS = 32;               // workgroups of the grid kernel (the barrier costs ~35 ns per workgroup beyond 16)
 #ifndef DLSA_LARS_SECONDARY
 std::mutex g_lars_grid_mu;                                     // serialises this process's grid-kernel launches (dlsa_lars_lsa_f64)
-std::atomic<long long> g_lars_barrier_timeout_ticks{200000000ll};   // 2 s of the 100 MHz wall clock
+std::atomic<long long> g_lars_barrier_timeout_ticks{25000000ll};    // 0.25 s of the 100 MHz wall clock (a barrier wait is microseconds)
 std::atomic<int> g_lars_grid_aborts{0};
 #endif
 
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
 // 4.0 vs 2.6 ms at p=200).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
 static int lars_workgroups(int p) {
     int wgs = p < 256 ? 1 : (p < 384 ? (LARS_THREADS == 512 ? 8 : 4) : (p < 768 ? 8 : (p < 1536 ? 16 : 32)));   // (512-thread build, p = 260: 3.78 ms at 4, 3.59 at 8)
-    if (const char* e = getenv("DLSA_LARS_WGS")) wgs = atoi(e);
+    if (const char* e = kernel_knob("DLSA_LARS_WGS")) wgs = atoi(e);
     return std::max(1, std::min(wgs, LARS_MAX_WGS));
 }
 
@@ -944,7 +945,10 @@ int lars_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int*
         // costs 15-19 us of host time per call.  What the plain launch cannot promise -- several grid kernels each partly
         // resident and waiting for their queued workgroups -- is covered twice: grid launches of one process are serialised
         // (g_lars_grid_mu in dlsa_lars_lsa_f64) and every barrier wait is bounded (grid_barrier: abort + single-workgroup rerun).
-        hipLaunchKernelGGL(lars_grid_kernel, dim3(wgs), dim3(LARS_THREADS), shm, s, a);
+        // (dlsa_kernel_options.cooperative = 1 asks for the cooperative launch all the same)
+        void* kargs[] = {(void*)&a};
+        if (launch_cooperative(reinterpret_cast<const void*>(lars_grid_kernel), dim3(wgs), dim3(LARS_THREADS), kargs, shm, s) != hipSuccess)
+            hipLaunchKernelGGL(lars_grid_kernel, dim3(wgs), dim3(LARS_THREADS), shm, s, a);
         DLSA_HIP_CHECK(hipGetLastError());
     } else {
         const size_t shm = (size_t)LARS_THREADS * 16 + mm * 44 + 64;
@@ -1005,9 +1009,9 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     a.beta_path = beta_path; a.beta0 = beta0; a.aic = aic; a.bic = bic;
     // 512-thread workgroups up to p = 768, 1024-thread ones beyond (DLSA_LARS_THREADS=512|1024 forces a build)
     bool small_wg = p <= 768;
-    if (const char* e = getenv("DLSA_LARS_THREADS")) small_wg = atoi(e) == 512;
+    if (const char* e = kernel_knob("DLSA_LARS_THREADS")) small_wg = atoi(e) == 512;
     // ticks of the 100 MHz wall clock a workgroup of the grid kernel waits at one grid barrier (normally microseconds) before it
-    // gives the launch up: 2 s
+    // gives the launch up: 0.25 s
     a.bar_timeout = g_lars_barrier_timeout_ticks.load();
     int steps = 0, wgs_used = 1;
     if (lars_q_eligible(p, intercept)) {
@@ -1059,10 +1063,10 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
 }
 
 // Test / diagnostics hook for the bounded grid barrier of lars_grid_kernel (not a reference entry: the reference's lars_lsa,
-// dlsa/lsa.py:90-212, is host numpy and has no such state): sets the barrier timeout in seconds (<= 0 restores the 2 s default)
+// dlsa/lsa.py:90-212, is host numpy and has no such state): sets the barrier timeout in seconds (<= 0 restores the 0.25 s default)
 // and returns how many grid launches of this process have aborted and been rerun on the single-workgroup kernel.
 int dlsa_lars_grid_barrier_timeout(double seconds) {
-    dlsa::g_lars_barrier_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 200000000ll);
+    dlsa::g_lars_barrier_timeout_ticks.store(seconds > 0.0 ? (long long)(seconds * 1e8) + 1 : 25000000ll);
     return dlsa::g_lars_grid_aborts.load();
 }
 

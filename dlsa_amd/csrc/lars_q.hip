@@ -675,8 +675,11 @@ int launch_q(LarsArgs& a, int m, hipStream_t s, int nwg = 1) {
         DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lars_q_kernel<T, LDSQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     a.nwg = LDSQ ? 1 : nwg;
     if (a.nwg > 1) DLSA_HIP_CHECK(hipMemsetAsync(a.bar, 0, 256, s));
-    // (a plain launch, as lars.hip's grid kernel: co-residency of the few workgroups follows from the idle CUs; the barrier is bounded)
-    hipLaunchKernelGGL((lars_q_kernel<T, LDSQ>), dim3(a.nwg), dim3(T), shm, s, a);
+    // several workgroups meet at a grid barrier per append: the plain launch (bounded barrier, single-workgroup rerun), or -- asked for
+    // through dlsa_kernel_options.cooperative -- a cooperative one
+    void* kargs[] = {(void*)&a};
+    if (a.nwg == 1 || launch_cooperative(reinterpret_cast<const void*>(lars_q_kernel<T, LDSQ>), dim3(a.nwg), dim3(T), kargs, shm, s) != hipSuccess)
+        hipLaunchKernelGGL((lars_q_kernel<T, LDSQ>), dim3(a.nwg), dim3(T), shm, s, a);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }
@@ -689,7 +692,7 @@ constexpr size_t LARS_Q_STATIC_LDS = 1024;      // red, sh_i and alignment
 bool lars_q_eligible(int p, int intercept) {
     const int m = p - (intercept ? 1 : 0);
     if (m < 1 || m > LARS_Q_MAX_M) return false;
-    if (const char* e = getenv("DLSA_LARS_Q")) return atoi(e) != 0;
+    if (const char* e = kernel_knob("DLSA_LARS_Q")) return atoi(e) != 0;
     return true;
 }
 
@@ -698,7 +701,7 @@ bool lars_q_eligible(int p, int intercept) {
 // (bench/lars_ab.py).  DLSA_LARS_Q_WGS overrides (1 .. 8).
 static int lars_q_workgroups(int m) {
     int nwg = m <= 200 ? 1 : (m <= 420 ? 4 : 8);
-    if (const char* e = getenv("DLSA_LARS_Q_WGS")) nwg = atoi(e);
+    if (const char* e = kernel_knob("DLSA_LARS_Q_WGS")) nwg = atoi(e);
     return std::max(1, std::min(nwg, 8));
 }
 
@@ -706,9 +709,9 @@ static int lars_q_workgroups(int m) {
 int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used) {
     const int m = p - (intercept ? 1 : 0);
     int threads = 0;
-    if (const char* e = getenv("DLSA_LARS_Q_THREADS")) threads = atoi(e);
+    if (const char* e = kernel_knob("DLSA_LARS_Q_THREADS")) threads = atoi(e);
     bool want_lds = true;
-    if (const char* e = getenv("DLSA_LARS_Q_LDS")) want_lds = atoi(e) != 0;
+    if (const char* e = kernel_knob("DLSA_LARS_Q_LDS")) want_lds = atoi(e) != 0;
     if (wgs_used) *wgs_used = 1;
     auto fits = [&](int T) { return lars_q_lds_doubles(m, T, true) * 8 + LARS_Q_STATIC_LDS <= (size_t)kLdsBytes && (m + 2) <= T; };
     if (want_lds) {

@@ -424,7 +424,7 @@ static int logit_pass_run(const double* X, int64_t ldx, const double* y, const d
     // Narrow designs (49 <= p <= 120, aligned rows): the rows come through the LDS-DMA ring of the fused Newton pass, which streams
     // at the HBM rate where this kernel's register loads reach 5.2-5.5 TB/s (DLSA_LOGIT_RING=0: keep the register-load kernel).
     if (!img && !intercept && irls_pass_fused_eligible(X, ldx, y, n, p) && (!w_out || ((uintptr_t)w_out % 8) == 0)) {
-        const char* e = getenv("DLSA_LOGIT_RING");
+        const char* e = kernel_knob("DLSA_LOGIT_RING");
         if (!e || atoi(e) != 0)
             return irls_pass_impl(X, ldx, y, beta, n, p, nullptr, p, g, loglik, w_out, nullptr, ws, ws_bytes, stream, nullptr);
     }

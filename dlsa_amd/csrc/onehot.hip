@@ -457,7 +457,7 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
     DLSA_REQUIRE(pl && y && beta && (num || !pl->needs_num || n == 0) && (codes || pl->desc.f == 0 || n == 0),
                  "onehot logit pass: null argument");
     OhDesc ds = pl->desc;
-    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }      // the logit pass: wave turn-taking unless 0
+    { const char* e = kernel_knob("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0) : 1; }      // the logit pass: wave turn-taking unless 0
     ds.overflow = nullptr;
     if (!ws || ws_bytes < onehot_workspace_bytes_impl(pl, n) || ((uintptr_t)ws & 255)) {
         set_error("onehot logit pass: workspace %zu bytes needed (256-aligned), got %zu", onehot_workspace_bytes_impl(pl, n), ws_bytes);
@@ -494,7 +494,7 @@ int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn,
 #endif
     // accumulation mode of the LDS tables: exact fixed-point (2, the default), ordered floating point (DLSA_OH_ORDERED=1),
     // unordered floating point (DLSA_OH_ORDERED=0)
-    { const char* e = getenv("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0 ? 1 : 0) : (irls_weights || !w ? 2 : 1); }
+    { const char* e = kernel_knob("DLSA_OH_ORDERED"); ds.ordered = e ? (atoi(e) != 0 ? 1 : 0) : (irls_weights || !w ? 2 : 1); }
     const size_t ws_need = onehot_workspace_bytes_impl(pl, n);
     if (!ws || ws_bytes < ws_need || ((uintptr_t)ws & 255)) {
         set_error("onehot gram: workspace %zu bytes needed (256-aligned), got %zu", ws_need, ws_bytes);

@@ -46,9 +46,74 @@ const char* knob(const char* env_name) {
 dlsa_irls_options irls_options_snapshot() { return g_opt_set ? g_opt : dlsa_irls_options{0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0}; }
 void irls_options_adopt(const dlsa_irls_options& o) { g_opt = o; g_opt_set = o.struct_bytes != 0; }
 
+// ---- kernel switches (dlsa_kernel_options)
+static const dlsa_kernel_options kKernelAuto = {0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static thread_local dlsa_kernel_options g_kopt = kKernelAuto;
+static thread_local bool g_kopt_set = false;
+#define DLSA_KKNOB(env, field) {env, offsetof(dlsa_kernel_options, field)}
+static const KnobField kKernelFields[] = {
+    DLSA_KKNOB("DLSA_LARS_Q", lars_q),             DLSA_KKNOB("DLSA_LARS_Q_WGS", lars_q_wgs),     DLSA_KKNOB("DLSA_LARS_Q_THREADS", lars_q_threads),
+    DLSA_KKNOB("DLSA_LARS_Q_LDS", lars_q_lds),     DLSA_KKNOB("DLSA_LARS_WGS", lars_wgs),         DLSA_KKNOB("DLSA_LARS_THREADS", lars_threads),
+    DLSA_KKNOB("DLSA_LOGIT_RING", logit_ring),     DLSA_KKNOB("DLSA_CHOL_SMALL", chol_small),     DLSA_KKNOB("DLSA_GRAM_WIDE_F32", gram_wide_f32),
+    DLSA_KKNOB("DLSA_OH_ORDERED", onehot_ordered), DLSA_KKNOB("DLSA_GRAM_DBG", gram_variant),     DLSA_KKNOB("DLSA_COOPERATIVE", cooperative),
+};
+#undef DLSA_KKNOB
+constexpr int kNumKernelFields = (int)(sizeof(kKernelFields) / sizeof(kKernelFields[0]));
+
+const char* kernel_knob(const char* env_name) {
+    static thread_local char text[kNumKernelFields][16];
+    if (g_kopt_set)
+        for (int i = 0; i < kNumKernelFields; ++i)
+            if (!strcmp(kKernelFields[i].env, env_name)) {
+                const int v = *(const int*)((const char*)&g_kopt + kKernelFields[i].off);
+                if (v < 0) break;
+                snprintf(text[i], sizeof text[i], "%d", v);
+                return text[i];
+            }
+#ifdef DLSA_DEBUG_KNOBS
+    return getenv(env_name);        // experiment builds only (make knobs): the A/B scripts under bench/
+#else
+    return nullptr;
+#endif
+}
+
+hipError_t launch_cooperative(const void* func, dim3 grid, dim3 block, void** args, size_t shm, hipStream_t stream) {
+    // OPT-IN (dlsa_kernel_options.cooperative = 1).  Measured on this runtime (round 3, again in round 5: bench/coop_streams.py): every
+    // HIP stream created AFTER a process's first cooperative launch is serialised with the others -- the partition chains of a later
+    // fit lose their overlap -- and a cooperative launch costs 15-19 us of host time.  The plain launch's barriers are bounded and its
+    // give-up path reruns on one workgroup, so the default stays the plain launch.
+    const char* e = kernel_knob("DLSA_COOPERATIVE");
+    if (!e || atoi(e) == 0) return hipErrorNotSupported;
+    const hipError_t rc = hipLaunchCooperativeKernel(func, grid, block, args, (unsigned)shm, stream);
+    if (rc != hipSuccess) (void)hipGetLastError();        // (refused: the sticky error must not fail the plain launch that follows)
+    return rc;
+}
+
+dlsa_kernel_options kernel_options_snapshot() { return g_kopt_set ? g_kopt : kKernelAuto; }
+void kernel_options_adopt(const dlsa_kernel_options& o) { g_kopt = o; g_kopt_set = o.struct_bytes != 0; }
+
 }  // namespace dlsa
 
 extern "C" {
+
+void dlsa_kernel_options_init(dlsa_kernel_options* o) {
+    if (!o) return;
+    *o = dlsa::kKernelAuto;
+    o->struct_bytes = (int)sizeof(dlsa_kernel_options);
+}
+
+int dlsa_kernel_set_options(const dlsa_kernel_options* o) {
+    if (!o) { dlsa::g_kopt_set = false; return DLSA_OK; }
+    if (o->struct_bytes != (int)sizeof(dlsa_kernel_options)) {
+        dlsa::set_error("dlsa_kernel_set_options: struct_bytes %d, this library's dlsa_kernel_options has %d (call dlsa_kernel_options_init first)",
+                        o->struct_bytes, (int)sizeof(dlsa_kernel_options));
+        return DLSA_ERR_INVALID;
+    }
+    dlsa::g_kopt = *o;
+    dlsa::g_kopt_set = true;
+    return DLSA_OK;
+}
+
 
 void dlsa_irls_options_init(dlsa_irls_options* o) {
     if (!o) return;

@@ -515,6 +515,83 @@ def irls_options(options=None, **fields):
             lib.dlsa_irls_set_options(None)
 
 
+@dataclasses.dataclass
+class KernelOptions:
+    """Which build of a kernel runs (never what it returns) for the calls inside `with engine.kernel_options(...)`:
+    include/dlsa_hip.h dlsa_kernel_options, field for field.  None = automatic.  The library reads no environment variable for these."""
+    lars_q: Optional[bool] = None           # LARS on carried Cholesky rows (lars_q.hip) up to 1020 variables
+    lars_q_wgs: Optional[int] = None        # workgroups that share its fused pass, 1..8
+    lars_q_threads: Optional[int] = None    # 256 | 512 | 1024
+    lars_q_lds: Optional[bool] = None
+    lars_wgs: Optional[int] = None          # workgroups of lars.hip's grid kernel, 1..32
+    lars_threads: Optional[int] = None      # 512 | 1024
+    logit_ring: Optional[bool] = None       # narrow designs' logit pass through the LDS-DMA ring
+    chol_small: Optional[bool] = None       # one-launch SPD inverse for p <= 112
+    gram_wide_f32: Optional[bool] = None    # the fp32 wide Gram kernel (p >= 768)
+    onehot_ordered: Optional[int] = None    # 0 unordered, 1 ordered floating point
+    gram_variant: Optional[int] = None      # valid-result A/B bits of the fp64 Gram dispatch (2 | 4 | 8 | 32 | 64 | 256)
+    cooperative: Optional[bool] = None      # multi-workgroup kernels launched cooperatively
+
+    def as_c(self):
+        lib = _lib.load()
+        c = _lib.KernelOptionsC()
+        lib.dlsa_kernel_options_init(ctypes.byref(c))
+        for f in dataclasses.fields(self):
+            v = getattr(self, f.name)
+            if v is not None:
+                setattr(c, f.name, int(v))
+        return c
+
+
+_kernel_options_stack = threading.local()
+
+# the environment variables earlier rounds' A/B scripts used for these switches, honoured by the HOST layer only (bench/ scripts call
+# kernel_options_from_env(); the library itself never reads them)
+_KERNEL_ENV = {"DLSA_LARS_Q": "lars_q", "DLSA_LARS_Q_WGS": "lars_q_wgs", "DLSA_LARS_Q_THREADS": "lars_q_threads", "DLSA_LARS_Q_LDS": "lars_q_lds",
+               "DLSA_LARS_WGS": "lars_wgs", "DLSA_LARS_THREADS": "lars_threads", "DLSA_LOGIT_RING": "logit_ring", "DLSA_CHOL_SMALL": "chol_small",
+               "DLSA_GRAM_WIDE_F32": "gram_wide_f32", "DLSA_OH_ORDERED": "onehot_ordered", "DLSA_GRAM_DBG": "gram_variant", "DLSA_COOPERATIVE": "cooperative"}
+
+
+def kernel_options_from_env(environ=None):
+    """A KernelOptions from the DLSA_* variables of the A/B scripts (None when none is set)."""
+    import os
+    environ = os.environ if environ is None else environ
+    fields = {f: int(environ[k]) for k, f in _KERNEL_ENV.items() if environ.get(k, "") != ""}
+    return KernelOptions(**fields) if fields else None
+
+
+@contextlib.contextmanager
+def kernel_options(options=None, **fields):
+    """The calling thread's kernel switches for the calls inside the block (a KernelOptions, or its fields as keyword arguments);
+    blocks nest like irls_options."""
+    if options is None:
+        options = KernelOptions(**fields) if fields else None
+    elif fields:
+        options = dataclasses.replace(options, **fields)
+    if options is None:
+        yield
+        return
+    lib = _lib.load()
+    stack = getattr(_kernel_options_stack, "items", None)
+    if stack is None:
+        stack = _kernel_options_stack.items = []
+    if stack:
+        options = dataclasses.replace(stack[-1], **{f.name: getattr(options, f.name) for f in dataclasses.fields(options)
+                                                    if getattr(options, f.name) is not None})
+    c = options.as_c()
+    check(lib.dlsa_kernel_set_options(ctypes.byref(c)))
+    stack.append(options)
+    try:
+        yield
+    finally:
+        stack.pop()
+        if stack:
+            c = stack[-1].as_c()
+            lib.dlsa_kernel_set_options(ctypes.byref(c))
+        else:
+            lib.dlsa_kernel_set_options(None)
+
+
 IRLS_PATH_CHAINS, IRLS_PATH_SMALL, IRLS_PATH_BATCHED = 0, 1, 2
 
 

@@ -169,6 +169,28 @@ typedef struct dlsa_irls_options {
     int own_hessian;     /* wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian */
     double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
 } dlsa_irls_options;
+/* Kernel switches outside the IRLS driver (round 5): which build of a kernel runs -- never what it returns.  Per thread, like
+ * dlsa_irls_options; every field -1 = automatic.  They replace the DLSA_LARS_* / DLSA_OH_ORDERED / DLSA_LOGIT_RING / DLSA_CHOL_SMALL /
+ * DLSA_GRAM_NOWIDE / DLSA_GRAM_DBG environment variables of earlier rounds: the shipped library reads no environment variable for
+ * them (builds made with -DDLSA_DEBUG_KNOBS, `make knobs`, still do, for fields left on automatic).  No reference counterpart. */
+typedef struct dlsa_kernel_options {
+    int struct_bytes;    /* sizeof(dlsa_kernel_options), set by dlsa_kernel_options_init                                  */
+    int lars_q;          /* LARS on carried Cholesky rows (lars_q.hip) up to 1020 variables; 0 = lars.hip's kernels        */
+    int lars_q_wgs;      /* workgroups that share lars_q's fused pass: 1..8                                                */
+    int lars_q_threads;  /* its workgroup size: 256 | 512 | 1024                                                           */
+    int lars_q_lds;      /* its matrices in LDS where they fit; 0 = global memory                                          */
+    int lars_wgs;        /* workgroups of lars.hip's grid kernel: 1..32                                                    */
+    int lars_threads;    /* lars.hip's workgroup size: 512 | 1024                                                          */
+    int logit_ring;      /* narrow designs' logit pass through the fused pass's LDS-DMA ring; 0 = register loads           */
+    int chol_small;      /* one-launch SPD inverse for p <= 112; 0 = the blocked Cholesky                                  */
+    int gram_wide_f32;   /* the fp32 wide Gram kernel (p >= 768); 0 = the panel kernel                                     */
+    int onehot_ordered;  /* accumulation of the structured one-hot passes: 0 unordered, 1 ordered floating point (the Gram's default for caller weights is the exact fixed-point mode) */
+    int gram_variant;    /* valid-result A/B bits of the fp64 Gram dispatch: 2 | 4 | 8 | 32 | 64 | 256 (gram.hip)          */
+    int cooperative;     /* 1 = multi-workgroup kernels launched with hipLaunchCooperativeKernel; default 0: plain launch + bounded barrier (streams created after a cooperative launch serialise on this runtime) */
+} dlsa_kernel_options;
+void dlsa_kernel_options_init(dlsa_kernel_options* opt);        /* every field on automatic */
+int dlsa_kernel_set_options(const dlsa_kernel_options* opt);     /* NULL: back to automatic   */
+
 /* which driver the calling thread's last dlsa_irls_fit_f64 / dlsa_irls_fit_ex_f64 took: 0 = host-driven partition chains, 1 = the
  * one-launch kernel for many small partitions (p <= 64), 2 = lock step (all partitions of the call together, narrow designs) */
 int dlsa_irls_last_fit_path(void);
@@ -273,11 +295,12 @@ int dlsa_sym_pinv_solve_f64(const double* S, int64_t lds, const double* v, int p
  * rows).  Runs as one persistent kernel on the device.  Up to 1020 variables the carried-rows
  * form (lars_q.hip): one workgroup up to 200 variables, 4 (beyond 420: 8) workgroups that share
  * the fused pass above; beyond 1020 a grid of up to 32 workgroups (lars.hip, two grid barriers
- * per step).  The multi-workgroup kernels need their workgroups resident together: they are
- * launched cooperatively (hipLaunchCooperativeKernel: co-residency or a clean launch error),
- * as a plain launch only where that is refused; their launches are serialised inside a
- * process, every barrier wait is bounded, and a launch that gives up is rerun on a single
- * workgroup -- slower, same path; DLSA_ERR_HIP only if that is impossible.
+ * per step).  The multi-workgroup kernels need their workgroups resident together: plain
+ * launches whose barrier waits are bounded (0.25 s) -- a launch that gives up is rerun on a
+ * single workgroup: slower, same path; DLSA_ERR_HIP only if that is impossible -- and whose
+ * launches are serialised inside a process; dlsa_kernel_options.cooperative = 1 launches them
+ * with hipLaunchCooperativeKernel instead (co-residency or a clean refusal; opt-in because
+ * HIP streams created after a process's first cooperative launch serialise on this runtime).
  * p is bounded by the LDS per workgroup: about 2400 columns for the grid kernel, 3300 for
  * the single workgroup it falls back to. */
 size_t dlsa_lars_workspace_bytes(int p);
@@ -287,14 +310,14 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
                       int* n_steps_host, void* ws, size_t ws_bytes, void* stream);
 
 /* Diagnostics / test hook of the grid kernel's bounded barrier (no reference counterpart: lars_lsa, dlsa/lsa.py:90-212,
- * is host numpy): sets the per-barrier timeout in seconds (<= 0 restores the 2 s default) and returns how many grid
+ * is host numpy): sets the per-barrier timeout in seconds (<= 0 restores the 0.25 s default) and returns how many grid
  * launches of this process have been given up and rerun on the single-workgroup kernel so far. */
 int dlsa_lars_grid_barrier_timeout(double seconds);
 
 /* The same for the one-launch kernel of many small partitions (dlsa_irls_fit*_f64 with K >= 2 partitions of <= 64 columns and
  * <= 65 536 rows; models.py:110-131 per partition): with fewer partitions than CUs several workgroups share a partition and meet
  * at a bounded per-partition barrier; a launch whose barrier times out is rerun with one workgroup per partition.  Sets the
- * timeout in seconds (<= 0 restores the 2 s default), returns the number of such reruns of this process so far. */
+ * timeout in seconds (<= 0 restores the 0.25 s default), returns the number of such reruns of this process so far. */
 int dlsa_irls_small_cluster_timeout(double seconds);
 
 /* ---- design matrix (N2) ----

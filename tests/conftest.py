@@ -23,6 +23,41 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture
+def kopt():
+    """The calling thread's kernel switches (include/dlsa_hip.h dlsa_kernel_options) for the length of a test: kopt.set(lars_q=0),
+    kopt.clear("lars_q_wgs").  What `monkeypatch.setenv("DLSA_LARS_Q", "0")` was before round 5 -- the library no longer reads the
+    environment for these."""
+    import ctypes
+    from dlsa_amd import _lib, engine
+
+    class Switches:
+        def __init__(self):
+            self.fields = {}
+
+        def _apply(self):
+            lib = _lib.load()
+            if self.fields:
+                c = engine.KernelOptions(**self.fields).as_c()
+                _lib.check(lib.dlsa_kernel_set_options(ctypes.byref(c)))
+            else:
+                lib.dlsa_kernel_set_options(None)
+
+        def set(self, **kw):
+            self.fields.update(kw)
+            self._apply()
+
+        def clear(self, *names):
+            for n in names:
+                self.fields.pop(n, None)
+            self._apply()
+
+    k = Switches()
+    yield k
+    k.fields = {}
+    k._apply()
+
+
 def _free_device_cache():
     """Hand torch's cached blocks and the engine's per-stream scratch back to the driver.  torch.cuda.mem_get_info()
     does not count cached blocks as free, so a 100 GB test that follows another one in the same process would otherwise

@@ -109,6 +109,9 @@ def test_timing_knobs_cannot_change_results_of_the_shipped_library(eng, orc, mon
             monkeypatch.setenv("DLSA_GRAM_DBG", val)
             monkeypatch.setenv("DLSA_OH_DBG", "3")
         outs.append((eng.gram(dev(X500), dev(w500)).cpu(), eng.gram(dev(X100), dev(w100)).cpu(), eng.gram(Xw).cpu()))
+    # ... nor can the options struct that replaced the environment for the valid-result switches: the wrong-result bits are masked out
+    with eng.kernel_options(gram_variant=1 | 16 | 128):
+        outs.append((eng.gram(dev(X500), dev(w500)).cpu(), eng.gram(dev(X100), dev(w100)).cpu(), eng.gram(Xw).cpu()))
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
             assert torch.equal(a, b)

@@ -4,6 +4,8 @@ size -- through size-independent properties.  Run with `pytest -m gpu` on an MI3
 import glob
 import os
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -108,7 +110,7 @@ def test_gram_dma_path_with_row_pitch(eng, orc, n, p, ld):
 def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
     """49 <= p <= 112, even p, >= 8192 rows: the row-split kernel (every wave owns the whole triangle; LDS-DMA ring;
     partial triangles meet in LDS).  Ragged row counts, row pitch != p (NaN padding), weighted and unweighted,
-    accumulate, and agreement with the tile-list kernel (DLSA_GRAM_DBG=64)."""
+    accumulate, and agreement with the tile-list kernel (dlsa_kernel_options.gram_variant = 64)."""
     rng = np.random.default_rng(n + p)
     buf = rng.random((n, ld)) - 0.5
     buf[:, p:] = np.nan
@@ -123,11 +125,8 @@ def test_gram_narrow_row_split_kernel(eng, orc, n, p, ld):
     Hacc = dev(H0.copy())
     eng.gram(Xd, dev(w), out=Hacc, accumulate=True)
     assert rel_inf(Hacc.cpu().numpy(), H0 + Ho) < 1e-11
-    os.environ["DLSA_GRAM_DBG"] = "64"
-    try:
+    with eng.kernel_options(gram_variant=64):
         Hl = eng.gram(Xd, dev(w))
-    finally:
-        del os.environ["DLSA_GRAM_DBG"]
     assert rel_inf(H.cpu().numpy(), Hl.cpu().numpy()) < 1e-12
 
 
@@ -253,11 +252,8 @@ def test_gram_f32_wide_panels(eng, n, p, hasw):
     Ho = X64.T @ ((w.astype(np.float64)[:, None] if hasw else 1.0) * X64)
     assert rel_inf(H, Ho) < 2e-5
     assert np.array_equal(H, H.T)
-    os.environ["DLSA_GRAM_NOWIDE"] = "1"
-    try:
+    with eng.kernel_options(gram_wide_f32=False):
         H2 = eng.gram(Xd, wd).cpu().numpy()
-    finally:
-        del os.environ["DLSA_GRAM_NOWIDE"]
     assert rel_inf(H2, Ho) < 2e-5
 
 
@@ -442,12 +438,12 @@ def test_lars_lasso_drops_wide_matches_oracle(eng, orc, p, rho, seed, intercept)
     assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7
 
 
-def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc, monkeypatch):
+def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc, kopt):
     """The grid kernel's hand-rolled barrier is bounded: a workgroup that waits longer than the timeout aborts the
     launch, every workgroup leaves, and the host reruns the path on the single-workgroup kernel.  With a timeout of one tick every
     wait is 'too long', so the rerun is what produces the result here -- same path as the oracle's; nothing hangs."""
     from dlsa_amd import _lib
-    monkeypatch.setenv("DLSA_LARS_Q", "0")         # (p = 300 would otherwise run on lars_q.hip's single workgroup)
+    kopt.set(lars_q=0)         # (p = 300 would otherwise run on lars_q.hip's single workgroup)
     lib = _lib.load()
     S, b, n = _correlated_lsa_problem(300, 0.9, 3)
     ro = orc.lars_lsa(S, b, False, n, type="lasso")
@@ -466,15 +462,14 @@ def test_lars_grid_barrier_timeout_falls_back_to_one_workgroup(eng, orc, monkeyp
 
 
 @pytest.mark.parametrize("wgs", [1, 5, 16, 32])
-def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, monkeypatch, wgs):
+def test_lars_grid_kernel_matches_single_workgroup_and_golden(eng, orc, kopt, wgs):
     """The multi-workgroup path kernel (cooperative launch, grid barriers) and the single-workgroup one walk the
     same path: reference goldens incl. drops, wide lasso paths with drops, the intercept."""
-    monkeypatch.setenv("DLSA_LARS_WGS", str(wgs))
-    monkeypatch.setenv("DLSA_LARS_Q", "0")         # lars.hip's kernels (the default for these widths is lars_q.hip, tested below)
+    kopt.set(lars_wgs=wgs, lars_q=0)         # lars.hip's kernels (the default for these widths is lars_q.hip, tested below)
     _lars_reference_cases(eng, orc)
 
 
-def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, monkeypatch):
+def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, kopt):
     """m > 200: a few workgroups share the fused pass of lars_q.hip and meet at the same bounded grid barrier; a launch that gives
     up there is rerun on one workgroup.  Any workgroup count walks the oracle's path (p = 300 with drops, p = 700 on the 1024-thread
     build against lars.hip)."""
@@ -483,11 +478,11 @@ def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, m
     S, b, n = _correlated_lsa_problem(300, 0.9, 3)
     ro = orc.lars_lsa(S, b, False, n, type="lasso")
     for wgs in ("1", "3", "8"):
-        monkeypatch.setenv("DLSA_LARS_Q_WGS", wgs)
+        kopt.set(lars_q_wgs=int(wgs))
         r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
         assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7, wgs
         assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
-    monkeypatch.delenv("DLSA_LARS_Q_WGS")
+    kopt.clear("lars_q_wgs")
     before = lib.dlsa_lars_grid_barrier_timeout(1e-9)
     try:
         r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
@@ -498,7 +493,7 @@ def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, m
     assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
     S, b, n = _correlated_lsa_problem(700, 0.9, 19)
     rq = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
-    monkeypatch.setenv("DLSA_LARS_Q", "0")
+    kopt.set(lars_q=0)
     r0 = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
     assert rq["beta"].shape == r0["beta"].shape
     assert rel_inf(rq["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
@@ -506,16 +501,15 @@ def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, m
 
 
 @pytest.mark.parametrize("threads,lds", [(256, 1), (512, 1), (512, 0), (1024, 0)])
-def test_lars_q_kernel_variants_match_golden_and_oracle(eng, orc, monkeypatch, threads, lds):
+def test_lars_q_kernel_variants_match_golden_and_oracle(eng, orc, kopt, threads, lds):
     """lars_q.hip (carried Cholesky rows, the default up to m = 400) in its four builds -- Q and RT in LDS or in global memory,
     256 / 512 / 1024 threads -- on the reference goldens incl. drops, wide lasso paths with drops, the intercept; and the width
     where it hands over to lars.hip."""
-    monkeypatch.setenv("DLSA_LARS_Q_THREADS", str(threads))
-    monkeypatch.setenv("DLSA_LARS_Q_LDS", str(lds))
+    kopt.set(lars_q_threads=threads, lars_q_lds=lds)
     _lars_reference_cases(eng, orc)
     S, b, n = _correlated_lsa_problem(400, 0.9, 17)
     r = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
-    monkeypatch.setenv("DLSA_LARS_Q", "0")
+    kopt.set(lars_q=0)
     r0 = eng.lars_path(dev(S), dev(b), False, float(n), type="lasso")
     assert r["beta"].shape == r0["beta"].shape
     assert rel_inf(r["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
@@ -619,3 +613,39 @@ def test_lars_randomised_problems_match_oracle(eng, orc, seed):
     assert rel_inf(r["AIC"].cpu().numpy(), ro["AIC"]) < 1e-7 and rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
     if intercept:
         assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7
+
+
+def test_cooperative_launch_option_walks_the_same_paths():
+    """dlsa_kernel_options.cooperative = 1: the multi-workgroup kernels (lars.hip's grid, lars_q.hip's clusters, the one-launch IRLS
+    kernel's clusters) launched with hipLaunchCooperativeKernel give the results of the plain launches.  In a child process: streams
+    created after a process's first cooperative launch serialise on this runtime (profiles/r05_coop_streams.txt), which is why the
+    option is off by default -- and why this test keeps it out of the test process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from dlsa_amd import engine
+rng = np.random.default_rng(5)
+out = []
+for p, opts in ((300, {}), (300, {"lars_q": 0}), (700, {})):
+    n = 40 * p
+    X = rng.random((n, p)) - 0.5
+    S = torch.from_numpy(X.T @ ((rng.random(n) * 0.25)[:, None] * X)).cuda()
+    b = torch.from_numpy(np.where(np.arange(p) < 0.4 * p, 1.0, 0.0) + 0.05 * rng.standard_normal(p)).cuda()
+    with engine.kernel_options(**opts):
+        r0 = engine.lars_path(S, b, False, float(n), type="lasso")
+    with engine.kernel_options(cooperative=True, **opts):
+        r1 = engine.lars_path(S, b, False, float(n), type="lasso")
+    assert r0["beta"].shape == r1["beta"].shape and torch.equal(r0["beta"], r1["beta"]) and torch.equal(r0["BIC"], r1["BIC"]), (p, opts)
+X, y = engine.synth(3, 0, 20 * 6000, 50, kind=engine.SYNTH_GAUSSIAN)
+offs = [6000 * k for k in range(21)]
+a = engine.irls_fit(X, y, offs)
+with engine.kernel_options(cooperative=True):
+    c = engine.irls_fit(X, y, offs)
+assert engine.irls_last_fit_path() == engine.IRLS_PATH_SMALL and a["status"] == c["status"] == [0] * 20
+assert torch.equal(a["coef"], c["coef"]) and torch.equal(a["Sig_inv"], c["Sig_inv"])
+print("cooperative ok")
+''' % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "cooperative ok" in r.stdout, r.stdout + r.stderr

@@ -155,11 +155,10 @@ def test_onehot_gram_exact_mode_agrees_with_float_modes_and_falls_back_on_overfl
     dn, dc, dw = dev(num), dev(codes), dev(w)
     H2 = engine.onehot_gram(plan, dn, dc, dw)                     # exact (default)
     assert torch.equal(H2, engine.onehot_gram(plan, dn, dc, dw))
-    monkeypatch.setenv("DLSA_OH_ORDERED", "1")
-    H1 = engine.onehot_gram(plan, dn, dc, dw)
-    monkeypatch.setenv("DLSA_OH_ORDERED", "0")
-    H0 = engine.onehot_gram(plan, dn, dc, dw)
-    monkeypatch.delenv("DLSA_OH_ORDERED")
+    with engine.kernel_options(onehot_ordered=1):
+        H1 = engine.onehot_gram(plan, dn, dc, dw)
+    with engine.kernel_options(onehot_ordered=0):
+        H0 = engine.onehot_gram(plan, dn, dc, dw)
     scale = float(H1.abs().max())
     assert float((H2 - H1).abs().max()) < 1e-13 * scale and float((H0 - H1).abs().max()) < 1e-13 * scale
     d = H1.diagonal().clamp_min(1e-300).sqrt()
@@ -167,9 +166,8 @@ def test_onehot_gram_exact_mode_agrees_with_float_modes_and_falls_back_on_overfl
     # weights far above the fixed-point range: every addend overflows -> ordered fall-back, same matrix as the ordered mode
     big = dev(w * 1e6)
     Hb = engine.onehot_gram(plan, dn, dc, big)
-    monkeypatch.setenv("DLSA_OH_ORDERED", "1")
-    Hb1 = engine.onehot_gram(plan, dn, dc, big)
-    monkeypatch.delenv("DLSA_OH_ORDERED")
+    with engine.kernel_options(onehot_ordered=1):
+        Hb1 = engine.onehot_gram(plan, dn, dc, big)
     assert torch.equal(Hb, Hb1) and bool(torch.isfinite(Hb).all())
     assert float((Hb - H1 * 1e6).abs().max()) < 1e-12 * float(Hb.abs().max())
     # caller weights of a tiny scale keep their RELATIVE accuracy (the fixed-point mode is absolute, 2^-40: w ~ 1e-8 would
