@@ -17,12 +17,12 @@ FP64_MFMA_PEAK_TF, FP32_MFMA_PEAK_TF, HBM_PEAK_GBS = 78.6, 157.3, 8000.0      # 
 
 
 def traffic_from_evidence(tag, p, n):
-    """HBM bytes of one launch over n rows from the committed counter passes of that kernel (profiles/r04_pmc_<tag>.json,
+    """HBM bytes of one launch over n rows from the committed counter passes of that kernel (profiles/r0N_pmc_<tag>.json,
     bench/pmc_evidence.py): per row of the evidence run, scaled; None when the evidence is of another width or of other sources."""
     try:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import pmc_evidence as ev
-        doc = json.load(open(ev.evidence_path("r04", tag)))
+        doc = json.load(open(ev.latest_evidence_path(tag)))
         if doc["p"] != p or doc["sources_sha16"] != ev.sources_sha16(ev.KERNELS[tag]["src"]):
             return None
         k = next(iter(doc["kernels"].values()))

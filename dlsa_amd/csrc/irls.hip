@@ -410,11 +410,21 @@ struct IrlsData {
 // at the final beta.  Returns a HIP/argument error code (0 = fine) and sets *status.
 // Did the Cholesky factorization that launch_chol_solve just enqueued succeed?  (stats[2]: 1 = non-positive pivot, 2 = NaN.)
 // One 8-byte read-back; used where a failed factor would otherwise only surface as NaN iterates.
+// The per-iteration read-back (four doubles) lands in PINNED host memory, one slot per host thread (a partition chain is a thread):
+// a copy into pageable memory goes through the runtime's staging path, ~30 us more per iteration -- and a config-3 fit makes ~130 of them.
+static double* readback_slot() {
+    static thread_local double* slot = nullptr;
+    if (!slot && hipHostMalloc((void**)&slot, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; }
+    return slot;          // (kept for the thread's lifetime; nullptr: the caller falls back to its stack buffer)
+}
+
 static int factor_ok(const IrlsBuffers& b, hipStream_t s, bool* ok) {
-    double flag = 0.0;
-    DLSA_HIP_CHECK(hipMemcpyAsync(&flag, b.stats + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+    double stack_flag = 0.0;
+    double* flag = readback_slot();
+    if (!flag) flag = &stack_flag;
+    DLSA_HIP_CHECK(hipMemcpyAsync(flag, b.stats + 2, sizeof(double), hipMemcpyDeviceToHost, s));
     DLSA_HIP_CHECK(hipStreamSynchronize(s));
-    *ok = (flag == 0.0);
+    *ok = (*flag == 0.0);
     return DLSA_OK;
 }
 
@@ -466,7 +476,11 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     // sweeps of two mat-vecs, no factorisation).  H~ at an iterate e away from the MLE contracts by ~2e + 1.5e-4 per pass; it is
     // refreshed when that is not enough.  The gradient, the stopping rule and the safeguard stay fp64: the fixed point is the MLE.
     const char* env_own = knob("DLSA_IRLS_OWN_HESSIAN");
+    // (only once the iterate is near the MLE -- the last step at most 0.2 max(1, |beta|): far from it, e.g. the first iterations from
+    // beta = 0, the weights move so much between iterates that refinement on the previous factor's inverse does not converge, and
+    // exact Hessians are the right tool)
     const bool can_approx = (env_own ? atoi(env_own) != 0 : true) && d.approx && d.approxable && b.Ha && d.approxable(n) && inv_enabled(p);
+    double near_scale = 1.0;          // max(1, |beta|) of the last completed iteration
     bool have_Ha = false, approx_ok = true, want_refresh = false;
     constexpr int kRefine = 3;
     auto ensure_inverse = [&]() -> int {
@@ -493,7 +507,8 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         if ((fresh_now || peek) && can_fuse) {
             rc = d.pass(b.beta, n, wout, b.g, b.stats + 3, H, b, s);     // w, g, loglik and H in one read of the rows
             if (rc) return rc;
-        } else if (can_approx && approx_ok && !fresh_now && !peek && ((!have_Ha && it >= 2) || (have_Ha && want_refresh))) {
+        } else if (can_approx && approx_ok && !fresh_now && !peek && isfinite(dprev) && dprev <= 0.2 * near_scale &&
+                   ((!have_Ha && it >= 2) || (have_Ha && want_refresh))) {
             rc = d.approx(b.beta, n, b.w, b.g, b.stats + 3, b.Ha, b, s);    // w, g, loglik as the logit pass + the partition's own H~
             if (rc) return rc;
             have_Ha = true;
@@ -615,8 +630,10 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
             }
         }
         have_factor = true;
-        double h[4];
-        DLSA_HIP_CHECK(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
+        double h_stack[4];
+        double* h = readback_slot();
+        if (!h) h = h_stack;
+        DLSA_HIP_CHECK(hipMemcpyAsync(h, b.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         DLSA_HIP_CHECK(hipStreamSynchronize(s));
         ll = h[3];
         *loglik = ll;
@@ -637,6 +654,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         }
         halvings = 0;
         const double scale = std::max(1.0, h[1]);
+        near_scale = scale;
         if (h[0] <= tol * scale) {
             *status = DLSA_PART_OK;
             *fresh = fresh_now || peek;
