@@ -180,3 +180,31 @@ def test_committed_kernel_evidence_matches_the_tree():
         kk = next(iter(doc["kernels"].values()))
         assert kk.get("duration_ms_under_pmc", 0) > 0 and "GRBM_GUI_ACTIVE" in kk and "FETCH_SIZE" in kk, tag
     assert not stale, "stale evidence for: " + ", ".join(stale)
+
+
+def test_committed_eight_rank_dry_run_line_is_consistent_with_the_one_rank_line():
+    """profiles/r05_bench_gloo8_dryrun.json: `DLSA_BENCH_BACKEND=gloo python bench.py --gpus 8 --rows-per-gpu 2000000` (eight ranks
+    SHARING one GPU over gloo: the N > 1 code path of the line, rates meaningless) against profiles/r05_bench_rows2e6_n1.json, the N = 1
+    line at the same rows per GPU: same metric / dtype / unit / rows per GPU / workload kernel, value = N x value_per_gpu, the ranks
+    counted from the communicator, a strong-scaling leg that kept the metric's kernel."""
+    n8 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_gloo8_dryrun.json")))
+    n1 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_rows2e6_n1.json")))
+    assert n8["n_gpus"] == 8 and n1["n_gpus"] == 1
+    for key in ("metric", "unit", "dtype", "higher_is_better", "scaling", "data", "steps", "warmup"):
+        assert n8[key] == n1[key], key
+    assert n8["config"]["rows_per_gpu"] == n1["config"]["rows_per_gpu"] == 2_000_000 and n8["config"]["p"] == n1["config"]["p"] == 500
+    assert n8["config"]["parallelism"] == "row-shards x8" and n1["config"]["parallelism"] == "row-shards x1"
+    assert abs(n8["value_per_gpu"] * 8 - n8["value"]) <= 1e-9 * n8["value"] and abs(n1["value_per_gpu"] - n1["value"]) <= 1e-9 * n1["value"]
+    assert n8["comm_ranks"] == 8 and n8["rccl_ranks"] == 0 and n1["comm_ranks"] == 1          # (gloo dry run: no RCCL rank claimed)
+    assert n8["allreduce"]["ranks"] == 8 and n8["allreduce"]["payload_bytes"] == (500 * 500 + 2 * 500) * 8
+    assert "gram_cyclic_kernel" in n8["roofline"]["kernel"] and "gram_cyclic_kernel" in n1["roofline"]["kernel"]
+    ss = n8["strong_scaling"]
+    assert ss and "skipped" not in ss and ss["rows_per_gpu"] == 250_000 and "gram_cyclic_kernel" in ss["kernel"]
+    assert n8["roofline"]["algorithmic_bytes_per_row"] == n1["roofline"]["algorithmic_bytes_per_row"] == 4008
+
+
+def test_strong_scaling_leg_is_refused_below_the_kernel_floor():
+    bench = _load_bench()
+    assert bench.STRONG_MIN_ROWS == 65536
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "strong-scaling leg skipped" in src and "R // world < STRONG_MIN_ROWS" in src
