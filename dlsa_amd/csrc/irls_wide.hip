@@ -27,6 +27,7 @@ typedef unsigned wide_u4v __attribute__((ext_vector_type(4)));
 typedef unsigned wide_u2v __attribute__((ext_vector_type(2)));
 
 constexpr int WIDE_WGS = 256;             // workgroups per launch (one per CU)
+constexpr int WIDE_RING_BYTES = 160 * 1024;      // the whole LDS of a CU: what bounds the syrk is the bytes its ring keeps in flight
 constexpr int64_t WIDE_MIN_ROWS = 32768;
 
 // Tiles in CYCLIC CLASSES: block row r owns the tiles (r, (r + d) mod NB), d = 0 .. NB / 2 (the last class only for r < NB / 2 when
@@ -48,9 +49,9 @@ __global__ __launch_bounds__(256, 1) void wide_syrk_kernel(const unsigned* __res
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int PW = (NB + 3) / 4;                              // 1 KiB pieces per wave and chunk
     constexpr int STG = 4 * PW * 1024, CH = NB * 1024;            // stage pitch, image bytes per chunk
-    constexpr int NS = (144 * 1024 / STG) < 16 ? (144 * 1024 / STG) : 16, D = NS - 2;      // ring stages; chunks in flight (two per trip)
+    constexpr int NS = (WIDE_RING_BYTES / STG) < 16 ? (WIDE_RING_BYTES / STG) : 16, D = NS - 2;      // ring stages; chunks in flight (two per trip)
     constexpr int HV = wide_hv(NB), NWV = wide_nwave(NB), D0 = wide_d0(NB), D1 = wide_d1(NB), T = (NB % 2) ? NB + 1 : NB;
-    static_assert(D >= 2 && (D - 2) * PW <= 63 && NS * STG <= 144 * 1024, "vmcnt immediate; ring fits");
+    static_assert(D >= 2 && (D - 2) * PW <= 63 && NS * STG <= WIDE_RING_BYTES, "vmcnt immediate; ring fits");
     static_assert(NWV + D1 < T && D0 < T, "the second row's classes end within the walk");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,7 +195,7 @@ size_t irls_wide_workspace_bytes(int64_t n, int p, int icpt) {
 
 template <int NB>
 static int wide_syrk_launch(const unsigned* img, int64_t nchunks, float* hpart, hipStream_t s) {
-    constexpr int PW = (NB + 3) / 4, STG = 4 * PW * 1024, NS = (144 * 1024 / STG) < 16 ? (144 * 1024 / STG) : 16;
+    constexpr int PW = (NB + 3) / 4, STG = 4 * PW * 1024, NS = (WIDE_RING_BYTES / STG) < 16 ? (WIDE_RING_BYTES / STG) : 16;
     constexpr size_t shm = (size_t)NS * STG;
     static bool attr_set = false;
     if (!attr_set) {
