@@ -71,6 +71,15 @@ def logistic_config(name, n, p, K, kind=engine.SYNTH_GAUSSIAN, Xy=None):
     if 49 <= p <= 120 and p % 2 == 0 and n >= 8192:
         t_fused, _ = timed(lambda: engine.irls_pass(X, y, beta))
         rl["fused"] = roofline("fused", n, p, t_fused, "fused_p100")
+        if p == 100:
+            # A second fraction: fp64 VALU and fp64 MFMA share ONE pipe on gfx950 (bench/ubench_gap.hip: every VALU
+            # instruction between MFMAs costs ~4.7 pipe cycles), so the fused pass's ceiling is not "the Gram's MFMAs with the logistic
+            # terms hidden" but MFMA cycles + 4.7 x VALU per trip: 112 MFMAs (5866 cycles) + 177 VALU = 6698 cycles per 64 rows and CU
+            # (irls_pass.hip's p = 100 shape), at 2.4 GHz and at the ~2.1 GHz the chip holds under this load
+            cyc = (n / 256.0 / 64.0) * (5866.0 + 4.7 * 177.0)
+            rl["fused"]["shared_pipe"] = {"ceiling_ms_at_2.4GHz": cyc / 2.4e6, "frac_at_2.4GHz": cyc / 2.4e6 / (t_fused * 1e3),
+                                          "ceiling_ms_at_2.1GHz": cyc / 2.1e6, "frac_at_2.1GHz": cyc / 2.1e6 / (t_fused * 1e3),
+                                          "what": "time of the pass's own MFMA + 4.7 x VALU pipe cycles / measured time"}
     def whole():
         mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs)
         out = dlsa_amd.dlsa_mapred(mb)
