@@ -86,7 +86,7 @@ bool irls_wide_eligible(const double* X, int64_t ldx, int64_t n, int p, int icpt
 size_t irls_wide_workspace_bytes(int64_t n, int p, int icpt);
 int irls_wide_pass_impl(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, int icpt, double* w_out,
                         double* g, double* loglik, double* Happrox, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t stream);
-constexpr int64_t kWideMaxRows = 32000000;       // (the pass keeps a bf16 image of the partition: p / 2 KiB... 1 KiB per row at p = 500)
+constexpr int64_t kWideMaxRows = 4000000;  // (the pass keeps a bf16 image of the partition, 1 KiB per row at p = 500.  A single 2.5e7-row partition would be served too -- measured: 7 -> 5 full passes, 0.2437 -> 0.2398 s -- for 25 GB more workspace: not taken)
 // irls_batch.hip: the lock-step fit of all partitions of a call together
 bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step);
 int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int64_t row_step, int K,
