@@ -12,7 +12,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = dict(score=0.0, H=0.0, smc=0.0, ll=0.0)
 paths = {}
 for c in range(cases):
-    p = int(rng.choice([rng.integers(2, 30), rng.integers(30, 70), 2 * rng.integers(25, 61), rng.integers(60, 130), rng.integers(130, 320)]))
+    p = int(rng.choice([rng.integers(2, 30), rng.integers(30, 70), 2 * rng.integers(25, 61), rng.integers(60, 130), rng.integers(130, 320),
+                        rng.integers(121, 513)]))        # (round 5: the wide pass's class up to 512 columns -- own-Hessian steps on warm partitions)
     K = int(rng.choice([1, 1, 2, 3, 7, 12, 40]))          # (>= 8 partitions of a fused-class width: the lock-step driver's territory)
     per = int(rng.choice([rng.integers(40 * p, 80 * p), rng.integers(200 * p, 400 * p), rng.integers(8192, 40000), rng.integers(100000, 400000)]))
     per = max(per, 40 * p)
