@@ -4,6 +4,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from dlsa_amd import _lib
+if os.environ.get("DLSA_AB_LIB"):          # same-box A/B of a build variant (bench/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["DLSA_AB_LIB"])
 import dlsa_amd
 from dlsa_amd import engine
 

@@ -315,7 +315,9 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         return DLSA_OK;
     };
     if (phase_a) {
-        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 1e-4), 1);
+        // (the subsample's MLE is ~2 sqrt(p / rows) away from the partition's own whatever happens here: a step of 3e-2 is close enough --
+        // round 5, same box: 1000 x 2e4 x 100 39.6 -> 37.0 ms, 200 x 1e5 x 100 31.6 -> 30.7, the full-row iterations unchanged at 5)
+        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1);
         if (rc) return fail(rc);
         // (a partition still live after the cap restarts like a failed one would: from where it is)
         hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
