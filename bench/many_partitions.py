@@ -18,15 +18,17 @@ for K, nk, p in shapes:
     icpt, strided = os.environ.get("MP_ICPT", "0") != "0", os.environ.get("MP_STRIDED", "0") != "0"
     part = dict(partition_num=K) if strided else dict(part_offsets=offs)
     res = {}
-    for name, opt in (("auto", {}), ("lock step", dict(batched=True, small=False)), ("chains", dict(batched=False, small=False))):
+    for name, opt in (("auto", {}), ("lock step", dict(batched=True, small=False)), ("own start", dict(batched=True, small=False, pooled_start=False)),
+                      ("chains", dict(batched=False, small=False))):
         ts = []
         for _ in range(3):
             torch.cuda.synchronize(); t = time.perf_counter()
             mb = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, **part, **opt)
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+        if os.environ.get("MP_VERBOSE"): print("   %s: %s ms" % (name, ["%.1f" % (v * 1e3) for v in ts]), flush=True)
         res[name] = (sorted(ts)[1], engine.irls_last_fit_path(), mb.n_iter[:2], all(s == 0 for s in mb.status), mb)
     err = float((res["lock step"][4].coef - res["chains"][4].coef).abs().max())
-    print("%s%sK=%5d n_k=%8d p=%3d (%.1f GB): auto %.1f ms (path %d) | lock step %.1f ms iters %s | chains %.1f ms iters %s | ok %s %s | max coef diff %.1e" % (
+    print("%s%sK=%5d n_k=%8d p=%3d (%.1f GB): auto %.1f ms (path %d) | lock step %.1f ms iters %s (own-subsample start %.1f ms iters %s) | chains %.1f ms iters %s | ok %s %s | max coef diff %.1e" % (
         "intercept " if icpt else "", "i%K " if strided else "", K, nk, p, K * nk * p * 8 / 1e9, res["auto"][0] * 1e3, res["auto"][1], res["lock step"][0] * 1e3, res["lock step"][2],
-        res["chains"][0] * 1e3, res["chains"][2], res["lock step"][3], res["chains"][3], err), flush=True)
+        res["own start"][0] * 1e3, res["own start"][2], res["chains"][0] * 1e3, res["chains"][2], res["lock step"][3], res["chains"][3], err), flush=True)
     del X, y, res

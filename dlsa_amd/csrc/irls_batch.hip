@@ -13,8 +13,9 @@
 //        halving, stopping rule |delta|_inf <= tol max(1, |beta|_inf), max_iter) -- a partition that ends writes coef, Sig_inv . coef
 //        and its status and leaves the active set; its slabs return at once in later passes.
 //   One 4-byte read-back per iteration (the number of live partitions).
-// Every partition starts from beta = 0 (no warm start from its neighbour: that is what lock step gives up); the MLE and the Hessian at
-// it are those of the host-driven path to the solver tolerance.  Shapes: what the fused pass and the one-launch inverse take (49 <= p
+// Start (round 5): ONE fit from beta = 0 on a few leading rows of all partitions together, then every partition's full-row iterations
+// from that pooled estimate (see `pooled` below; before: every partition's own fit on its leading quarter / eighth, still the fallback);
+// the MLE and the Hessian at it are those of the host-driven path to the solver tolerance.  Shapes: what the fused pass and the one-launch inverse take (49 <= p
 // + intercept <= 112; aligned rows of even width, or packed rows of odd width without the intercept; contiguous or i % K strided
 // partitions); chosen by a cost model against the chained path.
 // Scratch beyond the caller's workspace comes from the stream-ordered pool and is freed before the call returns.
@@ -146,6 +147,29 @@ __global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __
     active[k] = 1;
 }
 
+// pooled start: the groups' H, g, loglik (batch_unpack_kernel over the group table) summed in a fixed order into slot 0
+__global__ __launch_bounds__(256) void batch_pool_sum_kernel(int G, int p, double* __restrict__ H, double* __restrict__ g, double* __restrict__ ll) {
+    const int64_t pp = (int64_t)p * p, e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < pp) {
+        double s = H[e];
+        for (int q = 1; q < G; ++q) s += H[(int64_t)q * pp + e];
+        H[e] = s;
+    } else if (e - pp <= p) {
+        const int j = (int)(e - pp);
+        double s = j < p ? g[j] : ll[0];
+        for (int q = 1; q < G; ++q) s += j < p ? g[(int64_t)q * p + j] : ll[q];
+        if (j < p) g[j] = s;
+        else ll[0] = s;
+    }
+}
+
+// ... and its end: every partition starts the full-row phase from the pooled estimate
+__global__ __launch_bounds__(256) void batch_pool_spread_kernel(int K, int p, double* __restrict__ beta) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)K * p || e < p) return;
+    beta[e] = beta[e % p];
+}
+
 // Is the lock-step path the faster one?  Measured constants: a fused pass streams ~4.5e9 rows/s at p = 100 (scaled by the width), an
 // iteration of the four launches + the read-back ~0.15 ms; the chained path costs ~0.28 ms per partition on four chains + ~4.6 passes.
 bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept,
@@ -209,34 +233,60 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     // ---- cold start: the first Newton iterations from beta = 0 run on the leading 1 / 8 of every partition's rows (they only have to
     // get near the MLE: 4-5 passes at an eighth of the cost), then the full-row iterations start from there (3-4 passes instead of 7).
     // Only when every partition's eighth still pins its MLE (>= 40 rows per coefficient, >= 2048 rows).
-    std::vector<FusedSlab> slabsA;
+    std::vector<FusedSlab> slabsA, slabsP;
     std::vector<int> beginA((size_t)K + 1, 0);
     bool phase_a = true;
-    {
-        const char* e = knob("DLSA_IRLS_SUBSAMPLE");
-        int64_t mn = INT64_MAX;
-        for (int k = 0; k < K; ++k) mn = std::min(mn, rows_host[k]);
-        const int64_t need_rows = std::max<int64_t>(2048, 40 * (int64_t)p);
-        const int div = e ? atoi(e) : (mn / 8 / 32 * 32 >= need_rows ? 8 : 4);       // an eighth where that is enough rows, else a quarter
-        if (div < 2) phase_a = false;
-        for (int k = 0; k < K && phase_a; ++k) {
-            const int64_t nA = rows_host[k] / div / 32 * 32;
-            if (nA < std::max<int64_t>(2048, 40 * (int64_t)p)) { phase_a = false; break; }
-            const FusedSlab& f0 = slabs[(size_t)slab_begin[(size_t)k]];       // (the labels of a partition's leading rows lead its gathered labels)
-            const int nsl = (int)std::max<int64_t>(1, (nA + slab_cap - 1) / slab_cap);
-            const int64_t per = ((nA + nsl - 1) / nsl + 31) / 32 * 32;
-            beginA[(size_t)k] = (int)slabsA.size();
-            for (int64_t r = 0; r < nA; r += per) {
+    // the leading `lead(k)` rows of every partition as a slab table (the labels of a partition's leading rows lead its gathered labels)
+    auto leading_rows = [&](std::vector<FusedSlab>& tab, std::vector<int>* begin, auto lead) {
+        for (int k = 0; k < K; ++k) {
+            const int64_t nL = lead(k);
+            const FusedSlab& f0 = slabs[(size_t)slab_begin[(size_t)k]];
+            const int nsl = (int)std::max<int64_t>(1, (nL + slab_cap - 1) / slab_cap);
+            const int64_t per = ((nL + nsl - 1) / nsl + 31) / 32 * 32;
+            if (begin) (*begin)[(size_t)k] = (int)tab.size();
+            for (int64_t r = 0; r < nL; r += per) {
                 FusedSlab sd;
                 sd.xoff = f0.xoff + r * pitch; sd.yoff = f0.yoff + r;
-                sd.nrows = (int)std::min<int64_t>(per, nA - r); sd.part = k;
-                slabsA.push_back(sd);
+                sd.nrows = (int)std::min<int64_t>(per, nL - r); sd.part = k;
+                tab.push_back(sd);
             }
         }
-        beginA[(size_t)K] = (int)slabsA.size();
-        if (!phase_a) slabsA.clear();
+        if (begin) (*begin)[(size_t)K] = (int)tab.size();
+    };
+    int64_t mn = INT64_MAX, mx = 0;
+    for (int k = 0; k < K; ++k) { mn = std::min(mn, rows_host[k]); mx = std::max(mx, rows_host[k]); }
+    const int64_t need_rows = std::max<int64_t>(2048, 40 * (int64_t)p);
+    {
+        const char* e = knob("DLSA_IRLS_SUBSAMPLE");
+        const int div = e ? atoi(e) : (mn / 8 / 32 * 32 >= need_rows ? 8 : 4);       // an eighth where that is enough rows, else a quarter
+        if (div < 2 || mn / div / 32 * 32 < need_rows) phase_a = false;
+        if (phase_a) leading_rows(slabsA, &beginA, [&](int k) { return rows_host[k] / div / 32 * 32; });
     }
     const int nslabA = (int)slabsA.size();
+    // ---- pooled start (round 5): ONE fit on leading rows of ALL partitions together, and every partition's full-row iterations start
+    // from that estimate.  Where rows are exchangeable across partitions (the reference shuffles / deals them out as i % K,
+    // models.py:33) the pooled estimate is ~sqrt(p / rows_k) from partition k's own MLE -- nearer than the MLE of its own quarter --
+    // once the pool holds 8 rows_max rows (its own error is then a third of that; and >= 1000 rows per coefficient), whatever K is.  With many partitions that
+    // is a small fraction of the subsample phase's rows, and an iteration pays one inversion instead of K: 1000 x 2e4 x 100 four
+    // pooled iterations of ~0.4 ms instead of four subsample iterations of 1.8 ms.  Partitions that differ from each other just take
+    // the Newton iterations their distance asks for; a pooled fit that fails falls back to the subsample phase.
+    const char* pool_env = knob("DLSA_IRLS_POOLED_START");
+    const bool pooled = phase_a && !(pool_env && atoi(pool_env) == 0);
+    const int G = std::min(K, 128);                  // the pooled table's slabs in G groups: the unpack stays parallel
+    std::vector<int> beginP((size_t)G + 1, 0);
+    if (pooled) {
+        const int64_t want = std::max<int64_t>(8 * mx, 1000 * (int64_t)p), each = std::max<int64_t>(256, ((want + K - 1) / K + 31) / 32 * 32);
+        leading_rows(slabsP, nullptr, [&](int k) { return std::min<int64_t>(each, rows_host[k] / 4 / 32 * 32); });
+        int at = 0;
+        const int nP = (int)slabsP.size();
+        for (int q = 0; q < G; ++q) {
+            beginP[(size_t)q] = at;
+            const int k1 = (int)((int64_t)(q + 1) * K / G);
+            while (at < nP && slabsP[(size_t)at].part < k1) slabsP[(size_t)at++].part = q;
+        }
+        beginP[(size_t)G] = at;
+    }
+    const int nslabP = (int)slabsP.size();
 
     // ---- scratch: ONE block from the stream-ordered pool, freed before the call returns
     const size_t pb = (size_t)K * p * sizeof(double);
@@ -250,7 +300,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
                  o_stats = carve((size_t)K * 3 * sizeof(double)), o_beta = carve(pb), o_prev = carve(pb), o_step = carve(pb),
                  o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256),
                  o_ysrc = carve(gather_y ? (size_t)nslab * sizeof(int64_t) : 0), o_ybuf = carve(gather_y ? (size_t)(ytotal + 64) * sizeof(double) : 0),
-                 o_slabsA = carve((size_t)nslabA * sizeof(FusedSlab)), o_beginA = carve(((size_t)K + 1) * sizeof(int));
+                 o_slabsA = carve((size_t)nslabA * sizeof(FusedSlab)), o_beginA = carve(((size_t)K + 1) * sizeof(int)),
+                 o_slabsP = carve((size_t)nslabP * sizeof(FusedSlab)), o_beginP = carve(((size_t)G + 1) * sizeof(int));
     char* pool = nullptr;
     DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, off, stream));
     FusedSlab* d_slabs = (FusedSlab*)(pool + o_slabs);
@@ -266,6 +317,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     const double* ylab = gather_y ? d_ybuf : y;
     FusedSlab* d_slabsA = (FusedSlab*)(pool + o_slabsA);
     int* d_beginA = (int*)(pool + o_beginA);
+    FusedSlab* d_slabsP = (FusedSlab*)(pool + o_slabsP);
+    int* d_beginP = (int*)(pool + o_beginP);
     auto release = [&]() { (void)hipFreeAsync(pool, stream); };
     int rc = DLSA_OK;
     auto fail = [&](int code) { release(); return code; };
@@ -280,6 +333,10 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabsA, slabsA.data(), (size_t)nslabA * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_beginA, beginA.data(), ((size_t)K + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     }
+    if (pooled) {
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabsP, slabsP.data(), (size_t)nslabP * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_beginP, beginP.data(), ((size_t)G + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
     {
         std::vector<int> ones((size_t)K, 1);
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_active, ones.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -293,17 +350,22 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     const int cap = 2 * max_iter + 66;
     int live = K;
     // one phase: passes over the given slab table until no partition is live
-    auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a) -> int {
-        live = K;
-        for (int it = 0; it < cap && live > 0; ++it) {
-            int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream);
+    // (groups > 0: the pooled fit -- the table's parts are `groups` groups which all read beta row 0, summed into ONE problem)
+    auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a, int groups) -> int {
+        const int nprob = groups ? 1 : K, nunpack = groups ? groups : K;
+        // (the two start phases are the driver's own: the caller's max_iter bounds the full-row iterations only)
+        const int iter_cap = in_a ? std::max(max_iter, 30) : max_iter, pass_cap = in_a ? 2 * iter_cap + 66 : cap;
+        live = nprob;
+        for (int it = 0; it < pass_cap && live > 0; ++it) {
+            int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, groups ? 0 : p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream);
             if (r) return r;
-            hipLaunchKernelGGL(batch_unpack_kernel, dim3(K), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
+            hipLaunchKernelGGL(batch_unpack_kernel, dim3(nunpack), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
                                begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, Sig_inv, d_g, d_ll);
-            r = launch_chol_small_batched(K, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
+            if (groups > 1) hipLaunchKernelGGL(batch_pool_sum_kernel, dim3((unsigned)((p * p + p + 1 + 255) / 256)), dim3(256), 0, stream, groups, p, Sig_inv, d_g, d_ll);
+            r = launch_chol_small_batched(nprob, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
             if (r) return r;
             if (hipMemsetAsync(d_live, 0, sizeof(int), stream) != hipSuccess) return DLSA_ERR_HIP;
-            hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, stream, p, ptol, max_iter, (const double*)Sig_inv, (const double*)d_ll,
+            hipLaunchKernelGGL(batch_update_kernel, dim3(nprob), dim3(128), 0, stream, p, ptol, iter_cap, (const double*)Sig_inv, (const double*)d_ll,
                                (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
                                Sig_invMcoef, d_llout, d_iter, d_status, in_a);
             if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -314,15 +376,28 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         }
         return DLSA_OK;
     };
-    if (phase_a) {
+    bool started = false;
+    if (pooled) {
+        // the groups' slabs stay in the pass while active[0 .. G) are set: only the pooled problem's own flag (slot 0) changes
+        rc = run_phase(d_slabsP, nslabP, d_beginP, std::max(tol, 3e-2), 1, G);
+        if (rc) return fail(rc);
+        BatchState sp;
+        DLSA_BATCH_CHECK(hipMemcpyAsync(&sp, d_state, sizeof(BatchState), hipMemcpyDeviceToHost, stream));
+        DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
+        started = live == 0 && sp.status == DLSA_PART_OK;
+        if (started) hipLaunchKernelGGL(batch_pool_spread_kernel, dim3((unsigned)(((int64_t)K * p + 255) / 256)), dim3(256), 0, stream, K, p, d_beta);
+        else DLSA_BATCH_CHECK(hipMemsetAsync(d_beta, 0, pb, stream));
+        hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
+    }
+    if (phase_a && !started) {
         // (the subsample's MLE is ~2 sqrt(p / rows) away from the partition's own whatever happens here: a step of 3e-2 is close enough --
         // round 5, same box: 1000 x 2e4 x 100 39.6 -> 37.0 ms, 200 x 1e5 x 100 31.6 -> 30.7, the full-row iterations unchanged at 5)
-        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1);
+        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1, 0);
         if (rc) return fail(rc);
         // (a partition still live after the cap restarts like a failed one would: from where it is)
         hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
     }
-    rc = run_phase(d_slabs, nslab, d_begin, tol, 0);
+    rc = run_phase(d_slabs, nslab, d_begin, tol, 0, 0);
     if (rc) return fail(rc);
     if (live > 0) { set_error("irls_fit (batched): %d partitions still live after %d passes", live, cap); return fail(DLSA_ERR_INVALID); }
     if (n_iter_host) DLSA_BATCH_CHECK(hipMemcpyAsync(n_iter_host, d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -465,6 +465,7 @@ class IrlsOptions:
     lean: Optional[bool] = None             # fits at fused widths write no weight vector
     small_cluster: Optional[int] = None     # workgroups per partition of the one-launch kernel, 1..16
     own_hessian: Optional[bool] = None      # wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian
+    pooled_start: Optional[bool] = None     # lock step: full-row iterations start from one fit on the leading rows of all partitions
     freeze_at: Optional[float] = None       # 0: never freeze the factor
 
     def as_c(self):

@@ -143,3 +143,48 @@ def test_max_iter_means_full_row_iterations_on_every_driver(eng):
     with eng.irls_options(batched=True, small=False):
         short = eng.irls_fit(X, y, offs, max_iter=1)     # one full-row iteration cannot converge: NOT_CONVERGED on every partition, n_iter = 1
     assert all(s != 0 for s in short["status"]) and short["n_iter"] == [1] * K
+
+
+@pytest.mark.parametrize("p,K,nk,icpt", [(100, 40, 20000, False), (64, 24, 30000, True), (99, 16, 25000, False)])
+def test_pooled_start_changes_the_path_not_the_result(eng, orc, p, K, nk, icpt):
+    """round 5: the full-row iterations of a lock-step call start from ONE fit on the leading rows of all partitions together
+    (dlsa_irls_options.pooled_start) instead of every partition's own subsample MLE: fewer full-row iterations, the same MLEs and
+    Hessians (models.py:110-131 per partition), also against the oracle."""
+    import dlsa_amd
+    X, y = eng.synth(9100 + p, 0, K * nk, p, kind=eng.SYNTH_GAUSSIAN)
+    offs = [k * nk for k in range(K + 1)]
+    res = {}
+    for pooled in (True, False):
+        res[pooled] = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, part_offsets=offs, batched=True, small=False, pooled_start=pooled)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and res[pooled].status == [0] * K
+    a, b = res[True], res[False]
+    for key in ("coef", "Sig_inv", "Sig_invMcoef"):
+        assert rel_inf(getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy()) < 1e-10, key
+    assert max(a.n_iter) <= max(b.n_iter), (a.n_iter, b.n_iter)
+    k = K // 2
+    co, smc, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy(), icpt)
+    assert rel_inf(a.coef[k].cpu().numpy(), co) < 1e-10 and rel_inf(a.Sig_inv[k].cpu().numpy(), sig) < 1e-10
+    assert rel_inf(a.Sig_invMcoef[k].cpu().numpy(), smc) < 1e-10
+
+
+def test_pooled_start_with_partitions_that_differ(eng, orc):
+    """partitions drawn from DIFFERENT coefficient vectors (rows not exchangeable: the pooled estimate is nobody's MLE), one of them
+    perfectly separable: the pooled start costs iterations, never the result -- every partition ends at its own MLE (oracle)"""
+    p, K, nk = 64, 12, 24000
+    X, _ = eng.synth(515, 0, K * nk, p, kind=eng.SYNTH_GAUSSIAN)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    y = torch.empty(K * nk, dtype=torch.float64, device=X.device)
+    for k in range(K):
+        bk = (torch.randn(p, generator=g, dtype=torch.float64) * (0.2 + 0.15 * k) * (-1.0) ** k).to(X.device)
+        eta = X[k * nk:(k + 1) * nk] @ bk
+        u = torch.rand(nk, generator=g, dtype=torch.float64).to(X.device)
+        y[k * nk:(k + 1) * nk] = (u < torch.sigmoid(eta)).double()
+    y[5 * nk:6 * nk] = (X[5 * nk:6 * nk, 3] > 0).double()
+    offs = [k * nk for k in range(K + 1)]
+    with eng.irls_options(batched=True, small=False, pooled_start=True):
+        b = eng.irls_fit(X, y, offs, max_iter=30)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED
+    assert b["status"][5] != 0 and [s for k, s in enumerate(b["status"]) if k != 5] == [0] * (K - 1)
+    for k in (0, 4, 11):
+        co, _, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
+        assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
