@@ -46,7 +46,7 @@ $(BUILD)/gram_plan_unit_%.o: $(CSRC)/gram_plan_unit.hip $(GEN)/gram_plan_%.inc $
 	$(HIPCC) $(FLAGS) -I$(GEN) -DPLAN_LO=$(word 2,$(subst _, ,$*)) -DPLAN_HI=$(word 3,$(subst _, ,$*)) -DPLAN_INC='"gram_plan_$*.inc"' -x hip -c $< -o $@
 
 $(OUT): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined $(OBJS) -ldl -o $@
 
 check: $(OUT)
 	python3 tools/check_agpr_kernels.py $(OUT)

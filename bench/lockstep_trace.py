@@ -17,6 +17,11 @@ if sys.argv[1] == "run":
         mb = dlsa_amd.fit_logistic_partitions(X, y, part_offsets=offs, batched=True, small=False)
         torch.cuda.synchronize()
     print("iters", mb.n_iter[:3])
+    if os.environ.get("LS_SINGLE"):          # the same rows through the single-partition form of the fused pass, for the per-row rate
+        beta = mb.coef[0].clone()
+        for _ in range(5):
+            engine.irls_pass(X, y, beta)
+        torch.cuda.synchronize()
 else:
     rows = list(csv.DictReader(open(sys.argv[2])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -39,6 +44,8 @@ else:
         t = tot.setdefault(nm, [0, 0.0]); t[0] += 1; t[1] += (e - s) / 1e3
         t = tot.setdefault("(gaps)", [0, 0.0]); t[0] += 1; t[1] += gap
         prev_end = e
+    single = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[last_unpack + 1:] if "irls_pass_narrow" in r["Kernel_Name"]]
+    if single: print("---- single-partition form over the same rows: %s us" % ["%.1f" % v for v in single])
     print("---- totals of the last fit")
     for nm, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print("%9.1f us  %4d x  %s" % (us, c, nm))

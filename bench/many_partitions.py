@@ -18,6 +18,7 @@ for K, nk, p in shapes:
     icpt, strided = os.environ.get("MP_ICPT", "0") != "0", os.environ.get("MP_STRIDED", "0") != "0"
     part = dict(partition_num=K) if strided else dict(part_offsets=offs)
     res = {}
+    dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, **part)          # (untimed: the first calls on freshly written rows run up to 2x slower)
     for name, opt in (("auto", {}), ("lock step", dict(batched=True, small=False)), ("own start", dict(batched=True, small=False, pooled_start=False)),
                       ("chains", dict(batched=False, small=False))):
         ts = []

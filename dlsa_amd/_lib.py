@@ -20,7 +20,7 @@ c_u64 = ctypes.c_uint64
 class IrlsOptionsC(ctypes.Structure):
     """include/dlsa_hip.h: dlsa_irls_options (field for field)"""
     _fields_ = [(n, c_int) for n in ("struct_bytes", "chains", "seeded", "subsample_div", "factor_div", "warm", "inherit", "pool", "secant",
-                                     "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace", "lean", "small_cluster", "own_hessian", "pooled_start")] + [("freeze_at", c_dbl)]
+                                     "inverse", "predict", "fused", "fuse_last", "small", "batched", "qn_threads", "trace", "lean", "small_cluster", "own_hessian", "pooled_start", "grad_passes")] + [("freeze_at", c_dbl)]
 
 
 class KernelOptionsC(ctypes.Structure):

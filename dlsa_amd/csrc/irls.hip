@@ -53,7 +53,7 @@ int logit_pass_border_impl(const double* X, int64_t ldx, const double* y, const 
 int xtv_impl(const double* X, int64_t ldx, const double* v, int64_t n, int p, double* g, double* vv, double* sv,
              void* ws, size_t ws_bytes, hipStream_t s);
 // irls_small.hip: all partitions in ONE launch, a workgroup each (many small partitions)
-bool irls_small_eligible(const int64_t* rows_host, int K, int pe);
+bool irls_small_eligible(const int64_t* rows_host, int K, int pe, double* est_ms = nullptr);
 size_t irls_small_workspace_bytes(int K);
 int irls_small_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host,
                    int64_t step, int K, int p, int intercept, double tol, int max_iter, double* coef, double* Sig_inv,
@@ -88,7 +88,8 @@ int irls_wide_pass_impl(const double* X, int64_t ldx, const double* y, const dou
                         double* g, double* loglik, double* Happrox, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t stream);
 constexpr int64_t kWideMaxRows = 4000000;  // (the pass keeps a bf16 image of the partition, 1 KiB per row at p = 500.  A single 2.5e7-row partition would be served too -- measured: 7 -> 5 full passes, 0.2437 -> 0.2398 s -- for 25 GB more workspace: not taken)
 // irls_batch.hip: the lock-step fit of all partitions of a call together
-bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step);
+bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept, int64_t row_step,
+                           double* est_ms = nullptr);
 int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_t* first_host, const int64_t* rows_host, int64_t row_step, int K,
                      int p, int intercept, double tol, int max_iter, double* coef, double* Sig_inv, double* Sig_invMcoef, int* n_iter_host, int* status_host,
                      double* loglik_host, hipStream_t stream);
@@ -1147,12 +1148,17 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         std::vector<int64_t> rows((size_t)K);
         bool mono = true;
         for (int k = 0; k < K; ++k) { rows[(size_t)k] = part_offsets_host[k + 1] - part_offsets_host[k]; mono &= rows[(size_t)k] >= 0; }
-        if (mono && K <= 8192 && irls_small_eligible(rows.data(), K, p) && ws && ws_bytes >= irls_small_workspace_bytes(K) && !((uintptr_t)ws & 255)) {
+        // (both the one-launch kernel and the lock step beat the chains: the cheaper estimate of the two -- 300 x 3e4 x 64: 17 / 9.7 ms)
+        double t_small = 0.0, t_lock = 0.0;
+        const bool small_ok = mono && K <= 8192 && irls_small_eligible(rows.data(), K, p, &t_small) && ws && ws_bytes >= irls_small_workspace_bytes(K) &&
+                              !((uintptr_t)ws & 255);
+        const bool lock_ok = mono && irls_batched_eligible(X, ldx, y, rows.data(), K, p, 0, 1, &t_lock);
+        if (small_ok && !(lock_ok && t_lock < t_small)) {
             g_last_fit_path = 1;
             return irls_small_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef,
                                   n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
         }
-        if (mono && irls_batched_eligible(X, ldx, y, rows.data(), K, p, 0, 1)) {
+        if (lock_ok) {
             g_last_fit_path = 2;
             return irls_batched_fit(X, ldx, y, part_offsets_host, rows.data(), 1, K, p, 0, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
                                     status_host, loglik_host, (hipStream_t)stream);
@@ -1218,12 +1224,15 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
         set_error("irls_fit_ex: workspace %zu bytes needed (256-aligned), got %zu", need, ws_bytes);
         return DLSA_ERR_WORKSPACE;
     }
-    if (irls_small_eligible(part_rows_host, K, pe)) {
+    double t_small = 0.0, t_lock = 0.0;
+    const bool small_ok = irls_small_eligible(part_rows_host, K, pe, &t_small);
+    const bool lock_ok = irls_batched_eligible(X, ldx, y, part_rows_host, K, p, intercept, row_step, &t_lock);
+    if (small_ok && !(lock_ok && t_lock < t_small)) {
         g_last_fit_path = 1;
         return irls_small_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv,
                               Sig_invMcoef, n_iter_host, status_host, loglik_host, ws, ws_bytes, (hipStream_t)stream);
     }
-    if (irls_batched_eligible(X, ldx, y, part_rows_host, K, p, intercept, row_step)) {
+    if (lock_ok) {
         g_last_fit_path = 2;
         return irls_batched_fit(X, ldx, y, part_first_host, part_rows_host, row_step, K, p, intercept, tol, max_iter, coef, Sig_inv, Sig_invMcoef, n_iter_host,
                                 status_host, loglik_host, (hipStream_t)stream);

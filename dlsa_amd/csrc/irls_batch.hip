@@ -23,7 +23,13 @@
 #include "options.h"
 #include "irls_batch.h"
 #include <algorithm>
+#include <cmath>
 #include <vector>
+#ifndef FP_TIMELINE
+#define FP_TIMELINE 0
+#endif
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace dlsa {
 
@@ -34,7 +40,7 @@ int irls_pass_batched_ll_at(int p);
 bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, int p, int intercept, int64_t base_ldx);
 int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
-                             unsigned long long* clk, hipStream_t stream);
+                             unsigned long long* clk, hipStream_t stream, int want_h);
 // chol.hip
 bool chol_small_ok(int p);
 int launch_chol_small_batched(int count, const double* A, int64_t lda, int64_t sA, int p, const double* rhs, const double* ref, int64_t sV,
@@ -43,7 +49,7 @@ int launch_chol_small_batched(int count, const double* A, int64_t lda, int64_t s
 constexpr int BATCH_SLAB_ROWS = 24576;          // a partition longer than this is cut into equal slabs (whole 32-row chunks)
 
 struct BatchState {            // per partition, device
-    double ll_prev;
+    double ll_prev, dprev;     // dprev: the previous gradient-only step (its ratio to the next one is the contraction rate)
     int have_prev, halvings, iters, evals, last_pass, status;
 };
 
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void batch_unpack_kernel(const double* __restr
     const int s0 = slab_begin[k], s1 = slab_begin[k + 1];
     double* __restrict__ Hk = H + (int64_t)k * p * p;
     auto om = [&](int c) { return rot ? (c == p - 1 ? 0 : c + 1) : c; };
-    for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
+    for (int e = threadIdx.x; e < (H ? p * p : 0); e += blockDim.x) {           // (H == nullptr: a gradient-only pass left no H partials)
         const int i = e / p, j = e - i * p;
         if (i > j) continue;
         double s = 0.0;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
                                                            double* __restrict__ prev, double* __restrict__ stepv, BatchState* __restrict__ st,
                                                            int* __restrict__ active, int* __restrict__ n_live, double* __restrict__ coef,
                                                            double* __restrict__ smc, double* __restrict__ loglik, int* __restrict__ n_iter,
-                                                           int* __restrict__ status, int phase_a) {
+                                                           int* __restrict__ status, int phase_a, double etarget) {
     // phase_a: the cold start on the partitions' leading rows -- a partition that ends there writes no outputs (a failed one goes back
     // to beta = 0): batch_restart_kernel then opens the full-row phase from the subsample MLEs
     const int k = blockIdx.x, j = threadIdx.x;
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
     double* sk = stepv + (int64_t)k * p;
     const double* dk = delta + (int64_t)k * p;
     int end = -1;                                  // >= 0: the partition's fit ends with this status
+    bool stepped = false;
     ++s.evals;
     if (s.last_pass) end = DLSA_PART_NOT_CONVERGED;            // max_iter reached: H, loglik are those of the last iterate
     else if (!isfinite(ll)) end = DLSA_PART_NAN;
@@ -111,10 +118,17 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
             if (j < p) { const double b = bk[j], d = dk[j]; pk[j] = b; sk[j] = d; bk[j] = b + d; }
             s.ll_prev = ll; s.have_prev = 1; s.halvings = 0;
             if (s.iters >= max_iter) s.last_pass = 1;
+            if (phase_a == 2) {
+                // gradient-only phase: steps shrink by rho per pass, so ~rho dmax / (1 - rho) is left after this one -- near enough
+                // for the Newton phase to end in three passes?  Then this partition is done here.
+                const double rho = s.dprev > 0.0 ? dmax / s.dprev : 1.0;
+                if (rho < 0.5 && rho * dmax / (1.0 - rho) <= etarget * fmax(1.0, bmax)) { end = DLSA_PART_OK; stepped = true; }
+                s.dprev = dmax;
+            }
         }
     }
     if (end >= 0 && phase_a) {
-        if (end != DLSA_PART_OK && j < p) bk[j] = 0.0;
+        if (j < p && !stepped) bk[j] = end == DLSA_PART_OK ? bk[j] + dk[j] : 0.0;       // (a start phase takes its last, small step too)
         s.status = end;
     } else if (end >= 0) {
         // outputs: coef, Sig_inv . coef (models.py:131); Sig_inv is the H the unpack kernel has just written in place
@@ -142,7 +156,7 @@ __global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     BatchState s = st[k];
-    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0; s.iters = 0;
+    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0; s.iters = 0; s.dprev = 0.0;
     st[k] = s;
     active[k] = 1;
 }
@@ -163,6 +177,32 @@ __global__ __launch_bounds__(256) void batch_pool_sum_kernel(int G, int p, doubl
     }
 }
 
+// gradient-only iterations after the pooled start: partition k's Newton step with the POOLED Hessian in place of its own,
+// delta = (rows_k / rows_pool  H_pool)^-1 g_k -- H_pool^-1 is the explicit inverse the pooled fit's last iteration left
+__global__ __launch_bounds__(128) void batch_pool_step_kernel(int p, const double* __restrict__ Hinv, const double* __restrict__ scale,
+                                                              const double* __restrict__ g, const double* __restrict__ beta,
+                                                              const int* __restrict__ active, double* __restrict__ delta,
+                                                              double* __restrict__ stats) {
+    const int k = blockIdx.x, j = threadIdx.x;
+    if (!active[k]) return;
+    __shared__ double gs[128], red[2][2];
+    if (j < p) gs[j] = g[(int64_t)k * p + j];
+    __syncthreads();
+    double d = 0.0, b = 0.0;
+    if (j < p) {
+        double acc = 0.0;
+        for (int c = 0; c < p; ++c) acc = fma(Hinv[(int64_t)j * p + c], gs[c], acc);
+        d = acc * scale[k];
+        delta[(int64_t)k * p + j] = d;
+        b = fabs(beta[(int64_t)k * p + j]);
+    }
+    double dm = isfinite(d) ? fabs(d) : INFINITY;
+    for (int o = 32; o; o >>= 1) { dm = fmax(dm, __shfl_xor(dm, o)); b = fmax(b, __shfl_xor(b, o)); }
+    if ((j & 63) == 0) { red[j >> 6][0] = dm; red[j >> 6][1] = b; }
+    __syncthreads();
+    if (j == 0) { stats[3 * k] = fmax(red[0][0], red[1][0]); stats[3 * k + 1] = fmax(red[0][1], red[1][1]); stats[3 * k + 2] = 0.0; }
+}
+
 // ... and its end: every partition starts the full-row phase from the pooled estimate
 __global__ __launch_bounds__(256) void batch_pool_spread_kernel(int K, int p, double* __restrict__ beta) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,10 +210,10 @@ __global__ __launch_bounds__(256) void batch_pool_spread_kernel(int K, int p, do
     beta[e] = beta[e % p];
 }
 
-// Is the lock-step path the faster one?  Measured constants: a fused pass streams ~4.5e9 rows/s at p = 100 (scaled by the width), an
-// iteration of the four launches + the read-back ~0.15 ms; the chained path costs ~0.28 ms per partition on four chains + ~4.6 passes.
+// Is the lock-step path the faster one?  Measured constants: a fused pass streams ~4.5e9 rows/s at p = 100 (scaled by the width).
 bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const int64_t* rows_host, int K, int p, int intercept,
-                           int64_t row_step) {
+                           int64_t row_step, double* est_ms) {
+    if (est_ms) *est_ms = 0.0;                     // (stays 0 when forced)
     const char* e = knob("DLSA_IRLS_BATCHED");
     if (e && atoi(e) == 0) return false;
     const int pe = p + (intercept ? 1 : 0);
@@ -185,8 +225,11 @@ bool irls_batched_eligible(const double* X, int64_t ldx, const double* y, const 
     for (int k = 0; k < K; ++k) { total += rows_host[k]; mn = std::min(mn, rows_host[k]); }
     if (mn < 1) return false;                      // empty partitions: the host-driven path writes the reference's zero block
     if (e && atoi(e) != 0) return true;            // forced (A/B runs, tests)
+    // (round 5, bench/many_partitions.py: lock step = pooled start + ~3 gradient-only passes at half price + 3 Newton passes ~ 6 pass units
+    // + ~10 iterations' launches; the chains are bound by ~0.23 ms per partition or by their ~4.6 pass units of row traffic)
     const double pass_s = (double)total * (pe / 100.0) * 2.3e-10;
-    const double t_batch = 8.0 * (pass_s + 0.15e-3), t_chain = K * 0.28e-3 + 4.6 * pass_s;
+    const double t_batch = 6.0 * pass_s + 3.0e-3, t_chain = std::max(K * 0.23e-3, 4.6 * pass_s);
+    if (est_ms) *est_ms = t_batch * 1e3;
     return K >= 8 && t_batch < t_chain;
 }
 
@@ -271,22 +314,36 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     // pooled iterations of ~0.4 ms instead of four subsample iterations of 1.8 ms.  Partitions that differ from each other just take
     // the Newton iterations their distance asks for; a pooled fit that fails falls back to the subsample phase.
     const char* pool_env = knob("DLSA_IRLS_POOLED_START");
-    const bool pooled = phase_a && !(pool_env && atoi(pool_env) == 0);
+    bool pooled = !(pool_env && atoi(pool_env) == 0);
     const int G = std::min(K, 128);                  // the pooled table's slabs in G groups: the unpack stays parallel
     std::vector<int> beginP((size_t)G + 1, 0);
     if (pooled) {
         const int64_t want = std::max<int64_t>(8 * mx, 1000 * (int64_t)p), each = std::max<int64_t>(256, ((want + K - 1) / K + 31) / 32 * 32);
-        leading_rows(slabsP, nullptr, [&](int k) { return std::min<int64_t>(each, rows_host[k] / 4 / 32 * 32); });
-        int at = 0;
-        const int nP = (int)slabsP.size();
-        for (int q = 0; q < G; ++q) {
-            beginP[(size_t)q] = at;
-            const int k1 = (int)((int64_t)(q + 1) * K / G);
-            while (at < nP && slabsP[(size_t)at].part < k1) slabsP[(size_t)at++].part = q;
+        auto lead = [&](int k) { return std::max<int64_t>(32, std::min<int64_t>(each, rows_host[k] / 4 / 32 * 32)); };
+        int64_t rows_pool = 0;
+        for (int k = 0; k < K; ++k) rows_pool += std::min<int64_t>(lead(k), rows_host[k]);
+        // (a pool of fewer rows than this is no better a start than a partition's own rows, and its Hessian no stand-in)
+        if (rows_pool < std::max<int64_t>(4 * mx, 200 * (int64_t)p)) pooled = false;
+        if (pooled) {
+            leading_rows(slabsP, nullptr, [&](int k) { return std::min<int64_t>(lead(k), rows_host[k]); });
+            int at = 0;
+            const int nP = (int)slabsP.size();
+            for (int q = 0; q < G; ++q) {
+                beginP[(size_t)q] = at;
+                const int k1 = (int)((int64_t)(q + 1) * K / G);
+                while (at < nP && slabsP[(size_t)at].part < k1) slabsP[(size_t)at++].part = q;
+            }
+            beginP[(size_t)G] = at;
         }
-        beginP[(size_t)G] = at;
     }
     const int nslabP = (int)slabsP.size();
+    std::vector<double> pool_scale;                  // rows_pool / rows_k: the pooled Hessian stands in for rows_k / rows_pool of itself
+    if (pooled) {
+        int64_t rows_pool = 0;
+        for (const FusedSlab& sd : slabsP) rows_pool += sd.nrows;
+        pool_scale.resize((size_t)K);
+        for (int k = 0; k < K; ++k) pool_scale[(size_t)k] = (double)rows_pool / (double)rows_host[k];
+    }
 
     // ---- scratch: ONE block from the stream-ordered pool, freed before the call returns
     const size_t pb = (size_t)K * p * sizeof(double);
@@ -301,7 +358,8 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
                  o_hinv = carve((size_t)K * p * p * sizeof(double)), o_clk = carve(256),
                  o_ysrc = carve(gather_y ? (size_t)nslab * sizeof(int64_t) : 0), o_ybuf = carve(gather_y ? (size_t)(ytotal + 64) * sizeof(double) : 0),
                  o_slabsA = carve((size_t)nslabA * sizeof(FusedSlab)), o_beginA = carve(((size_t)K + 1) * sizeof(int)),
-                 o_slabsP = carve((size_t)nslabP * sizeof(FusedSlab)), o_beginP = carve(((size_t)G + 1) * sizeof(int));
+                 o_slabsP = carve((size_t)nslabP * sizeof(FusedSlab)), o_beginP = carve(((size_t)G + 1) * sizeof(int)),
+                 o_scale = carve((size_t)K * sizeof(double));
     char* pool = nullptr;
     DLSA_HIP_CHECK(hipMallocAsync((void**)&pool, off, stream));
     FusedSlab* d_slabs = (FusedSlab*)(pool + o_slabs);
@@ -319,6 +377,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     int* d_beginA = (int*)(pool + o_beginA);
     FusedSlab* d_slabsP = (FusedSlab*)(pool + o_slabsP);
     int* d_beginP = (int*)(pool + o_beginP);
+    double* d_scale = (double*)(pool + o_scale);
     auto release = [&]() { (void)hipFreeAsync(pool, stream); };
     int rc = DLSA_OK;
     auto fail = [&](int code) { release(); return code; };
@@ -336,6 +395,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     if (pooled) {
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_slabsP, slabsP.data(), (size_t)nslabP * sizeof(FusedSlab), hipMemcpyHostToDevice, stream));
         DLSA_BATCH_CHECK(hipMemcpyAsync(d_beginP, beginP.data(), ((size_t)G + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+        DLSA_BATCH_CHECK(hipMemcpyAsync(d_scale, pool_scale.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream));
     }
     {
         std::vector<int> ones((size_t)K, 1);
@@ -348,30 +408,48 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     DLSA_BATCH_CHECK(hipMemsetAsync(d_step, 0, pb, stream));
 
     const int cap = 2 * max_iter + 66;
+    const char* trace_env = knob("DLSA_IRLS_TRACE");
+    const bool trace = trace_env && atoi(trace_env) != 0;
     int live = K;
     // one phase: passes over the given slab table until no partition is live
     // (groups > 0: the pooled fit -- the table's parts are `groups` groups which all read beta row 0, summed into ONE problem)
-    auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a, int groups) -> int {
+    // (grad_passes > 0: that many gradient-only passes -- no H, the step from the pooled Hessian's inverse in d_hinv slot 0)
+    auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a, int groups, int grad_passes) -> int {
         const int nprob = groups ? 1 : K, nunpack = groups ? groups : K;
-        // (the two start phases are the driver's own: the caller's max_iter bounds the full-row iterations only)
-        const int iter_cap = in_a ? std::max(max_iter, 30) : max_iter, pass_cap = in_a ? 2 * iter_cap + 66 : cap;
+        // (the start phases are the driver's own: the caller's max_iter bounds the full-row Newton iterations only)
+        const int iter_cap = in_a ? std::max(max_iter, 30) : max_iter, pass_cap = grad_passes ? grad_passes : in_a ? 2 * iter_cap + 66 : cap;
         live = nprob;
         for (int it = 0; it < pass_cap && live > 0; ++it) {
-            int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, groups ? 0 : p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream);
+            int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, groups ? 0 : p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream,
+                                             grad_passes ? 0 : 1);
             if (r) return r;
             hipLaunchKernelGGL(batch_unpack_kernel, dim3(nunpack), dim3(256), 0, stream, (const double*)d_partial, (const double*)d_gpart,
-                               begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, Sig_inv, d_g, d_ll);
+                               begin, (const int*)d_active, PP, GP, ll_at, p, intercept ? 1 : 0, grad_passes ? (double*)nullptr : Sig_inv, d_g, d_ll);
             if (groups > 1) hipLaunchKernelGGL(batch_pool_sum_kernel, dim3((unsigned)((p * p + p + 1 + 255) / 256)), dim3(256), 0, stream, groups, p, Sig_inv, d_g, d_ll);
-            r = launch_chol_small_batched(nprob, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
+            if (grad_passes)
+                hipLaunchKernelGGL(batch_pool_step_kernel, dim3(K), dim3(128), 0, stream, p, (const double*)d_hinv, (const double*)d_scale, (const double*)d_g,
+                                   (const double*)d_beta, (const int*)d_active, d_delta, d_stats);
+            else
+                r = launch_chol_small_batched(nprob, Sig_inv, p, (int64_t)p * p, p, d_g, d_beta, p, d_hinv, (int64_t)p * p, d_delta, d_stats, 3, d_active, stream);
             if (r) return r;
             if (hipMemsetAsync(d_live, 0, sizeof(int), stream) != hipSuccess) return DLSA_ERR_HIP;
             hipLaunchKernelGGL(batch_update_kernel, dim3(nprob), dim3(128), 0, stream, p, ptol, iter_cap, (const double*)Sig_inv, (const double*)d_ll,
                                (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
-                               Sig_invMcoef, d_llout, d_iter, d_status, in_a);
+                               Sig_invMcoef, d_llout, d_iter, d_status, grad_passes ? 2 : in_a, ptol);
             if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
                 hipStreamSynchronize(stream) != hipSuccess) {
                 set_error("irls_fit (batched): a launch or the read-back of the live count failed");
                 return DLSA_ERR_HIP;
+            }
+            if (trace) {       // (dlsa_irls_options.trace: the iteration's relative steps over the partitions that took part in it)
+                std::vector<double> hs((size_t)nprob * 3);
+                if (hipMemcpyAsync(hs.data(), d_stats, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                    hipStreamSynchronize(stream) != hipSuccess) return DLSA_ERR_HIP;
+                std::vector<double> rel;
+                for (int k = 0; k < nprob; ++k) rel.push_back(hs[3 * (size_t)k] / std::max(1.0, hs[3 * (size_t)k + 1]));
+                std::sort(rel.begin(), rel.end());
+                fprintf(stderr, "[dlsa lock step] %s pass %d: live after it %d of %d; relative step (all partitions' last) median %.2e max %.2e\n",
+                        groups ? "pooled" : grad_passes ? "gradient-only" : in_a ? "subsample" : "Newton", it, live, nprob, rel[rel.size() / 2], rel.back());
             }
         }
         return DLSA_OK;
@@ -379,7 +457,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     bool started = false;
     if (pooled) {
         // the groups' slabs stay in the pass while active[0 .. G) are set: only the pooled problem's own flag (slot 0) changes
-        rc = run_phase(d_slabsP, nslabP, d_beginP, std::max(tol, 3e-2), 1, G);
+        rc = run_phase(d_slabsP, nslabP, d_beginP, std::max(tol, 3e-2), 1, G, 0);
         if (rc) return fail(rc);
         BatchState sp;
         DLSA_BATCH_CHECK(hipMemcpyAsync(&sp, d_state, sizeof(BatchState), hipMemcpyDeviceToHost, stream));
@@ -388,18 +466,44 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         if (started) hipLaunchKernelGGL(batch_pool_spread_kernel, dim3((unsigned)(((int64_t)K * p + 255) / 256)), dim3(256), 0, stream, K, p, d_beta);
         else DLSA_BATCH_CHECK(hipMemsetAsync(d_beta, 0, pb, stream));
         hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
+        // ---- gradient-only iterations: passes over all rows that cost half a fused pass (no H: HBM-bound), steps with the pooled
+        // Hessian (scaled to the partition's row count) in place of the partition's own.  They contract the distance to the partition's
+        // MLE by the relative distance of its Hessian from the pooled one, ~sqrt(p / rows_k) -- 0.17 -> 0.015 -> 1.5e-3 at 2e4 x 100 --
+        // and a partition leaves this phase once three Newton passes will do from where it is (steps e, c e^2, c^3 e^4 <= tol with
+        // c ~ 1/2): G G G F F F (tol 1e-13; G G for 1e-10) for F F F F F.  bench/lockstep_start_study.py, bench/grad_passes_ab.py.
+        // The safeguard is the Newton phase's own (a step that lowers the log-likelihood is halved).
+        const char* ge = knob("DLSA_IRLS_GRAD_PASSES");
+        const int gpasses = ge ? atoi(ge) : 4;
+        const double etarget = std::min(3e-3, std::max(1e-4, std::pow(0.8 * tol, 0.25)));
+        if (started && gpasses > 0) {
+            rc = run_phase(d_slabs, nslab, d_begin, etarget, 1, 0, gpasses);
+            if (rc) return fail(rc);
+            hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
+        }
     }
     if (phase_a && !started) {
         // (the subsample's MLE is ~2 sqrt(p / rows) away from the partition's own whatever happens here: a step of 3e-2 is close enough --
         // round 5, same box: 1000 x 2e4 x 100 39.6 -> 37.0 ms, 200 x 1e5 x 100 31.6 -> 30.7, the full-row iterations unchanged at 5)
-        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1, 0);
+        rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1, 0, 0);
         if (rc) return fail(rc);
         // (a partition still live after the cap restarts like a failed one would: from where it is)
         hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
     }
-    rc = run_phase(d_slabs, nslab, d_begin, tol, 0, 0);
+    rc = run_phase(d_slabs, nslab, d_begin, tol, 0, 0, 0);
     if (rc) return fail(rc);
     if (live > 0) { set_error("irls_fit (batched): %d partitions still live after %d passes", live, cap); return fail(DLSA_ERR_INVALID); }
+#if FP_TIMELINE
+    // (experiment builds, bench/lockstep_timeline.py: the last pass's per-workgroup time stamps ride in the free slots of the g partials)
+    if (const char* dump = getenv("DLSA_TL_DUMP")) {
+        std::vector<double> hostg((size_t)nslab * GP);
+        DLSA_BATCH_CHECK(hipMemcpyAsync(hostg.data(), d_gpart, hostg.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
+        if (FILE* fh = fopen(dump, "wb")) {
+            const int hdr[4] = {nslab, GP, p, 0};
+            fwrite(hdr, sizeof(int), 4, fh); fwrite(hostg.data(), sizeof(double), hostg.size(), fh); fclose(fh);
+        }
+    }
+#endif
     if (n_iter_host) DLSA_BATCH_CHECK(hipMemcpyAsync(n_iter_host, d_iter, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (status_host) DLSA_BATCH_CHECK(hipMemcpyAsync(status_host, d_status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (loglik_host) DLSA_BATCH_CHECK(hipMemcpyAsync(loglik_host, d_llout, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, stream));

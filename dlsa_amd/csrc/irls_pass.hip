@@ -1047,9 +1047,10 @@ bool irls_pass_batched_shape_ok(const double* X, int64_t ldx, const double* y, i
     if (intercept && (p & 1)) return false;
     return pe >= FP_MIN_P && pe <= FP_MAX_P && fp_rows_ok(X, ldx, p, base_ldx) && ((uintptr_t)y % 8) == 0;
 }
+// want_h == 0: the logit-only form (g and loglik per slab, no H partial: `partial` unused) -- the lock step's gradient-only iterations
 int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, const double* beta, int64_t beta_stride, int p, int intercept,
                              const FusedSlab* d_slabs, int nslab, const int* d_active, double* partial, double* gpart,
-                             unsigned long long* clk, hipStream_t stream) {
+                             unsigned long long* clk, hipStream_t stream, int want_h) {
     const int pe = p + (intercept ? 1 : 0);
     FusedArgs a;
     a.slabs = d_slabs; a.active = d_active; a.beta_stride = beta_stride;
@@ -1057,17 +1058,14 @@ int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, cons
     a.partial = partial; a.gpart = gpart; a.clk = clk;
     int nt, gt;
     fp_shape(pe, nt, gt);
+#define DLSA_LAUNCH_FPB2(HS, NTV, GV, IC) do { \
+        const size_t shm = (HS) ? fp_hess_lds(NTV, GV) : (size_t)fp_logit_stages(NTV + (GV > 0 ? 1 : 0)) * fp_buf(NTV + (GV > 0 ? 1 : 0)) * 8; \
+        DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, HS, NTV, GV, true, IC>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((irls_pass_narrow_kernel<false, HS, NTV, GV, true, IC>), dim3(nslab), dim3(256), shm, stream, a); } while (0)
 #define DLSA_LAUNCH_FPB(NTV, GV) do { \
-        const size_t shm = fp_hess_lds(NTV, GV); \
-        if (intercept) { \
-            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true, true>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-            hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true, true>), dim3(nslab), dim3(256), shm, stream, a); \
-        } else { \
-            DLSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(irls_pass_narrow_kernel<false, true, NTV, GV, true>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-            hipLaunchKernelGGL((irls_pass_narrow_kernel<false, true, NTV, GV, true>), dim3(nslab), dim3(256), shm, stream, a); \
-        } } while (0)
+        if (want_h) { if (intercept) DLSA_LAUNCH_FPB2(true, NTV, GV, true); else DLSA_LAUNCH_FPB2(true, NTV, GV, false); } \
+        else { if (intercept) DLSA_LAUNCH_FPB2(false, NTV, GV, true); else DLSA_LAUNCH_FPB2(false, NTV, GV, false); } } while (0)
 #define DLSA_LAUNCH_FPB_G(NTV) do { switch (gt) { \
         case 0: DLSA_LAUNCH_FPB(NTV, 0); break; case 1: DLSA_LAUNCH_FPB(NTV, 1); break; \
         case 2: DLSA_LAUNCH_FPB(NTV, 2); break; default: DLSA_LAUNCH_FPB(NTV, 3); break; } } while (0)
@@ -1078,6 +1076,7 @@ int irls_pass_batched_launch(const double* X, int64_t ldx, const double* y, cons
     }
 #undef DLSA_LAUNCH_FPB_G
 #undef DLSA_LAUNCH_FPB
+#undef DLSA_LAUNCH_FPB2
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

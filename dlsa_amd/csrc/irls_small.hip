@@ -426,7 +426,9 @@ bool irls_small_enabled() {
 // Measured (ms, p ~ 50): this kernel 1.0 + 1.9e-4 n_k whatever K (up to one workgroup per CU), the host-driven path 0.55 K
 // (per-iteration launch + synchronisation latency): K = 20 x 5 000 rows 1.9 vs 12.9, K = 200 x 5 000 2.6 vs 125,
 // K = 20 x 50 000 10.5 vs 11.3, K = 8 x 20 000 5.4 vs 5.4, K = 4 x 60 000 7.1 vs 2.3.
-bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
+// est_ms (nullable): the cost model's estimate for this kernel, 0 when forced -- the caller weighs it against the lock step's
+bool irls_small_eligible(const int64_t* rows_host, int K, int pe, double* est_ms) {
+    if (est_ms) *est_ms = 0.0;
     if (!irls_small_enabled() || pe > SM_MAXP || K < 2) return false;
     int64_t nmax = 0;
     for (int k = 0; k < K; ++k) nmax = std::max(nmax, rows_host[k]);
@@ -443,6 +445,7 @@ bool irls_small_eligible(const int64_t* rows_host, int K, int pe) {
     const int S = std::max(1, std::min(cap, (K - 1) / 2));
     static const double per_partition_ms[5] = {0.55, 0.55, 0.37, 0.29, 0.23};
     const double t_small = ((C > 8 ? 1.0 : 0.8) + 1.9e-4 * ((double)nmax / C) * std::max(0.5, pe / 50.0)) * rounds, t_host = per_partition_ms[std::min(S, 4)] * K;
+    if (est_ms) *est_ms = t_small;
     return t_small < t_host;
 }
 

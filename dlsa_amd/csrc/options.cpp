@@ -8,7 +8,7 @@
 namespace dlsa {
 void set_error(const char* fmt, ...);
 
-static thread_local dlsa_irls_options g_opt = {0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0};
+static thread_local dlsa_irls_options g_opt = {0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0};
 static thread_local bool g_opt_set = false;
 
 struct KnobField { const char* env; size_t off; };
@@ -21,6 +21,7 @@ static const KnobField kIntFields[] = {
     DLSA_KNOB("DLSA_IRLS_SMALL", small),         DLSA_KNOB("DLSA_QN_THREADS", qn_threads),    DLSA_KNOB("DLSA_IRLS_TRACE", trace),
     DLSA_KNOB("DLSA_IRLS_BATCHED", batched),     DLSA_KNOB("DLSA_IRLS_LEAN", lean),           DLSA_KNOB("DLSA_IRLS_SMALL_CLUSTER", small_cluster),
     DLSA_KNOB("DLSA_IRLS_OWN_HESSIAN", own_hessian), DLSA_KNOB("DLSA_IRLS_POOLED_START", pooled_start),
+    DLSA_KNOB("DLSA_IRLS_GRAD_PASSES", grad_passes),
 };
 #undef DLSA_KNOB
 constexpr int kNumIntFields = (int)(sizeof(kIntFields) / sizeof(kIntFields[0]));
@@ -43,7 +44,7 @@ const char* knob(const char* env_name) {
     return getenv(env_name);
 }
 
-dlsa_irls_options irls_options_snapshot() { return g_opt_set ? g_opt : dlsa_irls_options{0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0}; }
+dlsa_irls_options irls_options_snapshot() { return g_opt_set ? g_opt : dlsa_irls_options{0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0}; }
 void irls_options_adopt(const dlsa_irls_options& o) { g_opt = o; g_opt_set = o.struct_bytes != 0; }
 
 // ---- kernel switches (dlsa_kernel_options)
@@ -117,7 +118,7 @@ int dlsa_kernel_set_options(const dlsa_kernel_options* o) {
 
 void dlsa_irls_options_init(dlsa_irls_options* o) {
     if (!o) return;
-    *o = dlsa_irls_options{(int)sizeof(dlsa_irls_options), -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0};
+    *o = dlsa_irls_options{(int)sizeof(dlsa_irls_options), -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0};
 }
 
 int dlsa_irls_set_options(const dlsa_irls_options* o) {

@@ -466,6 +466,7 @@ class IrlsOptions:
     small_cluster: Optional[int] = None     # workgroups per partition of the one-launch kernel, 1..16
     own_hessian: Optional[bool] = None      # wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian
     pooled_start: Optional[bool] = None     # lock step: full-row iterations start from one fit on the leading rows of all partitions
+    grad_passes: Optional[int] = None       # lock step: at most this many gradient-only passes before the Newton passes; 0: none
     freeze_at: Optional[float] = None       # 0: never freeze the factor
 
     def as_c(self):

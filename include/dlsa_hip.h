@@ -168,6 +168,7 @@ typedef struct dlsa_irls_options {
     int small_cluster;   /* workgroups per partition of the one-launch kernel: 1..16; -1 = by the partitions' count    */
     int own_hessian;     /* wide designs: Newton steps preconditioned by the partition's own reduced-precision Hessian */
     int pooled_start;    /* lock step: full-row iterations start from ONE fit on the leading rows of all partitions together */
+    int grad_passes;     /* lock step: at most this many gradient-only passes (pooled Hessian) before the Newton passes; 0 = none; -1 = 4 */
     double freeze_at;    /* freeze the factor once steps are below this multiple of max(1, |beta|); 0 = never; < 0 = automatic (1.0) */
 } dlsa_irls_options;
 /* Kernel switches outside the IRLS driver (round 5): which build of a kernel runs -- never what it returns.  Per thread, like

@@ -145,22 +145,25 @@ def test_max_iter_means_full_row_iterations_on_every_driver(eng):
     assert all(s != 0 for s in short["status"]) and short["n_iter"] == [1] * K
 
 
-@pytest.mark.parametrize("p,K,nk,icpt", [(100, 40, 20000, False), (64, 24, 30000, True), (99, 16, 25000, False)])
-def test_pooled_start_changes_the_path_not_the_result(eng, orc, p, K, nk, icpt):
-    """round 5: the full-row iterations of a lock-step call start from ONE fit on the leading rows of all partitions together
-    (dlsa_irls_options.pooled_start) instead of every partition's own subsample MLE: fewer full-row iterations, the same MLEs and
-    Hessians (models.py:110-131 per partition), also against the oracle."""
+@pytest.mark.parametrize("p,K,nk,icpt,tol", [(100, 40, 20000, False, 1e-13), (64, 24, 30000, True, 1e-10), (99, 40, 25000, False, 1e-13)])
+def test_pooled_start_changes_the_path_not_the_result(eng, orc, p, K, nk, icpt, tol):
+    """round 5: the full-row iterations of a lock-step call start from ONE fit on a few leading rows of all partitions together
+    (dlsa_irls_options.pooled_start), followed by gradient-only passes whose steps use the pooled Hessian (grad_passes), instead
+    of every partition's own subsample MLE: fewer Newton passes, the same MLEs and Hessians (models.py:110-131 per partition),
+    also against the oracle."""
     import dlsa_amd
     X, y = eng.synth(9100 + p, 0, K * nk, p, kind=eng.SYNTH_GAUSSIAN)
     offs = [k * nk for k in range(K + 1)]
     res = {}
-    for pooled in (True, False):
-        res[pooled] = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, part_offsets=offs, batched=True, small=False, pooled_start=pooled)
-        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and res[pooled].status == [0] * K
-    a, b = res[True], res[False]
+    for name, opt in (("pooled+grad", dict(pooled_start=True)), ("pooled", dict(pooled_start=True, grad_passes=0)), ("own", dict(pooled_start=False))):
+        res[name] = dlsa_amd.fit_logistic_partitions(X, y, fit_intercept=icpt, part_offsets=offs, tol=tol, batched=True, small=False, **opt)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED and res[name].status == [0] * K
+    a, b, c = res["pooled+grad"], res["pooled"], res["own"]
     for key in ("coef", "Sig_inv", "Sig_invMcoef"):
-        assert rel_inf(getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy()) < 1e-10, key
-    assert max(a.n_iter) <= max(b.n_iter), (a.n_iter, b.n_iter)
+        assert rel_inf(getattr(a, key).cpu().numpy(), getattr(c, key).cpu().numpy()) < 1e-10, key
+        assert rel_inf(getattr(b, key).cpu().numpy(), getattr(c, key).cpu().numpy()) < 1e-10, key
+    assert max(a.n_iter) < max(b.n_iter) <= max(c.n_iter), (a.n_iter, b.n_iter, c.n_iter)     # Newton passes: the gradient-only ones are not counted
+    assert max(a.n_iter) <= 3
     k = K // 2
     co, smc, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy(), icpt)
     assert rel_inf(a.coef[k].cpu().numpy(), co) < 1e-10 and rel_inf(a.Sig_inv[k].cpu().numpy(), sig) < 1e-10
