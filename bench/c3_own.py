@@ -3,6 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from dlsa_amd import _lib
+if os.environ.get("DLSA_AB_LIB"):          # same-box A/B of a build variant
+    _lib.LIB_PATH = os.path.abspath(os.environ["DLSA_AB_LIB"])
 from dlsa_amd import engine
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 nk = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000

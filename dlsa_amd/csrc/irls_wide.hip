@@ -19,6 +19,14 @@
 #include "common.h"
 #include <algorithm>
 
+#ifndef DLSA_IMG_F16
+#define DLSA_IMG_F16 0
+#endif
+#if DLSA_IMG_F16
+#define WIDE_MFMA "v_mfma_f32_32x32x16_f16"
+#else
+#define WIDE_MFMA "v_mfma_f32_32x32x16_bf16"
+#endif
 namespace dlsa {
 
 typedef __bf16 wide_bf16x8 __attribute__((ext_vector_type(8)));
@@ -101,10 +109,10 @@ __global__ __launch_bounds__(256, 1) void wide_syrk_kernel(const unsigned* __res
             if (t + 2 < T) b[(t + 2) % 3] = frag(st, offB[t + 2]);
             // (the MFMAs as asm statements with the accumulator TIED to an AGPR tuple -- the last of 17 to VGPRs, there are 256 AGPRs: as
             // builtins hipcc rotates the loop-carried accumulators through v_accvgpr_read / _write every trip)
-            if (t <= D0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0[t]) : "v"(a0), "v"(b[t % 3]));
+            if (t <= D0) asm volatile(WIDE_MFMA " %0, %1, %2, %0" : "+a"(acc0[t]) : "v"(a0), "v"(b[t % 3]));
             if (t >= NWV && t <= NWV + D1) {
-                if (D0 + 1 + t - NWV < 16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1[t - NWV]) : "v"(a1), "v"(b[t % 3]));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1[t - NWV]) : "v"(a1), "v"(b[t % 3]));
+                if (D0 + 1 + t - NWV < 16) asm volatile(WIDE_MFMA " %0, %1, %2, %0" : "+a"(acc1[t - NWV]) : "v"(a1), "v"(b[t % 3]));
+                else asm volatile(WIDE_MFMA " %0, %1, %2, %0" : "+v"(acc1[t - NWV]) : "v"(a1), "v"(b[t % 3]));
             }
         }
     };

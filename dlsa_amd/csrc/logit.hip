@@ -78,9 +78,17 @@ struct LogitArgs {
 typedef __bf16 logit_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float logit_f2v __attribute__((ext_vector_type(2)));
 typedef unsigned logit_u4v __attribute__((ext_vector_type(4)));
+#ifndef DLSA_IMG_F16
+#define DLSA_IMG_F16 0
+#endif
+typedef _Float16 logit_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned logit_pack_bf16(float lo, float hi) {
     const logit_f2v v = {lo, hi};
+#if DLSA_IMG_F16
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, logit_f16x2));
+#else
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, logit_bf16x2));
+#endif
 }
 template <int RB, int I>
 __device__ __forceinline__ void logit_bcast_rows(float swf, float (&sw)[RB]) {
