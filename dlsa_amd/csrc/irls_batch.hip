@@ -50,7 +50,7 @@ constexpr int BATCH_SLAB_ROWS = 24576;          // a partition longer than this 
 
 struct BatchState {            // per partition, device
     double ll_prev, dprev;     // dprev: the previous gradient-only step (its ratio to the next one is the contraction rate)
-    int have_prev, halvings, iters, evals, last_pass, status;
+    int have_prev, halvings, iters, evals, last_pass, status, restarted;
 };
 
 // H, g, loglik of every live partition from its slabs' partials (fixed order over the slabs: bit-reproducible)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
                                                            double* __restrict__ prev, double* __restrict__ stepv, BatchState* __restrict__ st,
                                                            int* __restrict__ active, int* __restrict__ n_live, double* __restrict__ coef,
                                                            double* __restrict__ smc, double* __restrict__ loglik, int* __restrict__ n_iter,
-                                                           int* __restrict__ status, int phase_a, double etarget) {
+                                                           int* __restrict__ status, int phase_a, double etarget, int may_restart) {
     // phase_a: the cold start on the partitions' leading rows -- a partition that ends there writes no outputs (a failed one goes back
     // to beta = 0): batch_restart_kernel then opens the full-row phase from the subsample MLEs
     const int k = blockIdx.x, j = threadIdx.x;
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
     } else {
         const double dmax = stats[3 * k], bmax = stats[3 * k + 1], flag = stats[3 * k + 2];
         ++s.iters;
-        if (flag == 1.0) end = DLSA_PART_NOT_SPD;
+        // (gradient-only phase: a step beyond the iterate's own size means the pooled Hessian is no stand-in for this partition's --
+        // not taken; the Newton phase goes on from here)
+        if (phase_a == 2 && !(dmax <= fmax(1.0, bmax))) { end = DLSA_PART_OK; stepped = true; }
+        else if (flag == 1.0) end = DLSA_PART_NOT_SPD;
         else if (flag == 2.0 || !isfinite(dmax)) end = DLSA_PART_NAN;
         else if (dmax <= tol * fmax(1.0, bmax)) end = DLSA_PART_OK;
         else {
@@ -126,6 +129,13 @@ __global__ __launch_bounds__(128) void batch_update_kernel(int p, double tol, in
                 s.dprev = dmax;
             }
         }
+    }
+    if (!phase_a && may_restart && !s.restarted && (end == DLSA_PART_NOT_SPD || end == DLSA_PART_NAN)) {
+        // the start phases left this partition somewhere Newton's method cannot go on from: once more from beta = 0, as a call
+        // without them would have started (a partition without a finite MLE fails again, and is reported)
+        if (j < p) bk[j] = 0.0;
+        s.have_prev = 0; s.halvings = 0; s.iters = 0; s.evals = 0; s.last_pass = 0; s.ll_prev = 0.0; s.restarted = 1;
+        end = -1;
     }
     if (end >= 0 && phase_a) {
         if (j < p && !stepped) bk[j] = end == DLSA_PART_OK ? bk[j] + dk[j] : 0.0;       // (a start phase takes its last, small step too)
@@ -156,7 +166,7 @@ __global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     BatchState s = st[k];
-    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0; s.iters = 0; s.dprev = 0.0;
+    s.have_prev = 0; s.halvings = 0; s.evals = 0; s.last_pass = 0; s.status = 0; s.ll_prev = 0.0; s.iters = 0; s.dprev = 0.0; s.restarted = 0;
     st[k] = s;
     active[k] = 1;
 }
@@ -408,6 +418,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     DLSA_BATCH_CHECK(hipMemsetAsync(d_step, 0, pb, stream));
 
     const int cap = 2 * max_iter + 66;
+    bool used_start = false;                        // the Newton phase does not begin at beta = 0
     const char* trace_env = knob("DLSA_IRLS_TRACE");
     const bool trace = trace_env && atoi(trace_env) != 0;
     int live = K;
@@ -417,7 +428,9 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
     auto run_phase = [&](const FusedSlab* tab, int ntab, const int* begin, double ptol, int in_a, int groups, int grad_passes) -> int {
         const int nprob = groups ? 1 : K, nunpack = groups ? groups : K;
         // (the start phases are the driver's own: the caller's max_iter bounds the full-row Newton iterations only)
-        const int iter_cap = in_a ? std::max(max_iter, 30) : max_iter, pass_cap = grad_passes ? grad_passes : in_a ? 2 * iter_cap + 66 : cap;
+        // -- and a start phase that has not settled in 12 iterations (a healthy fit from zero takes 4-6 to a step of 3e-2) is given up: its
+        // relative step test is fooled by an estimate that grows without bound (separable rows: steps of 0.5 on |beta| -> 50)
+        const int iter_cap = in_a ? 12 : max_iter, pass_cap = grad_passes ? grad_passes : in_a ? 40 : cap;
         live = nprob;
         for (int it = 0; it < pass_cap && live > 0; ++it) {
             int r = irls_pass_batched_launch(X, pitch, ylab, d_beta, groups ? 0 : p, pdata, intercept, tab, ntab, d_active, d_partial, d_gpart, d_clk, stream,
@@ -435,7 +448,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
             if (hipMemsetAsync(d_live, 0, sizeof(int), stream) != hipSuccess) return DLSA_ERR_HIP;
             hipLaunchKernelGGL(batch_update_kernel, dim3(nprob), dim3(128), 0, stream, p, ptol, iter_cap, (const double*)Sig_inv, (const double*)d_ll,
                                (const double*)d_delta, (const double*)d_stats, d_beta, d_prev, d_step, d_state, d_active, d_live, coef,
-                               Sig_invMcoef, d_llout, d_iter, d_status, grad_passes ? 2 : in_a, ptol);
+                               Sig_invMcoef, d_llout, d_iter, d_status, grad_passes ? 2 : in_a, ptol, used_start ? 1 : 0);
             if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&live, d_live, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
                 hipStreamSynchronize(stream) != hipSuccess) {
                 set_error("irls_fit (batched): a launch or the read-back of the live count failed");
@@ -463,6 +476,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         DLSA_BATCH_CHECK(hipMemcpyAsync(&sp, d_state, sizeof(BatchState), hipMemcpyDeviceToHost, stream));
         DLSA_BATCH_CHECK(hipStreamSynchronize(stream));
         started = live == 0 && sp.status == DLSA_PART_OK;
+        used_start = started;
         if (started) hipLaunchKernelGGL(batch_pool_spread_kernel, dim3((unsigned)(((int64_t)K * p + 255) / 256)), dim3(256), 0, stream, K, p, d_beta);
         else DLSA_BATCH_CHECK(hipMemsetAsync(d_beta, 0, pb, stream));
         hipLaunchKernelGGL(batch_restart_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, K, d_state, d_active);
@@ -482,6 +496,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         }
     }
     if (phase_a && !started) {
+        used_start = true;
         // (the subsample's MLE is ~2 sqrt(p / rows) away from the partition's own whatever happens here: a step of 3e-2 is close enough --
         // round 5, same box: 1000 x 2e4 x 100 39.6 -> 37.0 ms, 200 x 1e5 x 100 31.6 -> 30.7, the full-row iterations unchanged at 5)
         rc = run_phase(d_slabsA, nslabA, d_beginA, std::max(tol, 3e-2), 1, 0, 0);
