@@ -196,7 +196,7 @@ def test_pooled_fit_that_fails_falls_back_to_the_subsample_start(eng, orc):
 def test_pooled_start_with_partitions_that_differ(eng, orc):
     """partitions drawn from DIFFERENT coefficient vectors (rows not exchangeable: the pooled estimate is nobody's MLE), one of them
     perfectly separable: the pooled start costs iterations, never the result -- every partition ends at its own MLE (oracle)"""
-    p, K, nk = 64, 12, 24000
+    p, K, nk = 64, 24, 24000
     X, _ = eng.synth(515, 0, K * nk, p, kind=eng.SYNTH_GAUSSIAN)
     g = torch.Generator(device="cpu").manual_seed(5)
     y = torch.empty(K * nk, dtype=torch.float64, device=X.device)
@@ -206,11 +206,14 @@ def test_pooled_start_with_partitions_that_differ(eng, orc):
         u = torch.rand(nk, generator=g, dtype=torch.float64).to(X.device)
         y[k * nk:(k + 1) * nk] = (u < torch.sigmoid(eta)).double()
     y[5 * nk:6 * nk] = (X[5 * nk:6 * nk, 3] > 0).double()
+    X = X.clone()
+    X[2 * nk:3 * nk] *= 3.0                          # ... and different scales: the pooled Hessian is 9x off for partition 2, 16x for 7
+    X[7 * nk:8 * nk] *= 0.25
     offs = [k * nk for k in range(K + 1)]
-    with eng.irls_options(batched=True, small=False, pooled_start=True):
+    with eng.irls_options(batched=True, small=False, pooled_start=True, trace=True):
         b = eng.irls_fit(X, y, offs, max_iter=30)
         assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED
     assert b["status"][5] != 0 and [s for k, s in enumerate(b["status"]) if k != 5] == [0] * (K - 1)
-    for k in (0, 4, 11):
+    for k in (0, 2, 4, 7, 11):
         co, _, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
         assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
