@@ -333,7 +333,7 @@ int irls_batched_fit(const double* X, int64_t ldx, const double* y, const int64_
         int64_t rows_pool = 0;
         for (int k = 0; k < K; ++k) rows_pool += std::min<int64_t>(lead(k), rows_host[k]);
         // (a pool of fewer rows than this is no better a start than a partition's own rows, and its Hessian no stand-in)
-        if (rows_pool < std::max<int64_t>(4 * mx, 200 * (int64_t)p)) pooled = false;
+        if (rows_pool < std::max<int64_t>(2 * mx, 200 * (int64_t)p)) pooled = false;      // (10 x 1e6 x 100 with 2.5 rows_max: 25.7 -> 21.6 ms)
         if (pooled) {
             leading_rows(slabsP, nullptr, [&](int k) { return std::min<int64_t>(lead(k), rows_host[k]); });
             int at = 0;
