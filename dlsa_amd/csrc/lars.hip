@@ -813,9 +813,15 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
         for (int j2 = tid; 2 * j2 < m; j2 += LARS_THREADS) {
             const double2* src = reinterpret_cast<const double2*>(a.upart + 2 * j2);
             double2 sum = {0.0, 0.0};
-            for (int q = 0; q < G; ++q) {
-                const double2 v = src[(int64_t)q * (ld / 2)];
-                sum.x += v.x; sum.y += v.y;
+            // (eight loads in flight per trip: as a plain loop every partial waited for its own L2 round trip -- 32 in a row at
+            // p = 2000, 10 of a step's 37 us; the additions keep their order)
+            for (int q0 = 0; q0 < G; q0 += 8) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (q0 + u < G) ? src[(int64_t)(q0 + u) * (ld / 2)] : double2{0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (q0 + u < G) { sum.x += v[u].x; sum.y += v[u].y; }
             }
             xu[2 * j2] = sum.x;
             if (2 * j2 + 1 < m) xu[2 * j2 + 1] = sum.y;
