@@ -922,7 +922,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_grid_kernel(LarsArgs a) {
 }
 
 // Workgroups for the path at width p (measured: p=200 one workgroup 2.6 ms / four 2.9; p=300 5.1 / 4.7; p=500 8.3 ms
-// at 8; p=1000 22 ms at 16; p=2000 74 ms at 32; the grid kernel with ONE workgroup is slower than lars_kernel:
+// at 8; p=1000 22 ms at 16; p=2000 74 ms at 32 (round 5: 66, see the reduce of u); the grid kernel with ONE workgroup is slower than lars_kernel:
 // 4.0 vs 2.6 ms at p=200).  DLSA_LARS_WGS overrides, 1..LARS_MAX_WGS.
 static int lars_workgroups(int p) {
     int wgs = p < 256 ? 1 : (p < 384 ? (LARS_THREADS == 512 ? 8 : 4) : (p < 768 ? 8 : (p < 1536 ? 16 : 32)));   // (512-thread build, p = 260: 3.78 ms at 4, 3.59 at 8)
