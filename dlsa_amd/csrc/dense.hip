@@ -24,6 +24,12 @@ __global__ void axpby_kernel(const double* a, const double* b, double s,
     if (i < n) out[i] = a[i] + s * b[i];
 }
 
+// the end of a Newton iteration in one launch: prev = beta, beta = beta + delta
+__global__ void advance_kernel(double* __restrict__ prev, double* __restrict__ beta, const double* __restrict__ delta, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const double b = beta[i]; prev[i] = b; beta[i] = b + 1.0 * delta[i]; }
+}
+
 // out[e] = sum over included k of in[k*stride + e]   (fixed order)
 __global__ void sum_blocks_kernel(const double* __restrict__ in, int64_t stride, int K,
                                   const int* __restrict__ mask, int64_t count, double* __restrict__ out) {
@@ -95,6 +101,12 @@ int launch_matvec_axpy(const double* A, int64_t lda, const double* x, int p, dou
 
 int launch_step_stats(const double* delta, const double* ref, int p, double* stats, hipStream_t s) {
     hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, s, delta, ref, p, stats);
+    DLSA_HIP_CHECK(hipGetLastError());
+    return DLSA_OK;
+}
+
+int launch_advance(double* prev, double* beta, const double* delta, int n, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3((n + 255) / 256), dim3(256), 0, s, prev, beta, delta, n);
     DLSA_HIP_CHECK(hipGetLastError());
     return DLSA_OK;
 }

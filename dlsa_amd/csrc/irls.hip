@@ -79,6 +79,7 @@ int onehot_logit_pass_impl(const dlsa_onehot_plan* pl, const double* num, int64_
 int onehot_gram_impl(const dlsa_onehot_plan* pl, const double* num, int64_t ldn, const int32_t* codes, int64_t ldc,
                      const double* w, int64_t n, double* H, int64_t ldh, void* ws, size_t ws_bytes, hipStream_t s, bool irls_weights);
 int launch_axpby(const double* a, const double* b, double sc, int n, double* out, hipStream_t s);
+int launch_advance(double* prev, double* beta, const double* delta, int n, hipStream_t s);
 int launch_matvec_axpy(const double* A, int64_t lda, const double* x, int p, double alpha, const double* z, double beta, double* y, hipStream_t s);
 int launch_step_stats(const double* delta, const double* ref, int p, double* stats, hipStream_t s);
 // irls_wide.hip: the logit pass of a wide design that also yields the partition's own Hessian in reduced precision (bf16 products)
@@ -700,8 +701,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
         }
         dprev2 = dprev;
         dprev = h[0];
-        DLSA_HIP_CHECK(hipMemcpyAsync(b.prev, b.beta, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, s));
-        rc = launch_axpby(b.beta, b.delta, 1.0, p, b.beta, s);
+        rc = launch_advance(b.prev, b.beta, b.delta, p, s);              // prev = beta, beta += delta (one launch: a copy + a launch cost ~10 us of gaps per iteration)
         if (rc) return rc;
         ll_prev = ll;
         have_prev = true;
