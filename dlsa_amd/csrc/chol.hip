@@ -383,7 +383,7 @@ __device__ __forceinline__ void cs_sweeps(double (&a)[CS_NS], double& diag, doub
 // Batched form (irls_batch.hip): workgroup b works on matrix b -- A + b sA, vectors + b sV, Hinv + b sH, stats + b sS -- and leaves at
 // once when active[b] == 0.  The single-matrix launch passes zero strides and no mask.
 struct CsBatch { int64_t sA, sV, sH, sS; const int* active; };
-__global__ __launch_bounds__(256) void spd_inverse_small_kernel(const double* __restrict__ A_, int64_t lda, int p,
+__global__ __launch_bounds__(256, 2) void spd_inverse_small_kernel(const double* __restrict__ A_, int64_t lda, int p,
                                                                 const double* __restrict__ rhs_, const double* __restrict__ ref_,
                                                                 double* __restrict__ Hinv_, double* __restrict__ xout_,
                                                                 double* __restrict__ stats_, CsBatch bt) {
