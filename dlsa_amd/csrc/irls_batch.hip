@@ -68,7 +68,14 @@ __global__ __launch_bounds__(256) void batch_unpack_kernel(const double* __restr
         const int i = e / p, j = e - i * p;
         if (i > j) continue;
         double s = 0.0;
-        for (int sl = s0; sl < s1; ++sl) s += partial[(int64_t)sl * PP * PP + (int64_t)i * PP + j];
+        for (int sl = s0; sl < s1; sl += 4) {            // (four slabs' loads in flight, added in their order)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = sl + u < s1 ? partial[(int64_t)(sl + u) * PP * PP + (int64_t)i * PP + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sl + u < s1) s += v[u];
+        }
         Hk[om(i) * p + om(j)] = s;
         Hk[om(j) * p + om(i)] = s;
     }
@@ -175,8 +182,16 @@ __global__ void batch_restart_kernel(int K, BatchState* __restrict__ st, int* __
 __global__ __launch_bounds__(256) void batch_pool_sum_kernel(int G, int p, double* __restrict__ H, double* __restrict__ g, double* __restrict__ ll) {
     const int64_t pp = (int64_t)p * p, e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < pp) {
+        // (eight loads in flight per trip, the additions in their order: as a plain loop every group waited for its own L2 round trip)
         double s = H[e];
-        for (int q = 1; q < G; ++q) s += H[(int64_t)q * pp + e];
+        for (int q0 = 1; q0 < G; q0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q0 + u < G ? H[(int64_t)(q0 + u) * pp + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + u < G) s += v[u];
+        }
         H[e] = s;
     } else if (e - pp <= p) {
         const int j = (int)(e - pp);
