@@ -4,8 +4,24 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dlsa_amd import engine
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from lars_fuzz import problem, rel_inf
+
+
+def rel_inf(a, b):
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def problem(p, rho, seed):
+    """(the generator of tests/lars_fuzz.py, restated: bench scripts do not import the oracle)"""
+    rng = np.random.default_rng(seed)
+    n = 6 * p + 4
+    L = rng.standard_normal((3, p))
+    X = np.sqrt(1 - rho) * rng.standard_normal((n, p)) + np.sqrt(rho) * (rng.standard_normal((n, 3)) @ L)
+    S = X.T @ ((rng.random(n) * 0.25)[:, None] * X)
+    b = rng.standard_normal(p)
+    if rng.random() < 0.3:
+        b[rng.random(p) < 0.5] *= 1e-3
+    return S, b, n
+
 
 for p in [int(v) for v in sys.argv[1:]] or [1100, 1536, 2000]:
     for intercept, typ in ((False, "lar"), (True, "lasso")):

@@ -73,7 +73,7 @@ def evidence_path(round_tag, tag):
     return os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (round_tag, tag))
 
 
-ROUNDS = ("r05", "r04")           # newest first: a kernel untouched since an earlier round keeps that round's evidence
+ROUNDS = ("r06", "r05", "r04")           # newest first: a kernel untouched since an earlier round keeps that round's evidence
 
 
 def latest_evidence_path(tag):

@@ -404,7 +404,7 @@ struct IrlsData {
     // optional (wide designs, irls_wide.hip): the logit pass that ALSO yields the partition's own Hessian in reduced precision -- a
     // preconditioner for the steps, never a result
     std::function<int(const double* beta, int64_t nrows, double* w, double* g, double* ll, double* Happrox, const IrlsBuffers& b, hipStream_t s)> approx;
-    std::function<bool(int64_t nrows)> approxable;
+    std::function<bool(int64_t nrows, size_t ws_pass_bytes)> approxable;      // (the wide pass's scratch must fit the pass workspace this call was sized for)
 };
 
 // Newton iterations on rows [0, n) of (X, y) starting from the beta already in b.beta.
@@ -414,10 +414,28 @@ struct IrlsData {
 // One 8-byte read-back; used where a failed factor would otherwise only surface as NaN iterates.
 // The per-iteration read-back (four doubles) lands in PINNED host memory, one slot per host thread (a partition chain is a thread):
 // a copy into pageable memory goes through the runtime's staging path, ~30 us more per iteration -- and a config-3 fit makes ~130 of them.
+// Slots are pooled for the PROCESS: a chain's thread lives for one fit call, so a thread_local pointer would allocate (and leak) a
+// pinned page per chain and call.  A thread borrows a slot for its lifetime and hands it back when it exits.
+struct ReadbackSlot {
+    double* p = nullptr;
+    static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }            // (never destroyed: threads may exit during process teardown)
+    static std::vector<double*>& idle() { static std::vector<double*>* v = new std::vector<double*>; return *v; }
+    ReadbackSlot() {
+        {
+            std::lock_guard<std::mutex> g(mu());
+            if (!idle().empty()) { p = idle().back(); idle().pop_back(); }
+        }
+        if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    }
+    ~ReadbackSlot() {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu());
+        idle().push_back(p);
+    }
+};
 static double* readback_slot() {
-    static thread_local double* slot = nullptr;
-    if (!slot && hipHostMalloc((void**)&slot, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; }
-    return slot;          // (kept for the thread's lifetime; nullptr: the caller falls back to its stack buffer)
+    static thread_local ReadbackSlot slot;
+    return slot.p;          // (nullptr: the caller falls back to its stack buffer)
 }
 
 static int factor_ok(const IrlsBuffers& b, hipStream_t s, bool* ok) {
@@ -481,7 +499,7 @@ static int newton_run(const IrlsData& d, int64_t n, int p, double tol, int max_i
     // (only once the iterate is near the MLE -- the last step at most 0.2 max(1, |beta|): far from it, e.g. the first iterations from
     // beta = 0, the weights move so much between iterates that refinement on the previous factor's inverse does not converge, and
     // exact Hessians are the right tool)
-    const bool can_approx = (env_own ? atoi(env_own) != 0 : true) && d.approx && d.approxable && b.Ha && d.approxable(n) && inv_enabled(p);
+    const bool can_approx = (env_own ? atoi(env_own) != 0 : true) && d.approx && d.approxable && b.Ha && d.approxable(n, b.ws_pass_bytes) && inv_enabled(p);
     double near_scale = 1.0;          // max(1, |beta|) of the last completed iteration
     bool have_Ha = false, approx_ok = true, want_refresh = false;
     constexpr int kRefine = 3;
@@ -1183,7 +1201,7 @@ int dlsa_irls_fit_f64(const double* X, int64_t ldx, const double* y, const int64
         d.approx = [=](const double* beta, int64_t nrows, double* w, double* g, double* ll, double* Ha, const IrlsBuffers& b, hipStream_t s) {
             return irls_wide_pass_impl(Xk, ldx, yk, beta, nrows, p, 0, w, g, ll, Ha, p, b.ws_pass, b.ws_pass_bytes, s);
         };
-        d.approxable = [=](int64_t nrows) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, ldx, nrows, p, 0); };
+        d.approxable = [=](int64_t nrows, size_t wsb) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, ldx, nrows, p, 0) && irls_wide_workspace_bytes(nrows, p, 0) <= wsb; };
         return d;
     };
     int64_t max_rows = 0;
@@ -1290,7 +1308,7 @@ int dlsa_irls_fit_ex_f64(const double* X, int64_t ldx, const double* y, const in
             if (intercept) *b.border_rows = -1;             // (this pass rewrites b.w: the border a logit pass left belongs to other weights)
             return irls_wide_pass_impl(Xk, pitch, yk, beta, nrows, p, intercept, w, g, ll, Ha, pe, b.ws_pass, b.ws_pass_bytes, s);
         };
-        d.approxable = [=](int64_t nrows) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, pitch, nrows, p, intercept); };
+        d.approxable = [=](int64_t nrows, size_t wsb) { return nrows <= kWideMaxRows && irls_wide_eligible(Xk, pitch, nrows, p, intercept) && irls_wide_workspace_bytes(nrows, p, intercept) <= wsb; };
         return d;
     };
     return irls_fit_core(make_data, [=](int64_t rows) { return std::max(dense_pass_bytes(rows, p), dense_pass_bytes(rows, pe)); },

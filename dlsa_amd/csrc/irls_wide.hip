@@ -205,11 +205,9 @@ template <int NB>
 static int wide_syrk_launch(const unsigned* img, int64_t nchunks, float* hpart, hipStream_t s) {
     constexpr int PW = (NB + 3) / 4, STG = 4 * PW * 1024, NS = (WIDE_RING_BYTES / STG) < 16 ? (WIDE_RING_BYTES / STG) : 16;
     constexpr size_t shm = (size_t)NS * STG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DLSA_HIP_CHECK(hipFuncSetAttribute((const void*)wide_syrk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        attr_set = true;
-    }
+    // (set on every launch, as the other large-LDS kernels do: the attribute belongs to the current device's function object, and
+    // chain threads launch concurrently)
+    DLSA_HIP_CHECK(hipFuncSetAttribute((const void*)wide_syrk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((wide_syrk_kernel<NB>), dim3(WIDE_WGS), dim3(256), shm, s, img, nchunks, hpart);
     return DLSA_OK;
 }

@@ -361,8 +361,8 @@ def irls_pass(X, y, beta, want_w=False):
 def newton_wide_pass(X, y, beta, fit_intercept=False, want_w=False):
     """The wide Newton pass (dlsa_newton_wide_pass_f64): g, loglik (and w) of the logit pass at beta plus, from the SAME read of
     the rows, the reduced-precision Hessian that preconditions the fit's Newton steps (bf16 products, fp32 accumulation; never a
-    result).  Returns (H_approx, g, loglik, w or None); raises when the shape is not served (121 <= p + intercept <= 512,
-    >= 32768 aligned rows)."""
+    result: exported for diagnostics and tests).  Returns (H_approx, g, loglik, w or None); raises when the shape is not served
+    (121 <= p + intercept <= 512, >= 32768 rows; any pitch or alignment -- unaligned / odd-pitch rows take the scalar-load form)."""
     lib = _lib.load()
     _require_gpu(X, y, beta)
     _f64(X, "X"); _f64(y, "y"); _f64(beta, "beta")

@@ -234,8 +234,9 @@ int dlsa_loglik_icpt_f64(const double* X, int64_t ldx, const double* y, int64_t 
  * w_out (nullable), g, loglik exactly as dlsa_logit_pass[_icpt]_f64; H_approx = [1 | X]' diag(w) [1 | X] from bf16-rounded
  * sqrt(w) x products accumulated in fp32 (relative error ~1e-3 per entry, far less in the spectrum) -- (p + intercept)^2 doubles,
  * both triangles, intercept first.  H_approx is the PRECONDITIONER of the fit's Newton steps (dlsa_irls_fit*_f64 uses it when a
- * partition is eligible); Sig_inv is never taken from it.  dlsa_newton_wide_eligible: >= 32768 rows, 16-byte aligned rows of
- * even pitch. */
+ * partition is eligible); Sig_inv is never taken from it -- the entry point exports H_approx for diagnostics and tests only.
+ * dlsa_newton_wide_eligible: 121 <= p + intercept <= 512, >= 32768 rows, ldx >= p; ANY pitch and alignment is served (rows that are
+ * not 16-byte aligned with an even pitch take the kernel's scalar-load form: same results, slower). */
 size_t dlsa_newton_wide_workspace_bytes(int64_t n, int p, int intercept);
 int dlsa_newton_wide_eligible(const double* X, int64_t ldx, int64_t n, int p, int intercept);
 int dlsa_newton_wide_pass_f64(const double* X, int64_t ldx, const double* y, const double* beta, int64_t n, int p, int intercept,

@@ -1,4 +1,5 @@
-"""Randomised LARS / lasso paths outside the suite: python bench/lars_fuzz.py [cases] [seed] [wide]      (wide = 1: widths up to 1020)
+"""Randomised LARS / lasso paths: python tests/lars_fuzz.py [cases] [seed] [wide]      (wide = 1: widths 400 ... 1020; wide = 2: 1021 ... 2000)
+(lives under tests/ because it checks against the oracle; run with 30 cases by tests/test_gpu_fuzz_smoke.py, with hundreds outside the suite)
 Every case runs lars_q.hip (default build for its width, plus one forced build) and lars.hip (DLSA_LARS_Q=0) and compares the whole
 path, beta0, AIC and BIC with the oracle's restatement of lsa.py:90-212."""
 import os, sys, time
@@ -39,8 +40,10 @@ def main():
     t0 = time.time()
     for c in range(cases):
         p = int(rng.choice([rng.integers(1, 30), rng.integers(30, 110), rng.integers(110, 260), rng.integers(260, 420)]))
-        if len(sys.argv) > 3 and sys.argv[3] != "0":
+        if len(sys.argv) > 3 and sys.argv[3] == "1":
             p = int(rng.choice([rng.integers(400, 520), rng.integers(520, 1021)]))
+        if len(sys.argv) > 3 and sys.argv[3] == "2":
+            p = int(rng.choice([rng.integers(1021, 1300), rng.integers(1300, 2001)]))
         intercept = bool(rng.random() < 0.4) and p > 1
         typ = "lasso" if rng.random() < 0.6 else "lar"
         rho = float(rng.choice([0.0, 0.5, 0.9, 0.98]))

@@ -217,3 +217,28 @@ def test_pooled_start_with_partitions_that_differ(eng, orc):
     for k in (0, 2, 4, 7, 11):
         co, _, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
         assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
+
+
+def test_pooled_start_with_row_counts_that_differ_by_100x(eng, orc):
+    """the gradient-only passes step with (rows_k / rows_pool) x the pooled Hessian (irls_batch.hip `pool_scale`): partitions of
+    3 000 and 300 000 rows in ONE call scale it by factors 100x apart; every partition still ends at its own MLE (oracle), and
+    the lock step is the driver that ran"""
+    p = 64
+    rows = [3000, 300000, 3000, 150000, 6000, 300000, 3100, 30000, 3000, 299999, 4000, 3000]
+    K = len(rows)
+    offs = [0]
+    for r in rows:
+        offs.append(offs[-1] + r)
+    X, y = eng.synth(717, 0, offs[-1], p, kind=eng.SYNTH_GAUSSIAN)
+    with eng.irls_options(batched=True, small=False, pooled_start=True):
+        b = eng.irls_fit(X, y, offs)
+        assert eng.irls_last_fit_path() == eng.IRLS_PATH_BATCHED
+    with eng.irls_options(batched=False, small=False):
+        c = eng.irls_fit(X, y, offs)
+    assert b["status"] == [0] * K and c["status"] == [0] * K
+    assert rel_inf(b["coef"].cpu().numpy(), c["coef"].cpu().numpy()) < 1e-10
+    assert rel_inf(b["Sig_inv"].cpu().numpy(), c["Sig_inv"].cpu().numpy()) < 1e-10
+    for k in (0, 1, 4, 9):
+        co, smc, sig = orc.logistic_model_block(X[offs[k]:offs[k + 1]].cpu().numpy(), y[offs[k]:offs[k + 1]].cpu().numpy())
+        assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10 and rel_inf(b["Sig_inv"][k].cpu().numpy(), sig) < 1e-10
+        assert rel_inf(b["Sig_invMcoef"][k].cpu().numpy(), smc) < 1e-10

@@ -170,9 +170,10 @@ def _run_bench(extra_env, *argv):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, stdout=subprocess.PIPE,
-                        stderr=subprocess.PIPE, text=True, timeout=900)
-    assert pr.returncode == 0, pr.stderr[-3000:]
+    # (--watchdog-seconds: a rank that hangs prints its Python stacks and exits; the message lands in the assertion below)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--watchdog-seconds", "150"] + list(argv), env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-6000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, pr.stdout
     return json.loads(lines[0])
@@ -201,6 +202,14 @@ def test_bench_single_gpu_line_keeps_its_contract():
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    # round 6: the slow-start guards and the fit legs are part of the default line
+    assert out["warmup_extra_steps"] >= 1 and out["first_step_ms"] > 0 and out["median_step_ms"] > 0
+    assert abs(out["first_over_median"] - out["first_step_ms"] / out["median_step_ms"]) < 1e-12 and out["first_over_median"] < 1.5
+    e2e = out["extra"]["end_to_end_fit"]
+    assert e2e["status_ok"] and e2e["partitions_per_rank"] == 25 and e2e["fit_path"] == 0 and e2e["map_s"] > 0
+    assert e2e["k1"]["status_ok"] and e2e["k1"]["partitions_per_rank"] == 1 and e2e["k1"]["passes_per_partition"]["max"] >= 1
+    ls = e2e["lock_step"]
+    assert ls["status_ok"] and ls["fit_path"] == 2 and ls["partitions"] == 1000 and 0 < ls["fit_s"] < 1.0
 
 
 def test_bench_refuses_world_size_mismatch():

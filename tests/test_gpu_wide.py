@@ -125,3 +125,26 @@ def test_fit_with_own_hessian_equals_fit_without_and_oracle(eng, orc, p, K, nk, 
         assert rel_inf(b["coef"][k].cpu().numpy(), co) < 1e-10
         assert rel_inf(b["Sig_inv"][k].cpu().numpy(), so) < 1e-10
         assert rel_inf(b["Sig_invMcoef"][k].cpu().numpy(), smo) < 1e-10
+
+
+def test_unequal_partitions_straddling_the_own_hessian_row_limit(eng):
+    """a call whose LARGEST partition is beyond the own-Hessian row limit (4e6 rows: no image scratch in the
+    workspace dlsa_irls_workspace_bytes() sizes for it) that also holds a partition inside the limit used to pick the wide pass for
+    the smaller one and fail it with DLSA_ERR_WORKSPACE.  The gate now also asks whether the pass's scratch fits the workspace of
+    THIS call; the smaller partition falls back to plain logit passes and ends at the same MLE as when it is fitted alone (where it
+    does take the own-Hessian steps)."""
+    p = 130
+    offs = [0, 4_200_000, 8_400_000, 10_500_000]
+    X, y = eng.synth(909, 0, offs[-1], p, kind=eng.SYNTH_GAUSSIAN)
+    r = eng.irls_fit(X, y, offs)
+    assert r["rc"] == 0 and r["status"] == [0, 0, 0], (r["rc"], r["status"])
+    alone = eng.irls_fit(X[offs[2]:], y[offs[2]:], [0, offs[3] - offs[2]])
+    assert alone["status"] == [0]
+    assert rel_inf(r["coef"][2].cpu().numpy(), alone["coef"][0].cpu().numpy()) < 1e-10
+    assert rel_inf(r["Sig_inv"][2].cpu().numpy(), alone["Sig_inv"][0].cpu().numpy()) < 1e-10
+    # i % K partitions of 4 000 001 / 4 000 000 rows with the intercept: the other entry point, the same gate
+    n = 8_000_001
+    ex = eng.irls_fit_ex(X[:n], y[:n], [0, 1], [4_000_001, 4_000_000], row_step=2, fit_intercept=True)
+    assert ex["rc"] == 0 and ex["status"] == [0, 0]
+    H = ex["Sig_inv"][1].cpu().numpy()
+    assert np.all(np.isfinite(H)) and rel_inf(H, H.T) < 1e-13
