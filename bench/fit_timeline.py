@@ -1,5 +1,5 @@
 """Kernel timeline of ONE fit (the last of several) under rocprofv3 --kernel-trace: every kernel in launch order with its duration
-and the gap before it.   rocprofv3 --kernel-trace -d gpurun_out/ft -o ft --output-format csv -- python3 bench/fit_timeline.py run n p [K]
+and the gap before it.   rocprofv3 --kernel-trace -d gpurun_out/ft -o ft --output-format csv -- python3 bench/fit_timeline.py run n p [K [chains]]      (chains = 1: one partition chain, no stream sharing)
    python3 bench/fit_timeline.py show gpurun_out/ft/*/ft_kernel_trace.csv"""
 import csv, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,12 +10,16 @@ if sys.argv[1] == "run":
     K = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     X, y = engine.synth(20260101, 0, n, p, kind=engine.SYNTH_GAUSSIAN)
     offs = [n * k // K for k in range(K + 1)]
-    for _ in range(4):
+    import contextlib, time
+    opt = engine.irls_options(chains=int(sys.argv[5])) if len(sys.argv) > 5 else contextlib.nullcontext()
+    with opt:
+        for _ in range(4):
+            t = time.perf_counter(); engine.irls_fit(X, y, offs); torch.cuda.synchronize()
+            print("fit %.2f ms (under the tracer)" % ((time.perf_counter() - t) * 1e3), file=sys.stderr)
+        marker = torch.zeros(7, device="cuda") + 1.0; torch.cuda.synchronize()       # (a torch kernel separates the fits in the trace)
         engine.irls_fit(X, y, offs); torch.cuda.synchronize()
-    marker = torch.zeros(7, device="cuda") + 1.0; torch.cuda.synchronize()       # (a torch kernel separates the fits in the trace)
-    engine.irls_fit(X, y, offs); torch.cuda.synchronize()
 else:
-    rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
+    rows = sorted(csv.DictReader(open((sys.argv[2] if os.path.exists(sys.argv[2]) else __import__("glob").glob(sys.argv[2])[0]))), key=lambda r: int(r["Start_Timestamp"]))
     last_torch = max(i for i, r in enumerate(rows) if "dlsa" not in r["Kernel_Name"] and "rocclr" not in r["Kernel_Name"])
     rows = rows[last_torch + 1:]
     prev = None

@@ -74,6 +74,10 @@ constexpr int narrow_buf_elems(int nt, int kc) { return kc * narrow_pitch(nt) + 
 // and copies all of them into AGPRs and back around every k-step (448 v_accvgpr moves per 28 MFMAs: measured no
 // faster than the tile-list kernel).  Named registers stay where the MFMAs want them.
 #include "gram_narrow_asm.inc"
+#ifndef DLSA_NARROW_DIAG4
+#define DLSA_NARROW_DIAG4 0           // 1 (round 6, measured, NOT the default -- same-box A/B: MFMA busy cycles -6.6 % at p = 100, -10.7 % at p = 50 as planned, launch time +-1 %, +2.5 % at p = 112; profiles/r06_narrow_diag4.txt): diagonal tiles on three v_mfma_f64_4x4x4_4b_f64 against column-rotated fragments (48 pipe cycles instead of 64; tools/gen_gram_narrow_d4_asm.py); 0: one 16x16x4 MFMA per diagonal tile
+#endif
+#include "gram_narrow_d4_asm.inc"
 
 // segments SEG .. NARROW_NSEG - 1 of a k-step's MFMA block, with between(q) issued behind segment q
 template <int NT, int G, int SEG, typename F>
@@ -85,6 +89,18 @@ __device__ __forceinline__ void narrow_kstep_spread(const double (&f)[NT + (G > 
         between(SEG);
         __builtin_amdgcn_sched_barrier(0);
         narrow_kstep_spread<NT, G, SEG + 1>(f, g, bt, between);
+    }
+}
+
+template <int NT, int G, int SEG, typename F>
+__device__ __forceinline__ void narrowd_kstep_spread(const double (&f)[NT + (G > 0 ? 1 : 0)], const double (&g)[NT],
+                                                     const double (&bt)[G > 0 ? G : 1], const double (&r1)[NT], const double (&r2)[NT], F&& between) {
+    if constexpr (SEG < NARROWD_NSEG) {
+        narrowd_kstep_seg<NT, G, SEG>(f, g, bt, r1, r2);
+        __builtin_amdgcn_sched_barrier(0);
+        between(SEG);
+        __builtin_amdgcn_sched_barrier(0);
+        narrowd_kstep_spread<NT, G, SEG + 1>(f, g, bt, r1, r2, between);
     }
 }
 
@@ -156,17 +172,91 @@ __device__ __forceinline__ void narrow_meet_tails(double* lds, int wave, int lan
     }
 }
 
+// ---- DIAG4 layout (tools/gen_gram_narrow_d4_asm.py): off-diagonal tiles o = tj (tj - 1) / 2 + ti in a[8 o : 8 o + 7], then PAIRS:
+// diagonal tile t under rotation s (pair 3 t + s), then the tail accumulators (pair 3 NT + k).
+template <int T, int TEND, typename F>
+__device__ __forceinline__ void narrowd_for_tiles(F&& fn) {
+    if constexpr (T < TEND) {
+        double v[4];
+        narrowd_tile_read<T>(v);
+        fn(T, v);
+        narrowd_for_tiles<T + 1, TEND>(fn);
+    }
+}
+template <int NOFF, int KEND, int K, typename F>
+__device__ __forceinline__ void narrowd_for_pairs(F&& fn) {
+    if constexpr (K < KEND) {
+        fn(K, narrowd_pair_read<8 * NOFF + 2 * K>());
+        narrowd_for_pairs<NOFF, KEND, K + 1>(fn);
+    }
+}
+template <int T0, int T1, int MEETN>
+__device__ __forceinline__ void narrowd_meet(double* lds, int wave, int lane, double* __restrict__ P, int PP) {
+    if constexpr (T0 < T1) {
+        if (wave != 0)
+            narrowd_for_tiles<T0, T1>([&](int t, double (&v)[4]) {
+                double* d = lds + ((wave - 1) * MEETN + (t - T0)) * 256 + lane * 4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            });
+        __syncthreads();
+        if (wave == 0)
+            narrowd_for_tiles<T0, T1>([&](int t, double (&v)[4]) {
+                int tj = 1;
+                while ((tj + 1) * tj / 2 <= t) ++tj;
+                const int ti = t - tj * (tj - 1) / 2;
+                const double* s1 = lds + (t - T0) * 256 + lane * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {     // C/D register r of lane l = C[4r + (l >> 4)][l & 15]
+                    const double sum = ((v[r] + s1[r]) + s1[MEETN * 256 + r]) + s1[2 * MEETN * 256 + r];
+                    P[(int64_t)(ti * 16 + 4 * r + (lane >> 4)) * PP + tj * 16 + (lane & 15)] = sum;
+                }
+            });
+        __syncthreads();
+    }
+}
+// Pair d of lane l (i = l >> 4, b = (l & 15) >> 2, j = l & 3).  d = 3 t + s < 3 NT: H[16 t + 4 b + i][16 t + 4 ((b + s) & 3) + j] -- block
+// (b, (b + s) & 3) of diagonal tile t; a block below the diagonal (b + s >= 4) is the mirror image of one the reduce needs above it
+// (s = 1: (3, 0) -> (0, 3)) or of one another lane group already holds (s = 2: (2, 0), (3, 1)), so it is stored transposed / dropped.
+// d = 3 NT + k, k = gi (NT + 1) + t: H[16 t + 4 b + i][16 NT + 4 gi + j] as narrow_meet_tails.
+// (pairs [K0, K1): as many per meeting pass as three parked copies fit the ring)
+template <int NT, int G, int K0, int K1>
+__device__ __forceinline__ void narrowd_meet_pairs(double* lds, int wave, int lane, double* __restrict__ P, int PP) {
+    constexpr int NOFF = NT * (NT - 1) / 2, NP = K1 - K0;
+    if constexpr (NP <= 0) return;
+    if (wave != 0)
+        narrowd_for_pairs<NOFF, K1, K0>([&](int k, double v) { lds[((wave - 1) * NP + (k - K0)) * 64 + lane] = v; });
+    __syncthreads();
+    if (wave == 0)
+        narrowd_for_pairs<NOFF, K1, K0>([&](int k, double v) {
+            const double* s1 = lds + (k - K0) * 64 + lane;
+            const double sum = ((v + s1[0]) + s1[NP * 64]) + s1[2 * NP * 64];
+            const int b = (lane & 15) >> 2, i = lane >> 4, j = lane & 3;
+            if (k < 3 * NT) {
+                const int t = k / 3, s = k - 3 * t, bc = (b + s) & 3;
+                const int row = 16 * t + 4 * b + i, col = 16 * t + 4 * bc + j;
+                if (b + s < 4) P[(int64_t)row * PP + col] = sum;
+                else if (s == 1) P[(int64_t)col * PP + row] = sum;
+            } else {
+                const int kt = k - 3 * NT, gi = kt / (NT + 1), t = kt - gi * (NT + 1);
+                P[(int64_t)(16 * t + 4 * b + i) * PP + 16 * NT + 4 * gi + j] = sum;
+            }
+        });
+    __syncthreads();
+}
+
 // Accumulator registers of a shape, and workgroups per CU: two fit when accumulators + ~72 fragment VGPRs stay within the 256
 // registers two waves per SIMD can have each (up to 6 tiles + one tail group: 182 + 72 = 254) and the two rings fit the
 // LDS (16-row chunks where 32-row ones would not: narrow_kc); one workgroup's LDS waits, barriers and DMA issue then hide
 // under the other's MFMAs (per 1e7 rows: p = 50 1.22 -> 1.06 ms, p = 100 2.32 -> 2.24 ms, p = 96 2.17 -> 2.08 ms).  Wider
 // shapes take a CU alone.  (Splitting the 28 tiles of 112 columns over wave PAIRS -- eight waves, 112 AGPRs each, two per
 // SIMD -- was built and measured in round 1: 2.53 vs 2.55 ms, no gain.)
-constexpr int narrow_nreg(int nt, int g) { return 8 * (nt * (nt + 1) / 2) + 2 * (nt + 1) * g; }
+constexpr int narrow_nreg_full(int nt, int g) { return 8 * (nt * (nt + 1) / 2) + 2 * (nt + 1) * g; }
+// (DIAG4: 6 instead of 8 accumulator registers per diagonal tile, and two more fragments -- the rotated ones -- per tile column)
+constexpr int narrow_nreg(int nt, int g) { return DLSA_NARROW_DIAG4 ? 8 * (nt * (nt - 1) / 2) + 2 * (3 * nt + (nt + 1) * g) : narrow_nreg_full(nt, g); }
 #ifndef DLSA_NARROW_WGS2_MAXREG
 #define DLSA_NARROW_WGS2_MAXREG 184
 #endif
-constexpr int narrow_wgs_per_cu(int nt, int g) { return narrow_nreg(nt, g) <= DLSA_NARROW_WGS2_MAXREG ? 2 : 1; }
+constexpr int narrow_wgs_per_cu(int nt, int g) { return narrow_nreg_full(nt, g) <= DLSA_NARROW_WGS2_MAXREG ? 2 : 1; }      // (the same shapes either way)
 // Rows per chunk: NARROW_KC (32: two k-steps per wave and barrier) unless two workgroups are to share a CU and their
 // rings would not fit the LDS side by side; then 16.
 constexpr int narrow_kc(int nt, int g) {
@@ -174,7 +264,7 @@ constexpr int narrow_kc(int nt, int g) {
     return (narrow_wgs_per_cu(nt, g) == 2 && (size_t)2 * NARROW_STAGES * narrow_buf_elems(ntc, NARROW_KC) * 8 > (size_t)kLdsBytes) ? 16 : NARROW_KC;
 }
 constexpr int narrow_meetn(int nt, int ntc, int kc) {      // tiles per meeting pass: three parked copies must fit in the ring
-    const int ntri = nt * (nt + 1) / 2, fit = (int)((size_t)NARROW_STAGES * narrow_buf_elems(ntc, kc) * 8 / (3 * 2048));
+    const int ntri = DLSA_NARROW_DIAG4 ? nt * (nt - 1) / 2 : nt * (nt + 1) / 2, fit = (int)((size_t)NARROW_STAGES * narrow_buf_elems(ntc, kc) * 8 / (3 * 2048));
     return fit < ntri ? fit : ntri;
 }
 constexpr size_t narrow_lds_bytes(int ntc, int kc) { return (size_t)NARROW_STAGES * narrow_buf_elems(ntc, kc) * 8; }
@@ -188,10 +278,12 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
     constexpr int NTC = NT + (G > 0 ? 1 : 0);            // tile columns staged and read as fragments (the last one partial)
     constexpr int LDP = narrow_pitch(NTC), BUF = narrow_buf_elems(NTC, KC), NTRI = NT * (NT + 1) / 2;
     constexpr int NTAIL = (NT + 1) * G, GA = G > 0 ? G : 1;
+    constexpr int NOFF = NT * (NT - 1) / 2, NPAIR = 3 * NT + NTAIL;      // DIAG4: off-diagonal tiles, pair accumulators
     constexpr int MEETN = narrow_meetn(NT, NTC, KC);
     constexpr int DMA_PER_CHUNK = KC / NWAVES + (HASW ? 1 : 0);        // instructions per wave and chunk
-    static_assert(KC % 16 == 0 && 4 * MEETN >= NTRI, "chunk / meeting shape");
-    static_assert((size_t)3 * NTAIL * 64 <= (size_t)NARROW_STAGES * BUF, "tail meeting fits the ring");
+    static_assert(KC % 16 == 0 && 4 * MEETN >= (DLSA_NARROW_DIAG4 ? NOFF : NTRI), "chunk / meeting shape");
+    constexpr int MEETP = (NARROW_STAGES * BUF) / (3 * 64);              // DIAG4: pairs per meeting pass
+    static_assert(DLSA_NARROW_DIAG4 ? 2 * MEETP >= NPAIR : (size_t)3 * NTAIL * 64 <= (size_t)NARROW_STAGES * BUF, "tail meeting fits the ring");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,7 +347,11 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
         }
     };
 
+#if DLSA_NARROW_DIAG4
+    narrowd_acc_zero<narrow_nreg(NT, G)>();
+#else
     narrow_acc_zero<narrow_nreg(NT, G)>();
+#endif
 
 #pragma unroll
     for (int ch = 0; ch < NARROW_AHEAD; ++ch) stage(ch, ch);
@@ -266,6 +362,11 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
 
     const int frag_off = (lane >> 4) * LDP + (lane & 15);
     const int tail_off = (lane >> 4) * LDP + 16 * NT + (lane & 3);      // the 4 tail columns, broadcast to the 4 blocks
+#if DLSA_NARROW_DIAG4
+    // the fragment's columns rotated by 4 and by 8 inside each group of 16 lanes: the B operands of the diagonal tiles' second and third
+    // small MFMA (the same LDS rows, the same 128-byte segments: conflict-free like frag_off)
+    const int rot1_off = (lane >> 4) * LDP + ((lane + 4) & 15), rot2_off = (lane >> 4) * LDP + ((lane + 8) & 15);
+#endif
     int cur = 0, nxt2 = NARROW_AHEAD % NARROW_STAGES;    // ring positions of chunk c and of the chunk the DMA fetches (c + NARROW_AHEAD)
     for (int c = 0; c < nchunks; ++c) {
 #if !DLSA_NARROW_SPREAD
@@ -274,12 +375,19 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
         const double* base = lds + cur * BUF;
         // all of this wave's fragments of the chunk are requested up front: only the first k-step waits for LDS
         double f[KC / 16][NTC], wv[KC / 16], bt[KC / 16][GA];
+#if DLSA_NARROW_DIAG4
+        double r1[KC / 16][NT], r2[KC / 16][NT];
+#endif
 #pragma unroll
         for (int kk = 0; kk < KC / 16; ++kk) {
             const int ks = wave + 4 * kk;
             const double* kb = base + ks * 4 * LDP;
 #pragma unroll
             for (int t = 0; t < NTC; ++t) f[kk][t] = kb[frag_off + t * 16];
+#if DLSA_NARROW_DIAG4
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { r1[kk][t] = kb[rot1_off + t * 16]; r2[kk][t] = kb[rot2_off + t * 16]; }
+#endif
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) bt[kk][gi] = kb[tail_off + 4 * gi];
             if (HASW) wv[kk] = base[KC * LDP + (DLSA_NARROW_PRIVATE ? (KC / 4) * wave + 4 * kk : ks * 4) + (lane >> 4)];
@@ -297,14 +405,23 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
             // segments of the chunk's first k-step (four row groups, then w): as a burst in front of the block it kept the wave
             // out of MFMAs for its whole issue time (gram_plan_kernel.inc)
             if (kk == 0 && !DLSA_DBG_WRONG(a.dbg, 128)) {
-                narrow_kstep_spread<NT, G, 0>(f[kk], g, btw, [&](int q) {
+                auto between = [&](int q) {
                     if (DLSA_DBG_WRONG(a.dbg, 1)) return;
                     if (q < 4) stage_rows(c + NARROW_AHEAD, nxt2, q); else stage_w(c + NARROW_AHEAD, nxt2);
-                });
+                };
+#if DLSA_NARROW_DIAG4
+                narrowd_kstep_spread<NT, G, 0>(f[kk], g, btw, r1[kk], r2[kk], between);
+#else
+                narrow_kstep_spread<NT, G, 0>(f[kk], g, btw, between);
+#endif
                 continue;
             }
 #endif
+#if DLSA_NARROW_DIAG4
+            if (!DLSA_DBG_WRONG(a.dbg, 128)) narrowd_kstep<NT, G>(f[kk], g, btw, r1[kk], r2[kk]);
+#else
             if (!DLSA_DBG_WRONG(a.dbg, 128)) narrow_kstep<NT, G>(f[kk], g, btw);
+#endif
             else asm volatile("" ::"v"(g[0]), "v"(g[NT - 1]), "v"(btw[0]));
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NARROW_AHEAD - 1) * DMA_PER_CHUNK) : "memory");      // chunk c + 1 has landed
@@ -320,11 +437,20 @@ __global__ __launch_bounds__(256, narrow_wgs_per_cu(NT, G)) void gram_narrow_ker
 
     // the four waves' triangles meet in LDS, MEETN tiles at a time; wave 0 stores the slab's partial
     double* __restrict__ P = a.partial + (int64_t)slab * a.PP * a.PP;
+#if DLSA_NARROW_DIAG4
+    narrowd_meet<0, (MEETN < NOFF ? MEETN : NOFF), MEETN>(lds, wave, lane, P, a.PP);
+    narrowd_meet<MEETN, (2 * MEETN < NOFF ? 2 * MEETN : NOFF), MEETN>(lds, wave, lane, P, a.PP);
+    narrowd_meet<2 * MEETN, (3 * MEETN < NOFF ? 3 * MEETN : NOFF), MEETN>(lds, wave, lane, P, a.PP);
+    narrowd_meet<3 * MEETN, NOFF, MEETN>(lds, wave, lane, P, a.PP);
+    narrowd_meet_pairs<NT, G, 0, (MEETP < NPAIR ? MEETP : NPAIR)>(lds, wave, lane, P, a.PP);
+    narrowd_meet_pairs<NT, G, (MEETP < NPAIR ? MEETP : NPAIR), NPAIR>(lds, wave, lane, P, a.PP);
+#else
     narrow_meet<0, (MEETN < NTRI ? MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<MEETN, (2 * MEETN < NTRI ? 2 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<2 * MEETN, (3 * MEETN < NTRI ? 3 * MEETN : NTRI), MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet<3 * MEETN, NTRI, MEETN>(lds, wave, lane, P, a.PP);
     narrow_meet_tails<NT, G>(lds, wave, lane, P, a.PP);
+#endif
     if (probe && lane == 0) *a.clk = __builtin_readcyclecounter() - t_begin;
 }
 

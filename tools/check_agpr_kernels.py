@@ -173,8 +173,10 @@ def expected_agprs(name):
     m = re.search(r"gram_narrow_kernelILb[01]ELi(\d+)ELi(\d+)EE", name)
     if m:
         nt, g = int(m.group(1)), int(m.group(2))
-        nreg = 8 * (nt * (nt + 1) // 2) + 2 * (nt + 1) * g          # gram_narrow.hip: narrow_nreg
-        return nreg, (256 if nreg <= 184 else 512)                 # narrow_wgs_per_cu: two workgroups of 4 waves per CU
+        full = 8 * (nt * (nt + 1) // 2) + 2 * (nt + 1) * g          # gram_narrow.hip: narrow_nreg_full (decides the workgroups per CU)
+        d4 = 8 * (nt * (nt - 1) // 2) + 2 * (3 * nt + (nt + 1) * g)        # narrow_nreg under -DDLSA_NARROW_DIAG4=1 (round 6 variant: diagonal tiles are three pairs)
+        nreg = d4 if os.environ.get("DLSA_CHECK_NARROW_DIAG4") else full
+        return nreg, (256 if full <= 184 else 512)                 # narrow_wgs_per_cu: two workgroups of 4 waves per CU
     m = re.search(r"irls_pass_narrow_kernelILb[01]ELb1ELi(\d+)ELi(\d+)ELb[01]ELb[01]EE", name)
     if m:                                                          # irls_pass.hip: one wave per SIMD
         nt, g = int(m.group(1)), int(m.group(2))
