@@ -8,7 +8,7 @@ OUT   ?= dlsa_amd/libdlsa_hip.so
 BUILD ?= build
 EXTRA ?=
 SRCS  := $(CSRC)/error.cpp $(CSRC)/options.cpp $(CSRC)/comm.cpp $(CSRC)/gram.hip $(CSRC)/gram_wide.hip $(CSRC)/gram_narrow.hip $(CSRC)/gram_cyclic.hip $(CSRC)/gram_plan.hip $(CSRC)/logit.hip $(CSRC)/dense.hip $(CSRC)/chol.hip $(CSRC)/eigsolve.hip $(CSRC)/synth.hip $(CSRC)/design.hip $(CSRC)/onehot.hip \
-         $(CSRC)/irls.hip $(CSRC)/irls_small.hip $(CSRC)/irls_pass.hip $(CSRC)/irls_batch.hip $(CSRC)/irls_wide.hip $(CSRC)/lars.hip $(CSRC)/lars_q.hip
+         $(CSRC)/irls.hip $(CSRC)/irls_small.hip $(CSRC)/irls_pass.hip $(CSRC)/irls_batch.hip $(CSRC)/irls_wide.hip $(CSRC)/lars.hip $(CSRC)/lars_q.hip $(CSRC)/lars_c.hip
 # the plan-driven fp64 Gram kernel: one translation unit per range of widths (C_LO_HI = CUs per slab group, full tiles),
 # each compiled from gram_plan_unit.hip with the plans tools/gen_gram_plan_asm.py writes into $(BUILD)/gen at build time
 PLAN_UNITS := 1_8_17 2_18_24 4_25_28 4_29_32 4_33_35

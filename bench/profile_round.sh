@@ -57,12 +57,12 @@ def line(path):
 un, pr = line("$OUT/bench_default.json"), line("$OUT/bench_under_rocprof.json")
 if un and pr:
     kname = un["roofline"]["kernel"].split("dlsa::")[1].split(" ")[0]
-    csv_avg = [v["avg_ms"] for k, v in out["kernel_ms"].items() if kname in k]
+    csv_avg = [v["avg_ms"] for k, v in out["kernel_ms"].items() if kname.replace(" ", "") in k.replace(" ", "")]
     out["same_call"] = {"kernel": kname, "unprofiled_kernel_ms": un["roofline"]["kernel_ms"], "unprofiled_clock_GHz": un["roofline"]["shader_clock_GHz"],
                         "unprofiled_ms_per_step": un["ms_per_step"], "profiled_kernel_ms_hip_events": pr["roofline"]["kernel_ms"],
                         "profiled_clock_GHz": pr["roofline"]["shader_clock_GHz"], "rocprof_csv_avg_ms": csv_avg[0] if csv_avg else None,
                         "rocprof_over_unprofiled": (csv_avg[0] / un["roofline"]["kernel_ms"]) if csv_avg else None,
-                        "note": "one gpurun call: `python3 bench.py --gpus 1 --steps 20 --warmup 5`, then the same command with "
+                        "note": "one gpurun call: python3 bench.py --gpus 1 --steps 20 --warmup 5, then the same command with "
                                 "--no-cpu-baseline --no-e2e under rocprofv3 --kernel-trace --stats"}
     print(json.dumps(out["same_call"], indent=1))
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1, sort_keys=True)

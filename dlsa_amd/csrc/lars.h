@@ -38,4 +38,11 @@ bool lars_q_eligible(int p, int intercept);
 // returns DLSA_OK with *aborted = 1 when a clustered launch gave up at its barrier (nothing usable was written: run again with max_wgs = 1)
 int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used);
 
+// lars_c.hip (round 6): the same carried rows for WIDE problems (LARS_Q_MAX_M < m <= LARS_C_MAX_M), the fused pass split by COLUMNS over
+// up to LARS_C_MAX_WGS workgroups that meet at one bounded grid barrier per append; *n_steps = -1 when a barrier gave up (the caller
+// reruns the path on lars.hip's single-workgroup kernel)
+constexpr int LARS_C_MAX_M = 2044, LARS_C_MAX_WGS = 64;
+bool lars_c_eligible(int p, int intercept);
+int lars_c_run(LarsArgs& a, int p, int intercept, hipStream_t s, int* wgs_used);
+
 }  // namespace dlsa

@@ -1042,7 +1042,23 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
         if (n_steps_host) *n_steps_host = steps;
         return DLSA_OK;
     }
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    int first_attempt = 0;
+    if (lars_c_eligible(p, intercept)) {
+        // 1021 .. 2044 variables: the carried rows with the pass split by columns over up to 64 workgroups (lars_c.hip); a launch that gave
+        // up at its bounded grid barrier is rerun on the single-workgroup kernel below
+        std::unique_lock<std::mutex> grid_lock(g_lars_grid_mu);
+        const int rc = lars_c_run(a, p, intercept, s, &wgs_used);
+        if (rc) return rc;
+        DLSA_HIP_CHECK(hipMemcpyAsync(&steps, a.n_steps, sizeof(int), hipMemcpyDeviceToHost, s));
+        DLSA_HIP_CHECK(hipStreamSynchronize(s));
+        if (steps >= 0) {
+            if (n_steps_host) *n_steps_host = steps;
+            return DLSA_OK;
+        }
+        g_lars_grid_aborts.fetch_add(1);
+        first_attempt = 1;
+    }
+    for (int attempt = first_attempt; attempt < 2; ++attempt) {
         // the triangular mat-vecs rely on zeros in the unused triangles and in the slack
         DLSA_HIP_CHECK(hipMemsetAsync(a.Rinv, 0, (m * ld + LARS_SLACK) * 8, s));
         DLSA_HIP_CHECK(hipMemsetAsync(a.RinvT, 0, (m * ld + LARS_SLACK) * 8, s));

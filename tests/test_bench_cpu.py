@@ -204,12 +204,12 @@ def test_committed_kernel_evidence_matches_the_tree():
 
 
 def test_committed_eight_rank_dry_run_line_is_consistent_with_the_one_rank_line():
-    """profiles/r05_bench_gloo8_dryrun.json: `DLSA_BENCH_BACKEND=gloo python bench.py --gpus 8 --rows-per-gpu 2000000` (eight ranks
-    SHARING one GPU over gloo: the N > 1 code path of the line, rates meaningless) against profiles/r05_bench_rows2e6_n1.json, the N = 1
+    """profiles/r06_bench_gloo8_dryrun.json: `DLSA_BENCH_BACKEND=gloo python bench.py --gpus 8 --rows-per-gpu 2000000` (eight ranks
+    SHARING one GPU over gloo: the N > 1 code path of the line, rates meaningless) against profiles/r06_bench_rows2e6_n1.json, the N = 1
     line at the same rows per GPU: same metric / dtype / unit / rows per GPU / workload kernel, value = N x value_per_gpu, the ranks
     counted from the communicator, a strong-scaling leg that kept the metric's kernel."""
-    n8 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_gloo8_dryrun.json")))
-    n1 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_rows2e6_n1.json")))
+    n8 = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_gloo8_dryrun.json")))
+    n1 = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_rows2e6_n1.json")))
     assert n8["n_gpus"] == 8 and n1["n_gpus"] == 1
     for key in ("metric", "unit", "dtype", "higher_is_better", "scaling", "data", "steps", "warmup"):
         assert n8[key] == n1[key], key

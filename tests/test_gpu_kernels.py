@@ -649,3 +649,56 @@ print("cooperative ok")
 ''' % (ROOT,)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "cooperative ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("p,rho,seed,intercept,typ", [(1030, 0.9, 3, True, "lasso"), (1101, 0.97, 11, False, "lasso"), (1536, 0.5, 5, False, "lar"),
+                                                      (2000, 0.9, 7, True, "lasso"), (2045, 0.5, 9, True, "lar")])
+def test_lars_column_split_kernel_matches_the_grid_kernel(eng, orc, kopt, p, rho, seed, intercept, typ):
+    """lsa.py:90-212 for 1021 .. 2044 penalised variables: lars_c.hip (round 6: the carried Cholesky rows, the pass split by columns
+    over up to 64 workgroups) walks the same path as lars.hip's R^{-1} form on the same problem -- lasso paths with drops, an odd
+    variable count (padded row stride), the intercept branch, the widest problem it takes (p = 2045 with the intercept) -- and as the
+    oracle where the oracle finishes in seconds (p = 1030)."""
+    S, b, n = _correlated_lsa_problem(p, rho, seed)
+    Sd, bd = dev(S), dev(b)
+    r = eng.lars_path(Sd, bd, intercept, float(n), type=typ)
+    kopt.set(lars_q=0)                       # lars.hip's grid kernel (what these widths ran on up to round 5)
+    r0 = eng.lars_path(Sd, bd, intercept, float(n), type=typ)
+    assert r["beta"].shape == r0["beta"].shape
+    if typ == "lasso" and rho > 0.8:
+        assert r["beta"].shape[0] > (p - int(intercept)) + 1          # the path has drops
+    for key in ("beta", "AIC", "BIC") + (("beta0",) if intercept else ()):
+        assert rel_inf(r[key].cpu().numpy(), r0[key].cpu().numpy()) < 1e-7, key
+    if p <= 1030:
+        ro = orc.lars_lsa(S, b, intercept, n, type=typ)
+        assert r["beta"].shape == ro["beta"].shape
+        assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7 and rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
+        assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7
+
+
+@pytest.mark.parametrize("wgs", [2, 17, 33, 64])
+def test_lars_column_split_kernel_any_workgroup_count(eng, kopt, wgs):
+    """the workgroup count decides which columns a workgroup owns and how many row groups sum them, never the path"""
+    S, b, n = _correlated_lsa_problem(1101, 0.97, 11)
+    Sd, bd = dev(S), dev(b)
+    r0 = eng.lars_path(Sd, bd, True, float(n), type="lasso")
+    kopt.set(lars_wgs=wgs)
+    r = eng.lars_path(Sd, bd, True, float(n), type="lasso")
+    assert r["beta"].shape == r0["beta"].shape
+    assert rel_inf(r["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-8 and rel_inf(r["beta0"].cpu().numpy(), r0["beta0"].cpu().numpy()) < 1e-8
+
+
+def test_lars_column_split_barrier_timeout_falls_back_to_one_workgroup(eng, kopt):
+    """a grid barrier of lars_c.hip that times out aborts the launch; the host reruns the path on lars.hip's single-workgroup kernel"""
+    from dlsa_amd import _lib
+    lib = _lib.load()
+    S, b, n = _correlated_lsa_problem(1040, 0.5, 2)
+    Sd, bd = dev(S), dev(b)
+    r0 = eng.lars_path(Sd, bd, False, float(n), type="lar")
+    before = lib.dlsa_lars_grid_barrier_timeout(1e-9)
+    try:
+        r = eng.lars_path(Sd, bd, False, float(n), type="lar")
+        after = lib.dlsa_lars_grid_barrier_timeout(0.0)
+    finally:
+        lib.dlsa_lars_grid_barrier_timeout(0.0)
+    assert after > before
+    assert r["beta"].shape == r0["beta"].shape and rel_inf(r["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
