@@ -27,7 +27,7 @@ def timed(fn, reps=3):
     return sorted(ts)[len(ts) // 2], r
 
 
-for p in [int(v) for v in sys.argv[1:]] or [1100, 1536, 2000]:
+for p in ([int(v) for v in sys.argv[1:]] or [1100, 1536, 2000]) if __name__ == "__main__" else []:
     for intercept, typ in ((False, "lar"), (True, "lasso")):
         S, b, n = problem(p, 0.5, 777 + p)
         St, bt = torch.from_numpy(S).cuda(), torch.from_numpy(b).cuda()

@@ -38,10 +38,12 @@ bool lars_q_eligible(int p, int intercept);
 // returns DLSA_OK with *aborted = 1 when a clustered launch gave up at its barrier (nothing usable was written: run again with max_wgs = 1)
 int lars_q_run(LarsArgs& a, int p, int intercept, hipStream_t s, int max_wgs, int* wgs_used);
 
-// lars_c.hip (round 6): the same carried rows for WIDE problems (LARS_Q_MAX_M < m <= LARS_C_MAX_M), the fused pass split by COLUMNS over
+// lars_c.hip (round 6): the same carried rows for WIDE problems (LARS_C_MIN_M < m <= LARS_C_MAX_M), the fused pass split by COLUMNS over
 // up to LARS_C_MAX_WGS workgroups that meet at one bounded grid barrier per append; *n_steps = -1 when a barrier gave up (the caller
 // reruns the path on lars.hip's single-workgroup kernel)
 constexpr int LARS_C_MAX_M = 2044, LARS_C_MAX_WGS = 64;
+constexpr int LARS_C_MIN_M = 448;                   // narrower problems: lars_q.hip (same box, lasso paths, lars_q.hip / lars_c.hip: p = 400 3.70 / 3.59 ms, 500 5.10 / 4.61,
+                                                    // 640 9.31 / 6.26, 1020 20.8 / 12.1: profiles/r06_lars_column_split.txt)
 bool lars_c_eligible(int p, int intercept);
 int lars_c_run(LarsArgs& a, int p, int intercept, hipStream_t s, int* wgs_used);
 

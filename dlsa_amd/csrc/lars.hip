@@ -1020,8 +1020,9 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
     // gives the launch up: 0.25 s
     a.bar_timeout = g_lars_barrier_timeout_ticks.load();
     int steps = 0, wgs_used = 1;
-    if (lars_q_eligible(p, intercept)) {
-        // up to 1020 variables: the carried Cholesky rows (lars_q.hip) -- one workgroup, or a few that share the fused pass and meet
+    const bool use_c = lars_c_eligible(p, intercept);
+    if (!use_c && lars_q_eligible(p, intercept)) {
+        // up to 448 variables (1020 when the column-split kernel is switched off): the carried Cholesky rows (lars_q.hip) -- one workgroup, or a few that share the fused pass and meet
         // at a bounded grid barrier (a launch that gave up there is rerun on one workgroup).  Every entry of its matrices is written
         // before it is read, so nothing is cleared.
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1043,8 +1044,8 @@ int dlsa_lars_lsa_f64(const double* Sigma0, int64_t lds, const double* b0, int p
         return DLSA_OK;
     }
     int first_attempt = 0;
-    if (lars_c_eligible(p, intercept)) {
-        // 1021 .. 2044 variables: the carried rows with the pass split by columns over up to 64 workgroups (lars_c.hip); a launch that gave
+    if (use_c) {
+        // 449 .. 2044 variables: the carried rows with the pass split by columns over up to 64 workgroups (lars_c.hip); a launch that gave
         // up at its bounded grid barrier is rerun on the single-workgroup kernel below
         std::unique_lock<std::mutex> grid_lock(g_lars_grid_mu);
         const int rc = lars_c_run(a, p, intercept, s, &wgs_used);

@@ -1,4 +1,4 @@
-// LARS / lasso path of the least-squares approximation for WIDE problems (LARS_Q_MAX_M < m = p - intercept <= LARS_C_MAX_M): the
+// LARS / lasso path of the least-squares approximation for WIDE problems (LARS_C_MIN_M < m = p - intercept <= LARS_C_MAX_M): the
 // carried Cholesky rows of lars_q.hip with the fused pass split by COLUMNS over 16 .. 64 workgroups (round 6; reference: lars_lsa and
 // updateR, dlsa/lsa.py:12-32, 90-212).
 //
@@ -574,13 +574,21 @@ __global__ __launch_bounds__(CT) void lars_c_kernel(LarsArgs a) {
 
 }  // namespace
 
-// Wide paths: LARS_Q_MAX_M < m <= LARS_C_MAX_M.  dlsa_kernel_options.lars_q = 0 keeps lars.hip's kernels for every width (A/B runs,
-// tests of both forms), as for lars_q.hip.
+// Wide paths: LARS_C_MIN_M < m <= LARS_C_MAX_M.  dlsa_kernel_options.lars_q = 0 keeps lars.hip's kernels for every width (A/B runs,
+// tests of both forms), as for lars_q.hip; 2 takes this kernel for every width it can (the crossover runs of bench/lars_crossover.py).
+// Tried and dropped: the transpose of Q beside Q, so that the next append's r is one contiguous read instead of a 16 KB-strided
+// gather -- 3.4 -> 3.0 us of a step at m = 2000, the path's time unchanged (35.0 ms): the gather waits for a fabric round trip to rows
+// other XCDs wrote (every grid barrier's agent-scope acquire empties this XCD's L2), not for its own access pattern.
 bool lars_c_eligible(int p, int intercept) {
     const int m = p - (intercept ? 1 : 0);
-    if (m <= LARS_Q_MAX_M || m > LARS_C_MAX_M) return false;
-    if (const char* e = kernel_knob("DLSA_LARS_Q")) return atoi(e) != 0;
-    return lars_c_lds_bytes(m) + 1024 <= (size_t)kLdsBytes;
+    if (m > LARS_C_MAX_M || lars_c_lds_bytes(m) + 1024 > (size_t)kLdsBytes) return false;
+    // dlsa_kernel_options.lars_q: automatic = the measured hand-over (LARS_C_MIN_M); 0: lars.hip for every width; 1: lars_q.hip for every
+    // width it takes (<= LARS_Q_MAX_M), this kernel beyond; 2: this kernel for every width it can take (A/B runs, tests)
+    const char* e = kernel_knob("DLSA_LARS_Q");
+    if (!e) return m > LARS_C_MIN_M;
+    const int mode = atoi(e);
+    if (mode == 0) return false;
+    return mode == 2 ? m >= 64 : m > LARS_Q_MAX_M;
 }
 
 // Workgroups: two 16-column blocks of Q (and of RT) per workgroup -- m = 2000: 63 workgroups of 32 column-pair slots x 16 row groups;

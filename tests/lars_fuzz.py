@@ -48,10 +48,13 @@ def main():
         typ = "lasso" if rng.random() < 0.6 else "lar"
         rho = float(rng.choice([0.0, 0.5, 0.9, 0.98]))
         S, b, n = problem(p, rho, 31000 + c)
+        # (DLSA_LARS_Q = 1: lars_q.hip up to 1020 variables -- the default hands m > 448 to lars_c.hip -- and lars_c.hip beyond, there with a
+        # forced workgroup count)
         forced = {"DLSA_LARS_Q_THREADS": str(rng.choice([256, 512, 1024])), "DLSA_LARS_Q_LDS": str(rng.integers(0, 2)),
-                  "DLSA_LARS_Q_WGS": str(rng.choice([1, 2, 3, 5, 8]))}
+                  "DLSA_LARS_Q_WGS": str(rng.choice([1, 2, 3, 5, 8])), "DLSA_LARS_Q": "1"}
+        if p > 1020: forced["DLSA_LARS_WGS"] = str(rng.choice([3, 16, 29, 64]))
         got = [run(S, b, intercept, n, typ, {}), run(S, b, intercept, n, typ, forced), run(S, b, intercept, n, typ, {"DLSA_LARS_Q": "0"})]
-        ref = orc.lars_lsa(S, b, intercept, n, type=typ) if p <= 420 else got[2]
+        ref = orc.lars_lsa(S, b, intercept, n, type=typ) if p <= 420 else got[2]      # (beyond: lars.hip's R^{-1} form, a different method, is the reference)
         kinds["oracle" if p <= 420 else "kernels only"] = kinds.get("oracle" if p <= 420 else "kernels only", 0) + 1
         kinds["drops"] = kinds.get("drops", 0) + int(ref["beta"].shape[0] - 1 > p - int(intercept))
         for g in got:

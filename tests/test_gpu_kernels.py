@@ -492,7 +492,11 @@ def test_lars_q_clusters_barrier_timeout_falls_back_and_counts_agree(eng, orc, k
     assert after > before
     assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7
     S, b, n = _correlated_lsa_problem(700, 0.9, 19)
+    kopt.set(lars_q=1)                       # (lars_q.hip up to 1020 variables: since round 6 the column-split kernel takes m > 448 by default)
     rq = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
+    kopt.clear("lars_q")
+    rc = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")         # the default at this width: lars_c.hip
+    assert rc["beta"].shape == rq["beta"].shape and rel_inf(rc["beta"].cpu().numpy(), rq["beta"].cpu().numpy()) < 1e-7
     kopt.set(lars_q=0)
     r0 = eng.lars_path(dev(S), dev(b), True, float(n), type="lasso")
     assert rq["beta"].shape == r0["beta"].shape
@@ -673,6 +677,20 @@ def test_lars_column_split_kernel_matches_the_grid_kernel(eng, orc, kopt, p, rho
         assert r["beta"].shape == ro["beta"].shape
         assert rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7 and rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7
         assert rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7
+
+
+def test_lars_column_split_kernel_on_reference_cases_and_narrow_widths(eng, orc, kopt):
+    """lars_c.hip forced onto every width it can take (lars_q = 2): the reference goldens incl. drops and the intercept (m = 64 .. 260),
+    and the widths around the hand-over from lars_q.hip (m = 449 by default) against the oracle"""
+    kopt.set(lars_q=2)
+    _lars_reference_cases(eng, orc)
+    kopt.clear("lars_q")
+    for p, intercept in ((449, False), (450, True), (520, True)):
+        S, b, n = _correlated_lsa_problem(p, 0.95, 100 + p)
+        ro = orc.lars_lsa(S, b, intercept, n, type="lasso")
+        r = eng.lars_path(dev(S), dev(b), intercept, float(n), type="lasso")
+        assert r["beta"].shape == ro["beta"].shape and rel_inf(r["beta"].cpu().numpy(), ro["beta"]) < 1e-7, p
+        assert rel_inf(r["BIC"].cpu().numpy(), ro["BIC"]) < 1e-7 and rel_inf(r["beta0"].cpu().numpy(), ro["beta0"]) < 1e-7
 
 
 @pytest.mark.parametrize("wgs", [2, 17, 33, 64])
