@@ -521,11 +521,11 @@ def irls_options(options=None, **fields):
 class KernelOptions:
     """Which build of a kernel runs (never what it returns) for the calls inside `with engine.kernel_options(...)`:
     include/dlsa_hip.h dlsa_kernel_options, field for field.  None = automatic.  The library reads no environment variable for these."""
-    lars_q: Optional[bool] = None           # LARS on carried Cholesky rows (lars_q.hip) up to 1020 variables
+    lars_q: Optional[int] = None            # LARS form: 0 lars.hip everywhere; 1 lars_q.hip up to 1020 variables, lars_c.hip beyond; 2 lars_c.hip from 64; None: the measured hand-over (448)
     lars_q_wgs: Optional[int] = None        # workgroups that share its fused pass, 1..8
     lars_q_threads: Optional[int] = None    # 256 | 512 | 1024
     lars_q_lds: Optional[bool] = None
-    lars_wgs: Optional[int] = None          # workgroups of lars.hip's grid kernel, 1..32
+    lars_wgs: Optional[int] = None          # workgroups of lars.hip's grid kernel (1..32) / of lars_c.hip's column split (2..64)
     lars_threads: Optional[int] = None      # 512 | 1024
     logit_ring: Optional[bool] = None       # narrow designs' logit pass through the LDS-DMA ring
     chol_small: Optional[bool] = None       # one-launch SPD inverse for p <= 112

@@ -177,11 +177,12 @@ typedef struct dlsa_irls_options {
  * them (builds made with -DDLSA_DEBUG_KNOBS, `make knobs`, still do, for fields left on automatic).  No reference counterpart. */
 typedef struct dlsa_kernel_options {
     int struct_bytes;    /* sizeof(dlsa_kernel_options), set by dlsa_kernel_options_init                                  */
-    int lars_q;          /* LARS on carried Cholesky rows (lars_q.hip) up to 1020 variables; 0 = lars.hip's kernels        */
+    int lars_q;          /* LARS form: 0 = lars.hip everywhere; 1 = lars_q.hip up to 1020 variables, lars_c.hip beyond;     */
+                         /* 2 = lars_c.hip from 64 variables; automatic: lars_q.hip up to 448, lars_c.hip up to 2044       */
     int lars_q_wgs;      /* workgroups that share lars_q's fused pass: 1..8                                                */
     int lars_q_threads;  /* its workgroup size: 256 | 512 | 1024                                                           */
     int lars_q_lds;      /* its matrices in LDS where they fit; 0 = global memory                                          */
-    int lars_wgs;        /* workgroups of lars.hip's grid kernel: 1..32                                                    */
+    int lars_wgs;        /* workgroups of lars.hip's grid kernel (1..32) / of lars_c.hip's column split (2..64)            */
     int lars_threads;    /* lars.hip's workgroup size: 512 | 1024                                                          */
     int logit_ring;      /* narrow designs' logit pass through the fused pass's LDS-DMA ring; 0 = register loads           */
     int chol_small;      /* one-launch SPD inverse for p <= 112; 0 = the blocked Cholesky                                  */
@@ -295,9 +296,11 @@ int dlsa_sym_pinv_solve_f64(const double* S, int64_t lds, const double* v, int p
  * Sigma0 p x p, b0 p (device).  type 0 = 'lar', 1 = 'lasso'.  max_steps <= 0 -> 8*m.
  * Outputs (device): beta_path (max_steps+1) x m row-major (m = p - intercept), beta0,
  * aic, bic (max_steps+1 each); n_steps_host = number of steps taken (path has n_steps+1
- * rows).  Runs as one persistent kernel on the device.  Up to 1020 variables the carried-rows
+ * rows).  Runs as one persistent kernel on the device.  Up to 448 variables the carried-rows
  * form (lars_q.hip): one workgroup up to 200 variables, 4 (beyond 420: 8) workgroups that share
- * the fused pass above; beyond 1020 a grid of up to 32 workgroups (lars.hip, two grid barriers
+ * the fused pass above; 449 .. 2044 variables the same rows with the pass split by COLUMNS over
+ * 16 .. 64 workgroups (lars_c.hip, round 6: one grid barrier per append; p = 2000 in 35 ms);
+ * beyond, a grid of up to 32 workgroups on the R^-1 form (lars.hip, two grid barriers
  * per step).  The multi-workgroup kernels need their workgroups resident together: plain
  * launches whose barrier waits are bounded (0.25 s) -- a launch that gives up is rerun on a
  * single workgroup: slower, same path; DLSA_ERR_HIP only if that is impossible -- and whose
