@@ -151,7 +151,10 @@ __device__ __forceinline__ void c_col_mv(const CLayout& L, const double* __restr
     const bool mine = L.live && (L.isq ? Qm != nullptr : L.c2 < ncolR);
     if (mine) {
         double2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
-        constexpr int NB = 8;                    // 16-byte row loads in flight per thread: 64 KB per workgroup
+#ifndef DLSA_LARS_C_NB
+#define DLSA_LARS_C_NB 8
+#endif
+        constexpr int NB = DLSA_LARS_C_NB;       // 16-byte row loads in flight per thread (8: 64 KB per workgroup)
         const int RG = L.RG;
         int i = L.rg;
         if (!L.isq && L.c2 > i) i += (L.c2 - i + RG - 1) / RG * RG;      // column pair (c2, c2 + 1) of RT exists from row c2 on

@@ -720,3 +720,17 @@ def test_lars_column_split_barrier_timeout_falls_back_to_one_workgroup(eng, kopt
         lib.dlsa_lars_grid_barrier_timeout(0.0)
     assert after > before
     assert r["beta"].shape == r0["beta"].shape and rel_inf(r["beta"].cpu().numpy(), r0["beta"].cpu().numpy()) < 1e-7
+
+
+def test_lars_column_split_kernel_is_bit_reproducible(eng):
+    """every workgroup of lars_c.hip reads rows other workgroups wrote (behind one grid barrier per append): a stale read would show
+    as run-to-run differences.  Twelve runs of a lasso path with drops at the default count and at 29 workgroups: bit-identical."""
+    S, b, n = _correlated_lsa_problem(1101, 0.97, 11)
+    Sd, bd = dev(S), dev(b)
+    from dlsa_amd import engine
+    for wgs in (None, 29):
+        with engine.kernel_options(lars_wgs=wgs) if wgs else engine.kernel_options():
+            r0 = eng.lars_path(Sd, bd, True, float(n), type="lasso")
+            for _ in range(11):
+                r = eng.lars_path(Sd, bd, True, float(n), type="lasso")
+                assert torch.equal(r["beta"], r0["beta"]) and torch.equal(r["BIC"], r0["BIC"]) and torch.equal(r["beta0"], r0["beta0"])
