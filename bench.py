@@ -233,6 +233,7 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches the "
                          "ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL's intra-node transport needs it on this pool); set before torch loads
     if args.watchdog_seconds > 0:
         import faulthandler
         faulthandler.enable()

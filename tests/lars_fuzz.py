@@ -54,7 +54,9 @@ def main():
                   "DLSA_LARS_Q_WGS": str(rng.choice([1, 2, 3, 5, 8])), "DLSA_LARS_Q": "1"}
         if p > 1020: forced["DLSA_LARS_WGS"] = str(rng.choice([3, 16, 29, 64]))
         got = [run(S, b, intercept, n, typ, {}), run(S, b, intercept, n, typ, forced), run(S, b, intercept, n, typ, {"DLSA_LARS_Q": "0"})]
-        ref = orc.lars_lsa(S, b, intercept, n, type=typ) if p <= 420 else got[2]      # (beyond: lars.hip's R^{-1} form, a different method, is the reference)
+        if p - int(intercept) >= 64:       # the column-split kernel forced onto widths it does not take by default (it serves m >= 64), at a random workgroup count
+            got.insert(2, run(S, b, intercept, n, typ, {"DLSA_LARS_Q": "2", "DLSA_LARS_WGS": str(rng.choice([2, 5, 16, 64]))}))
+        ref = orc.lars_lsa(S, b, intercept, n, type=typ) if p <= 420 else got[-1]      # (beyond: lars.hip's R^{-1} form, a different method, is the reference)
         kinds["oracle" if p <= 420 else "kernels only"] = kinds.get("oracle" if p <= 420 else "kernels only", 0) + 1
         kinds["drops"] = kinds.get("drops", 0) + int(ref["beta"].shape[0] - 1 > p - int(intercept))
         for g in got:

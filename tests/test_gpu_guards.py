@@ -170,10 +170,22 @@ def _run_bench(extra_env, *argv):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    # (--watchdog-seconds: a rank that hangs prints its Python stacks and exits; the message lands in the assertion below)
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--watchdog-seconds", "150"] + list(argv), env=env,
-                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert pr.returncode == 0, pr.stderr[-6000:]
+    # (--watchdog-seconds: a rank that hangs prints its Python stacks and exits; the message lands in the assertion below.  Round 6 saw
+    # ONE run of the two-rank line in ~120 stop making progress inside a pytest parent -- not reproduced since, lab notes r06 section 5 --
+    # so a run that ended on the watchdog or the timeout is repeated once, with a warning that carries the first attempt's output)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--watchdog-seconds", "150"] + list(argv)
+    for attempt in (0, 1):
+        try:
+            pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+            hung = pr.returncode != 0 and "Timeout (" in pr.stderr
+            err = pr.stderr
+        except subprocess.TimeoutExpired as e:
+            hung, err, pr = True, str(e.stderr)[-6000:], None
+        if not hung or attempt == 1:
+            break
+        import warnings
+        warnings.warn("bench.py %s stopped making progress and was repeated; first attempt's stderr tail:\n%s" % (" ".join(argv), err[-3000:]))
+    assert pr is not None and pr.returncode == 0, err[-6000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, pr.stdout
     return json.loads(lines[0])
